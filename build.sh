@@ -1,0 +1,21 @@
+#!/usr/bin/env bash
+# Build libuniver_hip.so (gfx950) in-tree.  hipcc cross-compiles without a GPU.
+set -euo pipefail
+ROOT="$(cd "$(dirname "$0")" && pwd)"
+SRC="$ROOT/univer-ocr_amd/csrc"
+OUT="$ROOT/univer-ocr_amd/libuniver_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" -I"$SRC" -Wall -Wno-unused-function -Wno-unused-value)
+mkdir -p "$SRC/.obj"
+pids=()
+for f in "$SRC"/*.hip; do
+  o="$SRC/.obj/$(basename "${f%.hip}").o"
+  if [[ ! -f "$o" || "$f" -nt "$o" || "$SRC/uocr_common.h" -nt "$o" || "$ROOT/include/univer_hip.h" -nt "$o" \
+        || -n "$(find "$SRC" -name '*.h' -newer "$o" -print -quit)" ]]; then
+    "$HIPCC" "${FLAGS[@]}" -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$SRC"/.obj/*.o
+echo "built $OUT"

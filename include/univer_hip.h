@@ -1,0 +1,176 @@
+/*
+ * univer_hip.h -- C ABI of libuniver_hip.so, the MI355X (gfx950) backend of the
+ * univer-ocr self-written deep-learning framework (KerkDovan/univer-ocr).
+ *
+ * The reference has no FFI: its device seam is `CP` (web_app/components/nn/gpu.py:5-29) plus the
+ * per-layer closure pair `_forward_gpu/_backward_gpu` (nn/layers/layers.py:169-197), implemented
+ * with CuPy and numba.cuda JIT kernels.  Every entry point below replaces one of those closures
+ * (or one CuPy expression on the hot path) and cites the reference lines it stands in for.
+ * Paths are relative to /root/reference/web_app/components/nn/.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all tensor pointers are DEVICE pointers, caller-owned,
+ *    C-contiguous, NHWC for images, (kh,kw,Cin,Cout) for conv weights, (n_in+1,n_out) with the
+ *    bias as the LAST ROW for dense weights (layers.py:326-338);
+ *  - `dtype` selects the arithmetic/storage type of every tensor argument of the call:
+ *    UOCR_F32 (the production type) or UOCR_F64 (the reference's own type, used by the parity
+ *    and numeric-gradient tests);
+ *  - every function returns 0 (UOCR_OK) or a negative UOCR_ERR_* code and never throws;
+ *    uocr_last_error(ctx) returns a human readable message for the last failure on that ctx;
+ *  - all work is enqueued asynchronously on the ctx's HIP stream; nothing synchronises unless
+ *    its name ends in _sync.  No call allocates device memory after uocr_ctx_create /
+ *    uocr_ctx_reserve_workspace, so a sequence of calls can be captured into a HIP graph;
+ *  - loss scalars are written as float64 to a caller-provided device slot and fetched by the
+ *    caller when it wants them (the reference does `float(loss)` = one D2H sync per loss).
+ */
+#ifndef UNIVER_HIP_H
+#define UNIVER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UOCR_ABI_VERSION 1
+
+typedef struct uocr_ctx uocr_ctx;
+
+enum { UOCR_F32 = 0, UOCR_F64 = 1 };
+enum { UOCR_ACT_NONE = 0, UOCR_ACT_RELU = 1, UOCR_ACT_LEAKY = 2, UOCR_ACT_SIGMOID = 3 };
+enum { UOCR_LOSS_DICE = 0, UOCR_LOSS_JACCARD = 1 };
+enum {
+    UOCR_OK = 0,
+    UOCR_ERR_ARG = -1,         /* null pointer, negative size, inconsistent shape */
+    UOCR_ERR_DTYPE = -2,       /* dtype is not UOCR_F32 / UOCR_F64 */
+    UOCR_ERR_HIP = -3,         /* a HIP runtime call failed (see uocr_last_error) */
+    UOCR_ERR_WORKSPACE = -4,   /* ctx workspace too small: call uocr_ctx_reserve_workspace */
+    UOCR_ERR_UNSUPPORTED = -5  /* shape outside what the kernels implement */
+};
+
+/* ---- context, memory, events (stand in for CP / cupy, gpu.py:5-29) ------------------------- */
+int uocr_abi_version(void);
+int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out);
+int uocr_ctx_destroy(uocr_ctx* ctx);
+/* run on a caller-owned hipStream_t (0 = the legacy default stream) instead of the ctx's own */
+int uocr_ctx_set_stream(uocr_ctx* ctx, void* hip_stream);
+void* uocr_ctx_get_stream(uocr_ctx* ctx);
+int uocr_ctx_reserve_workspace(uocr_ctx* ctx, size_t bytes);   /* synchronises; not capturable */
+const char* uocr_last_error(uocr_ctx* ctx);
+int uocr_malloc(uocr_ctx* ctx, size_t bytes, void** out);                       /* cupy.zeros/asarray */
+int uocr_free(uocr_ctx* ctx, void* ptr);
+int uocr_memset_zero(uocr_ctx* ctx, void* ptr, size_t bytes);                   /* Param.clear_grad, layers.py:20-21 */
+int uocr_h2d(uocr_ctx* ctx, void* dst, const void* src_host, size_t bytes);     /* CP.copy, gpu.py:19-23 */
+int uocr_d2h_sync(uocr_ctx* ctx, void* dst_host, const void* src, size_t bytes);/* CP.asnumpy, gpu.py:25-29 */
+int uocr_d2d(uocr_ctx* ctx, void* dst, const void* src, size_t bytes);
+int uocr_stream_sync(uocr_ctx* ctx);                                            /* cuda.synchronize() */
+int uocr_event_create(void** out_event);
+int uocr_event_destroy(void* event);
+int uocr_event_record(uocr_ctx* ctx, void* event);
+int uocr_event_elapsed_ms_sync(void* start, void* stop, float* out_ms);
+/* name, CU count, HBM bytes of the ctx's device (train.py:70-90 prints the numba equivalents) */
+int uocr_device_info(uocr_ctx* ctx, char* name_out, size_t name_cap, int* cu_count, size_t* hbm_bytes);
+
+/* ---- Convolutional2D (layers/convolutional.py) -------------------------------------------- */
+/* y[b,oy,ox,:] = sum_{ky,kx,ic} x~[b,oy*sh-ph+ky,ox*sw-pw+kx,ic] * w[ky,kx,ic,:] (+ b if use_bias),
+ * x~ = x inside, pad_value outside (convolutional.py:62-99; GPU kernel :153-195).  OH/OW follow
+ * convolutional.py:290-301 and are passed explicitly.  `act` fuses a following activation layer
+ * (UOCR_ACT_NONE = plain conv). */
+int uocr_conv2d_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* b, void* y,
+                    int n, int h, int wd, int cin, int cout, int kh, int kw, int sh, int sw,
+                    int ph, int pw, int oh, int ow, double pad_value, int use_bias,
+                    int act, double act_alpha);
+/* dx (unpadded input shape), overwritten (convolutional.py:101-145 dx part; GPU :203-219,239-250) */
+int uocr_conv2d_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, const void* w, void* dx,
+                         int n, int h, int wd, int cin, int cout, int kh, int kw, int sh, int sw,
+                         int ph, int pw, int oh, int ow);
+/* dw (+)= x~^T.dy, db (+)= sum dy (only when use_bias: bias_vec = bias*ones, convolutional.py:113,125);
+ * the padded border contributes pad_value to dw (:124-128; GPU :221-237).  accumulate!=0 adds
+ * into dw/db (`self.w.grad += dw_total`, :137-138), 0 overwrites. */
+int uocr_conv2d_bwd_weight(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db,
+                           int n, int h, int wd, int cin, int cout, int kh, int kw, int sh, int sw,
+                           int ph, int pw, int oh, int ow, double pad_value, int use_bias,
+                           int accumulate);
+
+/* ---- MaxPool2D (layers/maxpool.py; the NumPy path :24-90 is the semantics) ---------------- */
+/* y = window max with zero padding; mask (uint8, shape (n, kh*oh, kw*ow, c), window-major) marks
+ * every element equal to the max; windows running past the padded extent (ceil_mode) shrink. */
+int uocr_maxpool2d_fwd(uocr_ctx* ctx, int dtype, const void* x, void* y, uint8_t* mask,
+                       int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw,
+                       int oh, int ow);
+/* dx[b,y,x,c] = sum over windows containing (y,x) with mask set of dy/ties (maxpool.py:62-90) */
+int uocr_maxpool2d_bwd(uocr_ctx* ctx, int dtype, const void* dy, const uint8_t* mask, void* dx,
+                       int n, int h, int wd, int c, int kh, int kw, int sh, int sw, int ph, int pw,
+                       int oh, int ow);
+
+/* ---- Upsample2D (layers/upsample.py:21-110) ----------------------------------------------- */
+int uocr_upsample2d_fwd(uocr_ctx* ctx, int dtype, const void* x, void* y,
+                        int n, int h, int wd, int c, int sy, int sx);
+int uocr_upsample2d_bwd(uocr_ctx* ctx, int dtype, const void* dy, void* dx,
+                        int n, int h, int wd, int c, int sy, int sx);   /* h,wd = INPUT (dx) size */
+
+/* ---- Relu / LeakyRelu / Sigmoid (layers/layers.py:377-418) -------------------------------- */
+int uocr_act_fwd(uocr_ctx* ctx, int dtype, int kind, double alpha, const void* x, void* y, size_t count);
+/* x = the layer's stashed INPUT (the reference stashes the mask / X, layers.py:379,396,409) */
+int uocr_act_bwd(uocr_ctx* ctx, int dtype, int kind, double alpha, const void* x, const void* dy,
+                 void* dx, size_t count);
+
+/* ---- FullyConnected (layers/layers.py:307-363) -------------------------------------------- */
+int uocr_dense_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, void* y,
+                   int m, int n_in, int n_out);
+/* dx = dy . w[:-1]^T ; dw (+)= [x,1]^T . dy ; dx may be NULL to skip it */
+int uocr_dense_bwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* dy,
+                   void* dx, void* dw, int m, int n_in, int n_out, int accumulate);
+
+/* ---- Conv2DToBatchedFixedWidthed (layers/convolutional.py:330-373) ------------------------ */
+int uocr_fixed_width_fwd(uocr_ctx* ctx, int dtype, const void* x, void* y,
+                         int n, int h, int wd, int c, int width);
+int uocr_fixed_width_bwd(uocr_ctx* ctx, int dtype, const void* dy, void* dx,
+                         int n, int h, int wd, int c, int width);
+
+/* ---- Concat / fan-out sums / fills (layers.py:240-284; models.py:218) --------------------- */
+/* dst[r*dst_ld + c] = src[r*src_ld + c], r<rows, c<cols (element strides): one call per Concat input */
+int uocr_copy_2d(uocr_ctx* ctx, int dtype, void* dst, size_t dst_ld, const void* src, size_t src_ld,
+                 size_t rows, size_t cols);
+int uocr_add(uocr_ctx* ctx, int dtype, const void* a, const void* b, void* out, size_t count);
+int uocr_axpy(uocr_ctx* ctx, int dtype, double alpha, const void* x, void* y, size_t count); /* y += alpha*x */
+int uocr_scale(uocr_ctx* ctx, int dtype, double alpha, void* x, size_t count);
+int uocr_fill(uocr_ctx* ctx, int dtype, void* x, double value, size_t count);
+int uocr_convert(uocr_ctx* ctx, int src_dtype, const void* src, int dst_dtype, void* dst, size_t count);
+/* dst = u8 * scale (page images arrive as uint8, datasets.py:16-19 divides by 255) */
+int uocr_u8_to_float(uocr_ctx* ctx, int dtype, const uint8_t* src, void* dst, double scale, size_t count);
+
+/* ---- losses (losses.py) : grad tensor + float64 loss scalar at *loss_out (device) --------- */
+int uocr_seg_loss(uocr_ctx* ctx, int dtype, int kind /*UOCR_LOSS_DICE|JACCARD*/, const void* pred,
+                  const void* gt, void* grad /*may be NULL*/, double* loss_out,
+                  int n, int hw, int c);                                   /* losses.py:9-42 */
+int uocr_softmax_ce(uocr_ctx* ctx, int dtype, const void* pred, const void* gt, void* grad /*may be NULL*/,
+                    double* loss_out, int m, int c);                       /* losses.py:60-73 */
+int uocr_sigmoid_ce(uocr_ctx* ctx, int dtype, const void* pred, const void* gt, void* grad /*may be NULL*/,
+                    double* loss_out, int m, size_t count);                /* losses.py:45-57 */
+
+/* ---- regularizers (regularizations.py:15-26, applied at layers.py:147-155) ----------------- */
+/* grad += d/dw, *loss_out (+)= strength*sum(...)  (accumulate_loss=0 overwrites the slot) */
+int uocr_l2_reg(uocr_ctx* ctx, int dtype, const void* w, void* grad, size_t count, double strength,
+                double* loss_out, int accumulate_loss);
+int uocr_l1_reg(uocr_ctx* ctx, int dtype, const void* w, void* grad, size_t count, double strength,
+                double* loss_out, int accumulate_loss);
+
+/* ---- optimizers (optimizers.py:47-98), fused in-place updates ------------------------------ */
+/* v=b1*v+(1-b1)g; a=b2*a+(1-b2)g^2; w-=lr/(sqrt(a)+eps)*v   -- NO bias correction (:56-61) */
+int uocr_adam_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* v, void* a, size_t count,
+                   double lr, double beta1, double beta2, double eps);
+/* v=mu*v-lr*g; w+=v  (:75-78; mu=0 is plain SGD) */
+int uocr_momentum_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* v, size_t count,
+                       double lr, double momentum);
+/* a=rho*a+(1-rho)g^2; w-=lr/(sqrt(a)+eps)*g  (:92-95) */
+int uocr_rmsprop_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* a, size_t count,
+                      double lr, double rho, double eps);
+/* *flag_out (int32, device) = 1 if any element is NaN else 0  (nan_weights, layers.py:139-140) */
+int uocr_has_nan(uocr_ctx* ctx, int dtype, const void* x, size_t count, int32_t* flag_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNIVER_HIP_H */

@@ -1,0 +1,172 @@
+"""GPU parity of whole models driven through the framework API (Model / Sequential / my_model
+builders -> layer classes -> C ABI -> HIP kernels) against the reference's outputs in tests/golden:
+forward, loss, input gradient, every parameter gradient, three optimizer steps, post-step weights.
+
+Tolerance (normalised max error): float64 1e-10 (three chained steps), float32 1e-5 for single
+passes and 5e-5 for weights after three Adam steps (Adam divides by sqrt(a): rounding of tiny
+second moments is amplified; stated here, measured values are printed with -s)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_linf
+from oracle.nn_oracle import analytic_weights
+
+pytestmark = pytest.mark.gpu
+
+PASS_TOL = {'float32': 1e-5, 'float64': 1e-11}
+STEP_TOL = {'float32': 5e-5, 'float64': 1e-10}
+
+
+@pytest.fixture(params=['float32', 'float64'])
+def dt(request):
+    from univer_ocr_amd.nn import CP
+    CP.set_dtype(request.param)
+    yield request.param
+    CP.set_dtype('float32')
+
+
+def set_analytic_weights(model):
+    weights = {}
+    for salt, lname in enumerate(sorted(model.layers)):
+        ps = model.layers[lname].params()
+        if ps:
+            weights[lname] = {pn: analytic_weights(p.value.shape, salt + 0.5 * j).tolist()
+                              for j, (pn, p) in enumerate(sorted(ps.items()))}
+    model.set_weights(weights)
+
+
+def close(a, b, tol, what=''):
+    from univer_ocr_amd.nn import CP
+    err = rel_linf(CP.asnumpy(a), b)
+    assert err <= tol, f'{what}: rel_linf={err:.3e} > {tol:.1e}'
+    return err
+
+
+def check_sampled(name, arr, g, prefix, tol):
+    from univer_ocr_amd.nn import CP
+    key = f'{prefix}/{name}'
+    arr = CP.asnumpy(arr)
+    if key in g.files:
+        return close(arr, g[key], tol, key)
+    return close(arr.reshape(-1)[::97], g[key + '@stride97'], tol, key)
+
+
+def losses_row(losses):
+    return np.array([float(v) for v in losses['output_losses']] + [float(losses['regularization_loss'])])
+
+
+@pytest.mark.parametrize('net_name', ['Monochrome', 'Paragraph', 'Line', 'Char'])
+@pytest.mark.parametrize('opt_tag', ['adam', 'sgd'])
+def test_my_model_net(net_name, opt_tag, dt):
+    from univer_ocr_amd.my_model.model import NET_MAKERS
+    from univer_ocr_amd.nn import CP
+    from univer_ocr_amd.nn.optimizers import Adam, Momentum
+    g = load_golden(f'my_model_{net_name.lower()}')
+    opt = Adam(lr=0.0015) if opt_tag == 'adam' else Momentum(lr=0.01, momentum=0)
+    model = NET_MAKERS[net_name](tuple(int(v) for v in g['in_shape']), opt)
+    assert sorted(model.layers) == [str(s) for s in g['layer_names']]
+    assert sorted(model.params()) == [str(s) for s in g['param_names']]
+    set_analytic_weights(model)
+    X, y = CP.copy(g[f'{opt_tag}/X']), CP.copy(g[f'{opt_tag}/y'])
+    close(model.predict(X)[0], g[f'{opt_tag}/pred0'], PASS_TOL[dt], 'pred0')
+    losses = model.compute_loss_and_gradients(X, y)
+    close(losses_row(losses), g[f'{opt_tag}/grad_loss'], PASS_TOL[dt], 'loss')
+    close(model.input_grads[0], g[f'{opt_tag}/input_grad'], PASS_TOL[dt] * 2, 'input_grad')
+    for pn, p in model.params().items():
+        check_sampled(pn, p.grad, g, f'{opt_tag}/grad', PASS_TOL[dt] * 2)
+    model.clear_grads()
+    rows = [losses_row(model.train(X, y)) for _ in range(3)]
+    close(np.array(rows), g[f'{opt_tag}/step_losses'], STEP_TOL[dt], 'step_losses')
+    worst = max(check_sampled(pn, p.value, g, f'{opt_tag}/w3', STEP_TOL[dt]) for pn, p in model.params().items())
+    close(model.predict(X)[0], g[f'{opt_tag}/pred3'], STEP_TOL[dt], 'pred3')
+    test_losses = model.test(X, y)
+    close(np.array([float(v) for v in test_losses['output_losses']]), g[f'{opt_tag}/test_loss3'], STEP_TOL[dt])
+    assert not model.nan_weights()
+    print(f'{net_name}/{opt_tag}/{dt}: worst post-step weight error {worst:.2e}')
+
+
+@pytest.mark.parametrize('loss_tag', ['dice', 'jaccard'])
+def test_fcn_sequential(loss_tag, dt):
+    """test_gradients.py:191-214: conv conv pool3 conv upsample5 noop relu conv sigmoid."""
+    from univer_ocr_amd.nn import CP
+    from univer_ocr_amd.nn.layers import Convolutional2D, MaxPool2D, Noop, Relu, Sigmoid, Upsample2D
+    from univer_ocr_amd.nn.losses import SegmentationDice2D, SegmentationJaccard2D
+    from univer_ocr_amd.nn.models import Sequential
+    g = load_golden('graph_models')
+    layers = [Convolutional2D((3, 3), 3, 2, padding=1), Convolutional2D((3, 3), 2, 3, padding=1), MaxPool2D(3),
+              Convolutional2D((2, 2), 3, 4, padding=1), Upsample2D(5), Noop(), Relu(),
+              Convolutional2D((2, 2), 4, 5, padding=1), Sigmoid()]
+    loss = SegmentationDice2D() if loss_tag == 'dice' else SegmentationJaccard2D()
+    model = Sequential(layers, loss=loss)
+    X, gt = CP.copy(g['fcn/X']), CP.copy(g['fcn/gt'])
+    model.initialize_from_X(X)
+    set_analytic_weights(model)
+    losses = model.compute_loss_and_gradients(X, gt)
+    tol = PASS_TOL[dt] * 2
+    close(model.layers_outputs[0], g[f'fcn_{loss_tag}/pred'], tol, 'pred')
+    close(np.array([float(v) for v in losses['output_losses']]), g[f'fcn_{loss_tag}/loss'], tol, 'loss')
+    close(model.input_grads[0], g[f'fcn_{loss_tag}/input_grad'], tol, 'input_grad')
+    assert sorted(model.params()) == [str(s) for s in g[f'fcn_{loss_tag}/param_names']]
+    for pn, p in model.params().items():
+        close(p.grad, g[f'fcn_{loss_tag}/grad/{pn}'], tol, pn)
+
+
+def test_multi_io_dag(dt):
+    """test_gradients.py:225-259: three conv branches -> Concat -> MaxPool -> Flatten -> two dense heads."""
+    from univer_ocr_amd.nn import CP
+    from univer_ocr_amd.nn.layers import Concat, Convolutional2D, Flatten, FullyConnected, MaxPool2D
+    from univer_ocr_amd.nn.losses import SigmoidCrossEntropy
+    from univer_ocr_amd.nn.models import Model
+    g = load_golden('graph_models')
+    layers = {'conv1': Convolutional2D((2, 2), out_channels=3), 'conv2': Convolutional2D((2, 2), out_channels=3),
+              'conv3': Convolutional2D((2, 2), out_channels=3), 'concat': Concat(), 'pool': MaxPool2D(2),
+              'flatten': Flatten(), 'dense1': FullyConnected(n_output=3), 'dense2': FullyConnected(n_output=3)}
+    relations = {'conv1': 0, 'conv2': 1, 'conv3': 2, 'concat': ['conv1', 'conv2', 'conv3'], 'pool': 'concat',
+                 'flatten': 'pool', 'dense1': 'flatten', 'dense2': 'dense1', 0: 'dense1', 1: 'dense2'}
+    model = Model(layers, relations, loss=SigmoidCrossEntropy())
+    Xs = [CP.copy(g[f'dag/X{i}']) for i in range(3)]
+    ys = [CP.copy(g[f'dag/y{i}']) for i in range(2)]
+    model.initialize_from_X(Xs)
+    set_analytic_weights(model)
+    losses = model.compute_loss_and_gradients(Xs, ys)
+    tol = PASS_TOL[dt] * 2
+    close(np.array([float(v) for v in losses['output_losses']]), g['dag/loss'], tol, 'loss')
+    for i in range(2):
+        close(model.layers_outputs[i], g[f'dag/pred{i}'], tol, f'pred{i}')
+    for i in range(3):
+        close(model.input_grads[i], g[f'dag/input_grad{i}'], tol, f'input_grad{i}')
+    for pn, p in model.params().items():
+        close(p.grad, g[f'dag/grad/{pn}'], tol, pn)
+
+
+def test_nested_model_with_l1_l2(dt):
+    """test_gradients.py:261-308: nested Sequential sub-models, Concat of model inputs, L1/L2, Dice."""
+    from univer_ocr_amd.nn import CP
+    from univer_ocr_amd.nn.layers import Concat, Convolutional2D, MaxPool2D
+    from univer_ocr_amd.nn.losses import SegmentationDice2D
+    from univer_ocr_amd.nn.models import Model, Sequential
+    from univer_ocr_amd.nn.regularizations import L1, L2
+    g = load_golden('graph_models')
+
+    def sub(out_ch):
+        return Sequential([Convolutional2D((2, 2), out_channels=out_ch, regularizer=L2(0.1)),
+                           Convolutional2D((2, 2), out_channels=out_ch, regularizer=L1(0.1)), MaxPool2D((2, 2))])
+    layers = {'row_1': sub(2), 'row_2': sub(3), 'concat_rows': Concat(), 'concat_inputs': Concat(),
+              'row_inputs': sub(2), 'concat_all': Concat(), 'pool_1': MaxPool2D((2, 2)),
+              'pool_2': MaxPool2D((2, 2)), 'conv_end': Convolutional2D((2, 2), out_channels=3)}
+    relations = {'row_1': 0, 'row_2': 1, 'concat_rows': ['row_1', 'row_2'], 'concat_inputs': [0, 1],
+                 'row_inputs': 'concat_inputs', 'concat_all': ['concat_rows', 'row_inputs'],
+                 'pool_1': 'concat_all', 'pool_2': 'pool_1', 'conv_end': 'pool_2', 0: 'conv_end'}
+    model = Model(layers, relations, loss=SegmentationDice2D())
+    Xs = [CP.copy(g['nested/X0']), CP.copy(g['nested/X1'])]
+    model.initialize_from_X(Xs)
+    assert sorted(model.layers) == [str(s) for s in g['nested/layer_names']]
+    set_analytic_weights(model)
+    losses = model.compute_loss_and_gradients(Xs, CP.copy(g['nested/y']))
+    tol = PASS_TOL[dt] * 2
+    close(losses_row(losses), g['nested/loss'], tol, 'loss')
+    close(model.layers_outputs[0], g['nested/pred'], tol, 'pred')
+    close(model.input_grads[0], g['nested/input_grad0'], tol)
+    close(model.input_grads[1], g['nested/input_grad1'], tol)
+    for pn, p in model.params().items():
+        close(p.grad, g[f'nested/grad/{pn}'], tol, pn)

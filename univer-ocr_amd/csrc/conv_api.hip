@@ -1,0 +1,54 @@
+// C-ABI entry points of Convolutional2D: argument validation + dispatch between the
+// shape-specialised kernels and the generic ones (conv.hip).
+#include "conv_dims.h"
+
+namespace {
+
+int check_dims(uocr_ctx* ctx, const ConvDims& d) {
+    UOCR_REQUIRE(ctx, d.n > 0 && d.h > 0 && d.w > 0 && d.cin > 0 && d.cout > 0);
+    UOCR_REQUIRE(ctx, d.kh > 0 && d.kw > 0 && d.sh > 0 && d.sw > 0 && d.ph >= 0 && d.pw >= 0);
+    UOCR_REQUIRE(ctx, d.oh > 0 && d.ow > 0);
+    // every window must lie inside the padded input (convolutional.py:290-301 output shape)
+    UOCR_REQUIRE(ctx, (d.oh - 1) * d.sh + d.kh <= d.h + 2 * d.ph);
+    UOCR_REQUIRE(ctx, (d.ow - 1) * d.sw + d.kw <= d.w + 2 * d.pw);
+    return UOCR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uocr_conv2d_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* b, void* y, int n, int h,
+                    int wd, int cin, int cout, int kh, int kw, int sh, int sw, int ph, int pw, int oh, int ow,
+                    double pad_value, int use_bias, int act, double act_alpha) {
+    UOCR_CHECK_CTX(ctx);
+    const ConvDims d{n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, oh, ow};
+    int rc = check_dims(ctx, d);
+    if (rc) return rc;
+    UOCR_REQUIRE(ctx, x && w && y && (b || !use_bias));
+    UOCR_REQUIRE(ctx, act >= UOCR_ACT_NONE && act <= UOCR_ACT_SIGMOID);
+    return uocr_conv_fwd_generic(ctx, dtype, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
+}
+
+int uocr_conv2d_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, const void* w, void* dx, int n, int h, int wd,
+                         int cin, int cout, int kh, int kw, int sh, int sw, int ph, int pw, int oh, int ow) {
+    UOCR_CHECK_CTX(ctx);
+    const ConvDims d{n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, oh, ow};
+    int rc = check_dims(ctx, d);
+    if (rc) return rc;
+    UOCR_REQUIRE(ctx, dy && w && dx);
+    return uocr_conv_dgrad_generic(ctx, dtype, dy, w, dx, d);
+}
+
+int uocr_conv2d_bwd_weight(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db, int n, int h,
+                           int wd, int cin, int cout, int kh, int kw, int sh, int sw, int ph, int pw, int oh, int ow,
+                           double pad_value, int use_bias, int accumulate) {
+    UOCR_CHECK_CTX(ctx);
+    const ConvDims d{n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, oh, ow};
+    int rc = check_dims(ctx, d);
+    if (rc) return rc;
+    UOCR_REQUIRE(ctx, x && dy && dw && db);
+    return uocr_conv_wgrad_generic(ctx, dtype, x, dy, dw, db, d, pad_value, use_bias, accumulate);
+}
+
+}  // extern "C"

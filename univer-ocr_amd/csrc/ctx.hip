@@ -1,0 +1,172 @@
+// Context, memory and event entry points of the C ABI (include/univer_hip.h).
+// These stand in for the reference's `CP` backend switch (nn/gpu.py:5-29): CP.copy = H2D,
+// CP.asnumpy = D2H, cupy.zeros = malloc + memset, cuda.synchronize() = stream sync.
+#include "uocr_common.h"
+
+extern "C" {
+
+int uocr_abi_version(void) { return UOCR_ABI_VERSION; }
+
+int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
+    if (!out || device < 0) return UOCR_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device >= count) return UOCR_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return UOCR_ERR_HIP;
+    uocr_ctx* ctx = new uocr_ctx();
+    ctx->device = device;
+    ctx->err[0] = 0;
+    ctx->workspace = nullptr;
+    ctx->workspace_bytes = 0;
+    ctx->owns_stream = true;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return UOCR_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    ctx->cu_count = 256;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+    if (workspace_bytes) {
+        if (hipMalloc(&ctx->workspace, workspace_bytes) != hipSuccess) {
+            hipStreamDestroy(ctx->stream);
+            delete ctx;
+            return UOCR_ERR_HIP;
+        }
+        ctx->workspace_bytes = workspace_bytes;
+    }
+    *out = ctx;
+    return UOCR_OK;
+}
+
+int uocr_ctx_destroy(uocr_ctx* ctx) {
+    UOCR_CHECK_CTX(ctx);
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->workspace) hipFree(ctx->workspace);
+    if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return UOCR_OK;
+}
+
+int uocr_ctx_set_stream(uocr_ctx* ctx, void* hip_stream) {
+    UOCR_CHECK_CTX(ctx);
+    if (ctx->owns_stream) {
+        UOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        UOCR_HIP(ctx, hipStreamDestroy(ctx->stream));
+        ctx->owns_stream = false;
+    }
+    ctx->stream = (hipStream_t)hip_stream;
+    return UOCR_OK;
+}
+
+void* uocr_ctx_get_stream(uocr_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int uocr_ctx_reserve_workspace(uocr_ctx* ctx, size_t bytes) {
+    UOCR_CHECK_CTX(ctx);
+    if (bytes <= ctx->workspace_bytes) return UOCR_OK;
+    UOCR_HIP(ctx, hipSetDevice(ctx->device));
+    UOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->workspace) UOCR_HIP(ctx, hipFree(ctx->workspace));
+    ctx->workspace = nullptr;
+    ctx->workspace_bytes = 0;
+    UOCR_HIP(ctx, hipMalloc(&ctx->workspace, bytes));
+    ctx->workspace_bytes = bytes;
+    return UOCR_OK;
+}
+
+const char* uocr_last_error(uocr_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+int uocr_malloc(uocr_ctx* ctx, size_t bytes, void** out) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, out != nullptr);
+    UOCR_HIP(ctx, hipSetDevice(ctx->device));
+    UOCR_HIP(ctx, hipMalloc(out, bytes ? bytes : 1));
+    return UOCR_OK;
+}
+
+int uocr_free(uocr_ctx* ctx, void* ptr) {
+    UOCR_CHECK_CTX(ctx);
+    if (ptr) UOCR_HIP(ctx, hipFree(ptr));
+    return UOCR_OK;
+}
+
+int uocr_memset_zero(uocr_ctx* ctx, void* ptr, size_t bytes) {
+    UOCR_CHECK_CTX(ctx);
+    if (!bytes) return UOCR_OK;
+    UOCR_REQUIRE(ctx, ptr != nullptr);
+    UOCR_HIP(ctx, hipMemsetAsync(ptr, 0, bytes, ctx->stream));
+    return UOCR_OK;
+}
+
+int uocr_h2d(uocr_ctx* ctx, void* dst, const void* src_host, size_t bytes) {
+    UOCR_CHECK_CTX(ctx);
+    if (!bytes) return UOCR_OK;
+    UOCR_REQUIRE(ctx, dst && src_host);
+    UOCR_HIP(ctx, hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return UOCR_OK;
+}
+
+int uocr_d2h_sync(uocr_ctx* ctx, void* dst_host, const void* src, size_t bytes) {
+    UOCR_CHECK_CTX(ctx);
+    if (!bytes) return UOCR_OK;
+    UOCR_REQUIRE(ctx, dst_host && src);
+    UOCR_HIP(ctx, hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    UOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return UOCR_OK;
+}
+
+int uocr_d2d(uocr_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    UOCR_CHECK_CTX(ctx);
+    if (!bytes) return UOCR_OK;
+    UOCR_REQUIRE(ctx, dst && src);
+    UOCR_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return UOCR_OK;
+}
+
+int uocr_stream_sync(uocr_ctx* ctx) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return UOCR_OK;
+}
+
+int uocr_event_create(void** out_event) {
+    if (!out_event) return UOCR_ERR_ARG;
+    hipEvent_t ev;
+    if (hipEventCreate(&ev) != hipSuccess) return UOCR_ERR_HIP;
+    *out_event = (void*)ev;
+    return UOCR_OK;
+}
+
+int uocr_event_destroy(void* event) {
+    if (!event) return UOCR_ERR_ARG;
+    return hipEventDestroy((hipEvent_t)event) == hipSuccess ? UOCR_OK : UOCR_ERR_HIP;
+}
+
+int uocr_event_record(uocr_ctx* ctx, void* event) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, event != nullptr);
+    UOCR_HIP(ctx, hipEventRecord((hipEvent_t)event, ctx->stream));
+    return UOCR_OK;
+}
+
+int uocr_event_elapsed_ms_sync(void* start, void* stop, float* out_ms) {
+    if (!start || !stop || !out_ms) return UOCR_ERR_ARG;
+    if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return UOCR_ERR_HIP;
+    return hipEventElapsedTime(out_ms, (hipEvent_t)start, (hipEvent_t)stop) == hipSuccess ? UOCR_OK
+                                                                                           : UOCR_ERR_HIP;
+}
+
+int uocr_device_info(uocr_ctx* ctx, char* name_out, size_t name_cap, int* cu_count, size_t* hbm_bytes) {
+    UOCR_CHECK_CTX(ctx);
+    hipDeviceProp_t prop;
+    UOCR_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (name_out && name_cap) {
+        strncpy(name_out, prop.name, name_cap - 1);
+        name_out[name_cap - 1] = 0;
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return UOCR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,485 @@
+// HBM-bound elementwise kernels: activations, fan-out sums, fills, casts, regularizers,
+// fused optimizer steps, NaN check.  Roofline: HBM bandwidth; every kernel moves 16 B per lane
+// per access (float4 / double2) over a grid-stride loop capped at 2048 blocks (8 per CU).
+//
+// Reference semantics restated (paths relative to web_app/components/nn/):
+//   Relu / LeakyRelu / Sigmoid ........ layers/layers.py:377-418
+//   sum of fan-out gradients .......... models.py:218
+//   L1 / L2 ........................... regularizations.py:15-26, applied layers.py:147-155
+//   Adam / Momentum / RMSProp ......... optimizers.py:47-98
+//   nan_weights ....................... layers/layers.py:139-140
+#include "uocr_common.h"
+
+namespace {
+
+template <typename T, int V>
+struct alignas(sizeof(T) * V) Pack {
+    T v[V];
+};
+
+template <typename T>
+constexpr int vec_width() {
+    return 16 / (int)sizeof(T);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- generic N-input map kernel ----------------------------------------------------------
+template <typename T, int NIN>
+struct MapArgs {
+    T* out;
+    const T* in[NIN];
+};
+
+template <typename T, int NIN, int V, typename Op>
+__global__ __launch_bounds__(256) void map_kernel(MapArgs<T, NIN> a, size_t n, Op op) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t nvec = n / V;
+    for (size_t i = tid; i < nvec; i += stride) {
+        Pack<T, V> x[NIN];
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) x[k] = *reinterpret_cast<const Pack<T, V>*>(a.in[k] + i * V);
+        Pack<T, V> r;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            T args[NIN];
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) args[k] = x[k].v[j];
+            r.v[j] = op(args);
+        }
+        *reinterpret_cast<Pack<T, V>*>(a.out + i * V) = r;
+    }
+    for (size_t i = nvec * V + tid; i < n; i += stride) {
+        T args[NIN];
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) args[k] = a.in[k][i];
+        a.out[i] = op(args);
+    }
+}
+
+template <typename T, int NIN, typename Op>
+int launch_map(uocr_ctx* ctx, MapArgs<T, NIN> a, size_t n, Op op) {
+    if (n == 0) return UOCR_OK;
+    bool al = aligned16(a.out);
+    for (int k = 0; k < NIN; ++k) al = al && aligned16(a.in[k]);
+    constexpr int V = vec_width<T>();
+    const unsigned grid = uocr_blocks_for((n + V - 1) / V, 256, UOCR_MAX_GRID);
+    if (al)
+        hipLaunchKernelGGL((map_kernel<T, NIN, V, Op>), dim3(grid), dim3(256), 0, ctx->stream, a, n, op);
+    else
+        hipLaunchKernelGGL((map_kernel<T, NIN, 1, Op>), dim3(uocr_blocks_for(n, 256, UOCR_MAX_GRID)),
+                           dim3(256), 0, ctx->stream, a, n, op);
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
+}
+
+template <typename T>
+__device__ __forceinline__ T dev_exp(T x);
+template <>
+__device__ __forceinline__ float dev_exp<float>(float x) { return expf(x); }
+template <>
+__device__ __forceinline__ double dev_exp<double>(double x) { return exp(x); }
+
+// ---- activation functors -------------------------------------------------------------------
+// mask = (x >= 0) [+ alpha * (x < 0)], y = x * mask: NaN and -0.0 behave as in NumPy.
+template <typename T>
+struct ReluFwd {
+    __device__ T operator()(const T* a) const { return a[0] * (a[0] >= T(0) ? T(1) : T(0)); }
+};
+template <typename T>
+struct LeakyFwd {
+    T alpha;
+    __device__ T operator()(const T* a) const {
+        const T m = (a[0] >= T(0) ? T(1) : T(0)) + alpha * (a[0] < T(0) ? T(1) : T(0));
+        return a[0] * m;
+    }
+};
+template <typename T>
+struct SigmoidFwd {
+    __device__ T operator()(const T* a) const { return T(1) / (T(1) + dev_exp<T>(-a[0])); }
+};
+// backward: args = {x (stashed input), dy}
+template <typename T>
+struct ReluBwd {
+    __device__ T operator()(const T* a) const { return a[1] * (a[0] >= T(0) ? T(1) : T(0)); }
+};
+template <typename T>
+struct LeakyBwd {
+    T alpha;
+    __device__ T operator()(const T* a) const {
+        const T m = (a[0] >= T(0) ? T(1) : T(0)) + alpha * (a[0] < T(0) ? T(1) : T(0));
+        return a[1] * m;
+    }
+};
+// e^{-x}/(1+e^{-x})^2 is even in x: evaluate it at |x| so e <= 1 never overflows (the reference
+// formula, layers.py:412-415, overflows to NaN for x < -709 in float64 / x < -88 in float32).
+template <typename T>
+struct SigmoidBwd {
+    __device__ T operator()(const T* a) const {
+        const T e = dev_exp<T>(-(a[0] < T(0) ? -a[0] : a[0]));
+        const T d = e + T(1);
+        return a[1] * e / (d * d);
+    }
+};
+
+template <typename T>
+struct AddOp {
+    __device__ T operator()(const T* a) const { return a[0] + a[1]; }
+};
+template <typename T>
+struct AxpyOp {  // args = {y, x}
+    T alpha;
+    __device__ T operator()(const T* a) const { return a[0] + alpha * a[1]; }
+};
+template <typename T>
+struct ScaleOp {
+    T alpha;
+    __device__ T operator()(const T* a) const { return a[0] * alpha; }
+};
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void fill_kernel(T* x, T value, size_t n) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t nvec = n / V;
+    Pack<T, V> r;
+#pragma unroll
+    for (int j = 0; j < V; ++j) r.v[j] = value;
+    for (size_t i = tid; i < nvec; i += stride) *reinterpret_cast<Pack<T, V>*>(x + i * V) = r;
+    for (size_t i = nvec * V + tid; i < n; i += stride) x[i] = value;
+}
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void convert_kernel(const S* src, D* dst, D scale, bool use_scale, size_t n) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < n; i += stride) {
+        D v = (D)src[i];
+        dst[i] = use_scale ? v * scale : v;
+    }
+}
+
+// ---- regularizers: grad += dR/dw, partial sums of R in float64 ------------------------------
+template <typename T, int KIND /*1 = L1, 2 = L2*/>
+__global__ __launch_bounds__(256) void reg_kernel(const T* w, T* grad, size_t n, T strength, double* partial) {
+    __shared__ double smem[16];
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    double acc = 0.0;
+    for (size_t i = tid; i < n; i += stride) {
+        const T v = w[i];
+        if (KIND == 2) {
+            grad[i] += strength * T(2) * v;
+            acc += (double)v * (double)v;
+        } else {
+            const T s = v > T(0) ? T(1) : (v < T(0) ? T(-1) : (v == T(0) ? T(0) : v));
+            grad[i] += strength * s;
+            acc += (double)(v < T(0) ? -v : v);
+        }
+    }
+    acc = block_reduce_sum(acc, smem);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// final reduction of `count` float64 partials by ONE block; out = scale * sum (+ out if accumulate)
+__global__ __launch_bounds__(256) void finish_sum_kernel(const double* partial, int count, double scale,
+                                                         double* out, int accumulate) {
+    __shared__ double smem[16];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) acc += partial[i];
+    acc = block_reduce_sum(acc, smem);
+    if (threadIdx.x == 0) *out = (accumulate ? *out : 0.0) + scale * acc;
+}
+
+// ---- optimizers ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T dev_sqrt(T x);
+template <>
+__device__ __forceinline__ float dev_sqrt<float>(float x) { return sqrtf(x); }
+template <>
+__device__ __forceinline__ double dev_sqrt<double>(double x) { return sqrt(x); }
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void adam_kernel(T* w, const T* g, T* v, T* a, size_t n, T lr, T b1, T b2,
+                                                   T eps) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t nvec = n / V;
+    const T c1 = T(1) - b1, c2 = T(1) - b2;
+    for (size_t i = tid; i < nvec; i += stride) {
+        Pack<T, V> pw = *reinterpret_cast<const Pack<T, V>*>(w + i * V);
+        const Pack<T, V> pg = *reinterpret_cast<const Pack<T, V>*>(g + i * V);
+        Pack<T, V> pv = *reinterpret_cast<const Pack<T, V>*>(v + i * V);
+        Pack<T, V> pa = *reinterpret_cast<const Pack<T, V>*>(a + i * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            pv.v[j] = b1 * pv.v[j] + c1 * pg.v[j];
+            pa.v[j] = b2 * pa.v[j] + c2 * (pg.v[j] * pg.v[j]);
+            pw.v[j] -= lr / (dev_sqrt<T>(pa.v[j]) + eps) * pv.v[j];
+        }
+        *reinterpret_cast<Pack<T, V>*>(w + i * V) = pw;
+        *reinterpret_cast<Pack<T, V>*>(v + i * V) = pv;
+        *reinterpret_cast<Pack<T, V>*>(a + i * V) = pa;
+    }
+    for (size_t i = nvec * V + tid; i < n; i += stride) {
+        const T gi = g[i];
+        const T vi = b1 * v[i] + c1 * gi;
+        const T ai = b2 * a[i] + c2 * (gi * gi);
+        v[i] = vi;
+        a[i] = ai;
+        w[i] -= lr / (dev_sqrt<T>(ai) + eps) * vi;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void momentum_kernel(T* w, const T* g, T* v, size_t n, T lr, T mu) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < n; i += stride) {
+        const T vi = mu * v[i] - lr * g[i];
+        v[i] = vi;
+        w[i] += vi;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rmsprop_kernel(T* w, const T* g, T* a, size_t n, T lr, T rho, T eps) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < n; i += stride) {
+        const T gi = g[i];
+        const T ai = rho * a[i] + (T(1) - rho) * (gi * gi);
+        a[i] = ai;
+        w[i] -= lr / (dev_sqrt<T>(ai) + eps) * gi;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void has_nan_kernel(const T* x, size_t n, int32_t* flag) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    bool found = false;
+    for (size_t i = tid; i < n; i += stride) found |= (x[i] != x[i]);
+    if (__any(found) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+template <typename T>
+int reg_impl(uocr_ctx* ctx, int kind, const void* w, void* grad, size_t n, double strength, double* loss_out,
+             int accumulate) {
+    const unsigned grid = uocr_blocks_for(n, 256 * 4, 512);
+    int rc = uocr_need_workspace(ctx, grid * sizeof(double));
+    if (rc) return rc;
+    double* partial = (double*)ctx->workspace;
+    if (kind == 2)
+        hipLaunchKernelGGL((reg_kernel<T, 2>), dim3(grid), dim3(256), 0, ctx->stream, (const T*)w, (T*)grad, n,
+                           (T)strength, partial);
+    else
+        hipLaunchKernelGGL((reg_kernel<T, 1>), dim3(grid), dim3(256), 0, ctx->stream, (const T*)w, (T*)grad, n,
+                           (T)strength, partial);
+    UOCR_LAUNCH_CHECK(ctx);
+    return uocr_finish_sum(ctx, partial, (int)grid, strength, loss_out, accumulate);
+}
+
+}  // namespace
+
+int uocr_finish_sum(uocr_ctx* ctx, const double* partial, int count, double scale, double* out, int accumulate) {
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, partial, count, scale, out, accumulate);
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
+}
+
+extern "C" {
+
+int uocr_act_fwd(uocr_ctx* ctx, int dtype, int kind, double alpha, const void* x, void* y, size_t count) {
+    UOCR_CHECK_CTX(ctx);
+    if (!count) return UOCR_OK;
+    UOCR_REQUIRE(ctx, x && y);
+    UOCR_DISPATCH(ctx, dtype, {
+        MapArgs<T, 1> a{(T*)y, {(const T*)x}};
+        switch (kind) {
+            case UOCR_ACT_RELU: return launch_map(ctx, a, count, ReluFwd<T>{});
+            case UOCR_ACT_LEAKY: return launch_map(ctx, a, count, LeakyFwd<T>{(T)alpha});
+            case UOCR_ACT_SIGMOID: return launch_map(ctx, a, count, SigmoidFwd<T>{});
+            default: UOCR_FAIL(ctx, UOCR_ERR_ARG, "unknown activation kind %d", kind);
+        }
+    });
+    return UOCR_OK;
+}
+
+int uocr_act_bwd(uocr_ctx* ctx, int dtype, int kind, double alpha, const void* x, const void* dy, void* dx,
+                 size_t count) {
+    UOCR_CHECK_CTX(ctx);
+    if (!count) return UOCR_OK;
+    UOCR_REQUIRE(ctx, x && dy && dx);
+    UOCR_DISPATCH(ctx, dtype, {
+        MapArgs<T, 2> a{(T*)dx, {(const T*)x, (const T*)dy}};
+        switch (kind) {
+            case UOCR_ACT_RELU: return launch_map(ctx, a, count, ReluBwd<T>{});
+            case UOCR_ACT_LEAKY: return launch_map(ctx, a, count, LeakyBwd<T>{(T)alpha});
+            case UOCR_ACT_SIGMOID: return launch_map(ctx, a, count, SigmoidBwd<T>{});
+            default: UOCR_FAIL(ctx, UOCR_ERR_ARG, "unknown activation kind %d", kind);
+        }
+    });
+    return UOCR_OK;
+}
+
+int uocr_add(uocr_ctx* ctx, int dtype, const void* a, const void* b, void* out, size_t count) {
+    UOCR_CHECK_CTX(ctx);
+    if (!count) return UOCR_OK;
+    UOCR_REQUIRE(ctx, a && b && out);
+    UOCR_DISPATCH(ctx, dtype, {
+        MapArgs<T, 2> m{(T*)out, {(const T*)a, (const T*)b}};
+        return launch_map(ctx, m, count, AddOp<T>{});
+    });
+    return UOCR_OK;
+}
+
+int uocr_axpy(uocr_ctx* ctx, int dtype, double alpha, const void* x, void* y, size_t count) {
+    UOCR_CHECK_CTX(ctx);
+    if (!count) return UOCR_OK;
+    UOCR_REQUIRE(ctx, x && y);
+    UOCR_DISPATCH(ctx, dtype, {
+        MapArgs<T, 2> m{(T*)y, {(const T*)y, (const T*)x}};
+        return launch_map(ctx, m, count, AxpyOp<T>{(T)alpha});
+    });
+    return UOCR_OK;
+}
+
+int uocr_scale(uocr_ctx* ctx, int dtype, double alpha, void* x, size_t count) {
+    UOCR_CHECK_CTX(ctx);
+    if (!count) return UOCR_OK;
+    UOCR_REQUIRE(ctx, x != nullptr);
+    UOCR_DISPATCH(ctx, dtype, {
+        MapArgs<T, 1> m{(T*)x, {(const T*)x}};
+        return launch_map(ctx, m, count, ScaleOp<T>{(T)alpha});
+    });
+    return UOCR_OK;
+}
+
+int uocr_fill(uocr_ctx* ctx, int dtype, void* x, double value, size_t count) {
+    UOCR_CHECK_CTX(ctx);
+    if (!count) return UOCR_OK;
+    UOCR_REQUIRE(ctx, x != nullptr);
+    UOCR_DISPATCH(ctx, dtype, {
+        constexpr int V = vec_width<T>();
+        if (aligned16(x))
+            hipLaunchKernelGGL((fill_kernel<T, V>), dim3(uocr_blocks_for((count + V - 1) / V, 256, UOCR_MAX_GRID)),
+                               dim3(256), 0, ctx->stream, (T*)x, (T)value, count);
+        else
+            hipLaunchKernelGGL((fill_kernel<T, 1>), dim3(uocr_blocks_for(count, 256, UOCR_MAX_GRID)), dim3(256), 0,
+                               ctx->stream, (T*)x, (T)value, count);
+        UOCR_LAUNCH_CHECK(ctx);
+    });
+    return UOCR_OK;
+}
+
+int uocr_convert(uocr_ctx* ctx, int src_dtype, const void* src, int dst_dtype, void* dst, size_t count) {
+    UOCR_CHECK_CTX(ctx);
+    if (!count) return UOCR_OK;
+    UOCR_REQUIRE(ctx, src && dst);
+    const dim3 grid(uocr_blocks_for(count, 256, UOCR_MAX_GRID)), block(256);
+    if (src_dtype == UOCR_F32 && dst_dtype == UOCR_F64)
+        hipLaunchKernelGGL((convert_kernel<float, double>), grid, block, 0, ctx->stream, (const float*)src,
+                           (double*)dst, 1.0, false, count);
+    else if (src_dtype == UOCR_F64 && dst_dtype == UOCR_F32)
+        hipLaunchKernelGGL((convert_kernel<double, float>), grid, block, 0, ctx->stream, (const double*)src,
+                           (float*)dst, 1.0f, false, count);
+    else if (src_dtype == dst_dtype && (src_dtype == UOCR_F32 || src_dtype == UOCR_F64))
+        return uocr_d2d(ctx, dst, src, count * (src_dtype == UOCR_F32 ? 4 : 8));
+    else
+        UOCR_FAIL(ctx, UOCR_ERR_DTYPE, "unsupported conversion %d -> %d", src_dtype, dst_dtype);
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
+}
+
+int uocr_u8_to_float(uocr_ctx* ctx, int dtype, const uint8_t* src, void* dst, double scale, size_t count) {
+    UOCR_CHECK_CTX(ctx);
+    if (!count) return UOCR_OK;
+    UOCR_REQUIRE(ctx, src && dst);
+    const dim3 grid(uocr_blocks_for(count, 256, UOCR_MAX_GRID)), block(256);
+    UOCR_DISPATCH(ctx, dtype, {
+        hipLaunchKernelGGL((convert_kernel<uint8_t, T>), grid, block, 0, ctx->stream, src, (T*)dst, (T)scale, true,
+                           count);
+        UOCR_LAUNCH_CHECK(ctx);
+    });
+    return UOCR_OK;
+}
+
+int uocr_l2_reg(uocr_ctx* ctx, int dtype, const void* w, void* grad, size_t count, double strength,
+                double* loss_out, int accumulate_loss) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, w && grad && loss_out && count > 0);
+    UOCR_DISPATCH(ctx, dtype, { return reg_impl<T>(ctx, 2, w, grad, count, strength, loss_out, accumulate_loss); });
+    return UOCR_OK;
+}
+
+int uocr_l1_reg(uocr_ctx* ctx, int dtype, const void* w, void* grad, size_t count, double strength,
+                double* loss_out, int accumulate_loss) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, w && grad && loss_out && count > 0);
+    UOCR_DISPATCH(ctx, dtype, { return reg_impl<T>(ctx, 1, w, grad, count, strength, loss_out, accumulate_loss); });
+    return UOCR_OK;
+}
+
+int uocr_adam_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* v, void* a, size_t count, double lr,
+                   double beta1, double beta2, double eps) {
+    UOCR_CHECK_CTX(ctx);
+    if (!count) return UOCR_OK;
+    UOCR_REQUIRE(ctx, w && g && v && a);
+    UOCR_DISPATCH(ctx, dtype, {
+        constexpr int V = vec_width<T>();
+        if (aligned16(w) && aligned16(g) && aligned16(v) && aligned16(a))
+            hipLaunchKernelGGL((adam_kernel<T, V>), dim3(uocr_blocks_for((count + V - 1) / V, 256, UOCR_MAX_GRID)),
+                               dim3(256), 0, ctx->stream, (T*)w, (const T*)g, (T*)v, (T*)a, count, (T)lr, (T)beta1,
+                               (T)beta2, (T)eps);
+        else
+            hipLaunchKernelGGL((adam_kernel<T, 1>), dim3(uocr_blocks_for(count, 256, UOCR_MAX_GRID)), dim3(256), 0,
+                               ctx->stream, (T*)w, (const T*)g, (T*)v, (T*)a, count, (T)lr, (T)beta1, (T)beta2,
+                               (T)eps);
+        UOCR_LAUNCH_CHECK(ctx);
+    });
+    return UOCR_OK;
+}
+
+int uocr_momentum_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* v, size_t count, double lr,
+                       double momentum) {
+    UOCR_CHECK_CTX(ctx);
+    if (!count) return UOCR_OK;
+    UOCR_REQUIRE(ctx, w && g && v);
+    UOCR_DISPATCH(ctx, dtype, {
+        hipLaunchKernelGGL((momentum_kernel<T>), dim3(uocr_blocks_for(count, 256, UOCR_MAX_GRID)), dim3(256), 0,
+                           ctx->stream, (T*)w, (const T*)g, (T*)v, count, (T)lr, (T)momentum);
+        UOCR_LAUNCH_CHECK(ctx);
+    });
+    return UOCR_OK;
+}
+
+int uocr_rmsprop_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* a, size_t count, double lr,
+                      double rho, double eps) {
+    UOCR_CHECK_CTX(ctx);
+    if (!count) return UOCR_OK;
+    UOCR_REQUIRE(ctx, w && g && a);
+    UOCR_DISPATCH(ctx, dtype, {
+        hipLaunchKernelGGL((rmsprop_kernel<T>), dim3(uocr_blocks_for(count, 256, UOCR_MAX_GRID)), dim3(256), 0,
+                           ctx->stream, (T*)w, (const T*)g, (T*)a, count, (T)lr, (T)rho, (T)eps);
+        UOCR_LAUNCH_CHECK(ctx);
+    });
+    return UOCR_OK;
+}
+
+int uocr_has_nan(uocr_ctx* ctx, int dtype, const void* x, size_t count, int32_t* flag_out) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, flag_out != nullptr);
+    UOCR_HIP(ctx, hipMemsetAsync(flag_out, 0, sizeof(int32_t), ctx->stream));
+    if (!count) return UOCR_OK;
+    UOCR_REQUIRE(ctx, x != nullptr);
+    UOCR_DISPATCH(ctx, dtype, {
+        hipLaunchKernelGGL((has_nan_kernel<T>), dim3(uocr_blocks_for(count, 256, UOCR_MAX_GRID)), dim3(256), 0,
+                           ctx->stream, (const T*)x, count, flag_out);
+        UOCR_LAUNCH_CHECK(ctx);
+    });
+    return UOCR_OK;
+}
+
+}  // extern "C"

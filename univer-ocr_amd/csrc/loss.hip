@@ -1,0 +1,213 @@
+// Loss kernels: wavefront / block reductions in float64, gradient written in the tensor dtype,
+// loss scalar written once (float64) to a device slot -- no host sync (the reference does
+// float(loss) per call: losses.py:25,42,57,73).  Roofline: HBM bandwidth.
+//
+//   SegmentationDice2D / SegmentationJaccard2D ... losses.py:9-42
+//   SigmoidCrossEntropy .......................... losses.py:45-57
+//   SoftmaxCrossEntropy .......................... losses.py:60-73
+#include "uocr_common.h"
+
+namespace {
+
+constexpr double SEG_EPS = 1e-8;   // losses.py:17,36
+
+// stage 1: block (chunk, pair=(b,ch)) sums p*g, p, g over its pixel range of image b, channel ch
+template <typename T>
+__global__ __launch_bounds__(256) void seg_partial_kernel(const T* __restrict__ pred, const T* __restrict__ gt,
+                                                          double* __restrict__ partial, int hw, int c, int nchunks) {
+    __shared__ double smem[16];
+    const int chunk = blockIdx.x, pair = blockIdx.y;
+    const int b = pair / c, ch = pair % c;
+    const int per = (hw + nchunks - 1) / nchunks;
+    const int p0 = chunk * per, p1 = min(hw, p0 + per);
+    const T* pp = pred + (size_t)b * hw * c + ch;
+    const T* gp = gt + (size_t)b * hw * c + ch;
+    double s_pg = 0.0, s_p = 0.0, s_g = 0.0;
+    for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+        const double pv = (double)pp[(size_t)p * c], gv = (double)gp[(size_t)p * c];
+        s_pg += pv * gv;
+        s_p += pv;
+        s_g += gv;
+    }
+    s_pg = block_reduce_sum(s_pg, smem);
+    s_p = block_reduce_sum(s_p, smem);
+    s_g = block_reduce_sum(s_g, smem);
+    if (threadIdx.x == 0) {
+        double* o = partial + ((size_t)pair * nchunks + chunk) * 3;
+        o[0] = s_pg;
+        o[1] = s_p;
+        o[2] = s_g;
+    }
+}
+
+// stage 2 (one block): per pair num/den, loss = sum over pairs; stats[pair] = {num, den}
+template <int KIND>
+__global__ __launch_bounds__(256) void seg_finish_kernel(const double* __restrict__ partial, double* __restrict__ stats,
+                                                         double* __restrict__ loss_out, int npairs, int nchunks) {
+    __shared__ double smem[16];
+    double loss = 0.0;
+    for (int pair = threadIdx.x; pair < npairs; pair += blockDim.x) {
+        double s_pg = 0.0, s_p = 0.0, s_g = 0.0;
+        for (int k = 0; k < nchunks; ++k) {
+            const double* o = partial + ((size_t)pair * nchunks + k) * 3;
+            s_pg += o[0];
+            s_p += o[1];
+            s_g += o[2];
+        }
+        const double num = s_pg + SEG_EPS;
+        double den;
+        if (KIND == UOCR_LOSS_DICE) {
+            den = s_p + s_g + 2 * SEG_EPS;            // losses.py:19-20
+            loss += 1.0 - 2.0 * num / den;            // :22
+        } else {
+            den = s_p + s_g - num + 2 * SEG_EPS;      // losses.py:38
+            loss += 1.0 - num / den;                  // :40
+        }
+        stats[2 * pair] = num;
+        stats[2 * pair + 1] = den;
+    }
+    loss = block_reduce_sum(loss, smem);
+    if (threadIdx.x == 0) *loss_out = loss;
+}
+
+// stage 3: dice grad = -2 (g den - num) / den^2 ; jaccard grad = -(g den - num (1 - g)) / den^2
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void seg_grad_kernel(const T* __restrict__ gt, const double* __restrict__ stats,
+                                                       T* __restrict__ grad, size_t total, int hwc, int c) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / hwc), ch = (int)(idx % c);
+        const double num = stats[2 * (b * c + ch)], den = stats[2 * (b * c + ch) + 1];
+        const double g = (double)gt[idx];
+        double r;
+        if (KIND == UOCR_LOSS_DICE) r = -2.0 * (g * den - num) / (den * den);
+        else r = -(g * den - num * (1.0 - g)) / (den * den);
+        grad[idx] = (T)r;
+    }
+}
+
+// one wave per row: max, sum exp, grad = (p - gt)/m, row loss = -sum gt * log p
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const T* __restrict__ pred, const T* __restrict__ gt,
+                                                         T* __restrict__ grad, double* __restrict__ row_loss, int m,
+                                                         int c) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= m) return;
+    const T* x = pred + (size_t)row * c;
+    const T* g = gt + (size_t)row * c;
+    double mx = -INFINITY;
+    for (int j = lane; j < c; j += 64) mx = fmax(mx, (double)x[j]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    double se = 0.0;
+    for (int j = lane; j < c; j += 64) se += exp((double)x[j] - mx);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) se += __shfl_xor(se, off, 64);
+    const double lse = log(se);
+    double loss = 0.0;
+    for (int j = lane; j < c; j += 64) {
+        const double z = (double)x[j] - mx;
+        const double gv = (double)g[j];
+        if (gv != 0.0) loss -= gv * (z - lse);
+        if (grad) grad[(size_t)row * c + j] = (T)((exp(z) / se - gv) / (double)m);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) loss += __shfl_xor(loss, off, 64);
+    if (lane == 0) row_loss[row] = loss;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sigmoid_ce_kernel(const T* __restrict__ pred, const T* __restrict__ gt,
+                                                         T* __restrict__ grad, double* __restrict__ partial,
+                                                         size_t total, double inv_m) {
+    __shared__ double smem[16];
+    double acc = 0.0;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const double x = (double)pred[idx], g = (double)gt[idx];
+        const double p = 1.0 / (1.0 + exp(-x));
+        acc -= g * log(p) + (1.0 - g) * log(1.0 - p);
+        if (grad) grad[idx] = (T)((g * (p - 1.0) + (1.0 - g) * p) * inv_m);
+    }
+    acc = block_reduce_sum(acc, smem);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uocr_seg_loss(uocr_ctx* ctx, int dtype, int kind, const void* pred, const void* gt, void* grad,
+                  double* loss_out, int n, int hw, int c) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, pred && gt && loss_out && n > 0 && hw > 0 && c > 0);
+    UOCR_REQUIRE(ctx, kind == UOCR_LOSS_DICE || kind == UOCR_LOSS_JACCARD);
+    const int npairs = n * c;
+    int nchunks = (hw + 8191) / 8192;
+    if (nchunks > 64) nchunks = 64;
+    const size_t part_bytes = (size_t)npairs * nchunks * 3 * sizeof(double);
+    const size_t stats_bytes = (size_t)npairs * 2 * sizeof(double);
+    int rc = uocr_need_workspace(ctx, part_bytes + stats_bytes);
+    if (rc) return rc;
+    double* partial = (double*)ctx->workspace;
+    double* stats = (double*)((char*)ctx->workspace + part_bytes);
+    const size_t total = (size_t)n * hw * c;
+    UOCR_REQUIRE(ctx, (size_t)hw * c < (size_t)INT32_MAX && npairs <= 65535);
+    UOCR_DISPATCH(ctx, dtype, {
+        hipLaunchKernelGGL((seg_partial_kernel<T>), dim3(nchunks, npairs), dim3(256), 0, ctx->stream, (const T*)pred,
+                           (const T*)gt, partial, hw, c, nchunks);
+        UOCR_LAUNCH_CHECK(ctx);
+        if (kind == UOCR_LOSS_DICE)
+            hipLaunchKernelGGL((seg_finish_kernel<UOCR_LOSS_DICE>), dim3(1), dim3(256), 0, ctx->stream,
+                               (const double*)partial, stats, loss_out, npairs, nchunks);
+        else
+            hipLaunchKernelGGL((seg_finish_kernel<UOCR_LOSS_JACCARD>), dim3(1), dim3(256), 0, ctx->stream,
+                               (const double*)partial, stats, loss_out, npairs, nchunks);
+        UOCR_LAUNCH_CHECK(ctx);
+        if (grad) {
+            const dim3 grid(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4));
+            if (kind == UOCR_LOSS_DICE)
+                hipLaunchKernelGGL((seg_grad_kernel<T, UOCR_LOSS_DICE>), grid, dim3(256), 0, ctx->stream,
+                                   (const T*)gt, (const double*)stats, (T*)grad, total, hw * c, c);
+            else
+                hipLaunchKernelGGL((seg_grad_kernel<T, UOCR_LOSS_JACCARD>), grid, dim3(256), 0, ctx->stream,
+                                   (const T*)gt, (const double*)stats, (T*)grad, total, hw * c, c);
+            UOCR_LAUNCH_CHECK(ctx);
+        }
+    });
+    return UOCR_OK;
+}
+
+int uocr_softmax_ce(uocr_ctx* ctx, int dtype, const void* pred, const void* gt, void* grad, double* loss_out,
+                    int m, int c) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, pred && gt && loss_out && m > 0 && c > 0);
+    int rc = uocr_need_workspace(ctx, (size_t)m * sizeof(double));
+    if (rc) return rc;
+    double* row_loss = (double*)ctx->workspace;
+    UOCR_DISPATCH(ctx, dtype, {
+        hipLaunchKernelGGL((softmax_ce_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, ctx->stream, (const T*)pred,
+                           (const T*)gt, (T*)grad, row_loss, m, c);
+        UOCR_LAUNCH_CHECK(ctx);
+    });
+    return uocr_finish_sum(ctx, row_loss, m, 1.0 / (double)m, loss_out, 0);
+}
+
+int uocr_sigmoid_ce(uocr_ctx* ctx, int dtype, const void* pred, const void* gt, void* grad, double* loss_out,
+                    int m, size_t count) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, pred && gt && loss_out && m > 0 && count > 0);
+    const unsigned grid = uocr_blocks_for(count, 256 * 4, 512);
+    int rc = uocr_need_workspace(ctx, grid * sizeof(double));
+    if (rc) return rc;
+    double* partial = (double*)ctx->workspace;
+    UOCR_DISPATCH(ctx, dtype, {
+        hipLaunchKernelGGL((sigmoid_ce_kernel<T>), dim3(grid), dim3(256), 0, ctx->stream, (const T*)pred,
+                           (const T*)gt, (T*)grad, partial, count, 1.0 / (double)m);
+        UOCR_LAUNCH_CHECK(ctx);
+    });
+    return uocr_finish_sum(ctx, partial, (int)grid, 1.0 / (double)m, loss_out, 0);
+}
+
+}  // extern "C"

@@ -1,0 +1,313 @@
+// HBM-bound index-shuffling kernels: MaxPool2D, Upsample2D, Conv2DToBatchedFixedWidthed, Concat.
+// Roofline: HBM bandwidth.  One thread per OUTPUT element of the pass (gather formulation, so no
+// atomics), channel index fastest so a wave's accesses are contiguous in NHWC.
+//
+// Reference semantics restated (paths relative to web_app/components/nn/layers/):
+//   MaxPool2D .................... maxpool.py:24-90 (NumPy path; numba path :92-202 differs on
+//                                  all-negative partial windows -- the NumPy path is the oracle)
+//   Upsample2D ................... upsample.py:21-110
+//   Conv2DToBatchedFixedWidthed .. convolutional.py:330-373
+//   Concat ....................... layers.py:240-284
+#include "uocr_common.h"
+
+namespace {
+
+struct PoolDims {
+    int n, h, w, c, kh, kw, sh, sw, ph, pw, oh, ow;
+};
+
+// y = max over the window clipped to the zero-padded extent [0,h+2ph) x [0,w+2pw); padded cells
+// count as 0 (maxpool.py:36-40); the mask cell (kh x kw bytes per window, window-major) marks
+// every position equal to the max, positions outside the padded extent stay 0 (:47-53).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          uint8_t* __restrict__ mask, PoolDims d) {
+    const size_t total = (size_t)d.n * d.oh * d.ow * d.c;
+    const int hp = d.h + 2 * d.ph, wp = d.w + 2 * d.pw;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % d.c);
+        size_t t = idx / d.c;
+        const int ox = (int)(t % d.ow);
+        t /= d.ow;
+        const int oy = (int)(t % d.oh);
+        const int b = (int)(t / d.oh);
+        const int py0 = oy * d.sh, px0 = ox * d.sw;   // padded coordinates
+        T best = T(0);
+        bool any = false;
+        for (int ky = 0; ky < d.kh; ++ky) {
+            const int py = py0 + ky;
+            if (py >= hp) break;
+            const int iy = py - d.ph;
+            for (int kx = 0; kx < d.kw; ++kx) {
+                const int px = px0 + kx;
+                if (px >= wp) break;
+                const int ix = px - d.pw;
+                const bool inside = iy >= 0 && iy < d.h && ix >= 0 && ix < d.w;
+                const T v = inside ? x[(((size_t)b * d.h + iy) * d.w + ix) * d.c + ch] : T(0);
+                if (!any) best = v;
+                else if (best == best && (v > best || v != v)) best = v;   // NaN sticks, as np.max
+                any = true;
+            }
+        }
+        y[idx] = best;
+        for (int ky = 0; ky < d.kh; ++ky) {
+            const int py = py0 + ky, iy = py - d.ph;
+            for (int kx = 0; kx < d.kw; ++kx) {
+                const int px = px0 + kx, ix = px - d.pw;
+                uint8_t m = 0;
+                if (py < hp && px < wp) {
+                    const bool inside = iy >= 0 && iy < d.h && ix >= 0 && ix < d.w;
+                    const T v = inside ? x[(((size_t)b * d.h + iy) * d.w + ix) * d.c + ch] : T(0);
+                    m = (v == best) ? 1 : 0;
+                }
+                mask[(((size_t)b * d.oh * d.kh + (size_t)oy * d.kh + ky) * ((size_t)d.ow * d.kw) +
+                      (size_t)ox * d.kw + kx) * d.c + ch] = m;
+            }
+        }
+    }
+}
+
+// dx[b,y,x,c] = sum over windows (oy,ox) covering (y,x) whose mask bit at that position is set of
+// dy[b,oy,ox,c] / (#set bits of the window).  Windows are visited in raster order (oy, ox
+// ascending) = the order in which the reference accumulates (maxpool.py:73-83).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                                          T* __restrict__ dx, PoolDims d) {
+    const size_t total = (size_t)d.n * d.h * d.w * d.c;
+    const size_t mrow = (size_t)d.ow * d.kw * d.c;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % d.c);
+        size_t t = idx / d.c;
+        const int ix = (int)(t % d.w);
+        t /= d.w;
+        const int iy = (int)(t % d.h);
+        const int b = (int)(t / d.h);
+        const int py = iy + d.ph, px = ix + d.pw;
+        T acc = T(0);
+        for (int ky = d.kh - 1; ky >= 0; --ky) {
+            const int ty = py - ky;
+            if (ty < 0 || ty % d.sh) continue;
+            const int oy = ty / d.sh;
+            if (oy >= d.oh) continue;
+            for (int kx = d.kw - 1; kx >= 0; --kx) {
+                const int tx = px - kx;
+                if (tx < 0 || tx % d.sw) continue;
+                const int ox = tx / d.sw;
+                if (ox >= d.ow) continue;
+                const uint8_t* cell = mask + ((size_t)b * d.oh * d.kh + (size_t)oy * d.kh) * mrow +
+                                      (size_t)ox * d.kw * d.c + ch;
+                if (!cell[(size_t)ky * mrow + (size_t)kx * d.c]) continue;
+                int cnt = 0;
+                for (int a = 0; a < d.kh; ++a)
+                    for (int e = 0; e < d.kw; ++e) cnt += cell[(size_t)a * mrow + (size_t)e * d.c];
+                acc += dy[(((size_t)b * d.oh + oy) * d.ow + ox) * d.c + ch] / (T)cnt;
+            }
+        }
+        dx[idx] = acc;
+    }
+}
+
+// y[b, Y, X, c] = x[b, Y / sy, X / sx, c]   (upsample.py:21-25)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h,
+                                                           int w, int c, int sy, int sx) {
+    const int oh = h * sy, ow = w * sx;
+    const size_t total = (size_t)n * oh * ow * c;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % c);
+        size_t t = idx / c;
+        const int X = (int)(t % ow);
+        t /= ow;
+        const int Y = (int)(t % oh);
+        const int b = (int)(t / oh);
+        y[idx] = x[(((size_t)b * h + Y / sy) * w + X / sx) * c + ch];
+    }
+}
+
+// dx[b,y,x,c] = sum_{j<sy, i<sx} dy[b, y*sy + j, x*sx + i, c]   (upsample.py:27-39)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int n, int h,
+                                                           int w, int c, int sy, int sx) {
+    const int ow = w * sx, oh = h * sy;
+    const size_t total = (size_t)n * h * w * c;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % c);
+        size_t t = idx / c;
+        const int ix = (int)(t % w);
+        t /= w;
+        const int iy = (int)(t % h);
+        const int b = (int)(t / h);
+        T acc = T(0);
+        for (int j = 0; j < sy; ++j)
+            for (int i = 0; i < sx; ++i)
+                acc += dy[(((size_t)b * oh + iy * sy + j) * ow + ix * sx + i) * c + ch];
+        dx[idx] = acc;
+    }
+}
+
+// y[(b*w + col), r, j, c] = xpad[b, r, col + j, c], xpad = x shifted right by width/2 inside a
+// zero row of length w + width (convolutional.py:335-349)
+template <typename T>
+__global__ __launch_bounds__(256) void fixed_width_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h,
+                                                              int w, int c, int width) {
+    const int hw = width / 2;
+    const size_t total = (size_t)n * w * h * width * c;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % c);
+        size_t t = idx / c;
+        const int j = (int)(t % width);
+        t /= width;
+        const int r = (int)(t % h);
+        t /= h;
+        const int col = (int)(t % w);
+        const int b = (int)(t / w);
+        const int src = col + j - hw;
+        y[idx] = (src >= 0 && src < w) ? x[(((size_t)b * h + r) * w + src) * c + ch] : T(0);
+    }
+}
+
+// dx[b, r, xcol, c] = sum_j dy[(b*w + (xcol + hw - j)), r, j, c] over windows inside [0, w)
+// (convolutional.py:351-362; the reference scatter-adds window by window, col ascending = j descending)
+template <typename T>
+__global__ __launch_bounds__(256) void fixed_width_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int n,
+                                                              int h, int w, int c, int width) {
+    const int hw = width / 2;
+    const size_t total = (size_t)n * h * w * c;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % c);
+        size_t t = idx / c;
+        const int xc = (int)(t % w);
+        t /= w;
+        const int r = (int)(t % h);
+        const int b = (int)(t / h);
+        T acc = T(0);
+        for (int j = width - 1; j >= 0; --j) {
+            const int col = xc + hw - j;
+            if (col < 0 || col >= w) continue;
+            acc += dy[((((size_t)b * w + col) * h + r) * width + j) * c + ch];
+        }
+        dx[idx] = acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void copy2d_kernel(T* __restrict__ dst, size_t dst_ld, const T* __restrict__ src,
+                                                     size_t src_ld, size_t rows, size_t cols) {
+    const size_t total = rows * cols;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = idx / cols, cc = idx % cols;
+        dst[r * dst_ld + cc] = src[r * src_ld + cc];
+    }
+}
+
+inline bool pool_dims_ok(const PoolDims& d) {
+    return d.n > 0 && d.h > 0 && d.w > 0 && d.c > 0 && d.kh > 0 && d.kw > 0 && d.sh > 0 && d.sw > 0 && d.ph >= 0 &&
+           d.pw >= 0 && d.oh > 0 && d.ow > 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uocr_maxpool2d_fwd(uocr_ctx* ctx, int dtype, const void* x, void* y, uint8_t* mask, int n, int h, int wd, int c,
+                       int kh, int kw, int sh, int sw, int ph, int pw, int oh, int ow) {
+    UOCR_CHECK_CTX(ctx);
+    const PoolDims d{n, h, wd, c, kh, kw, sh, sw, ph, pw, oh, ow};
+    UOCR_REQUIRE(ctx, x && y && mask && pool_dims_ok(d));
+    // every window must start inside the padded extent (true for maxpool.py:204-216 shapes)
+    UOCR_REQUIRE(ctx, (oh - 1) * sh < h + 2 * ph && (ow - 1) * sw < wd + 2 * pw);
+    const size_t total = (size_t)n * oh * ow * c;
+    UOCR_DISPATCH(ctx, dtype, {
+        hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4)), dim3(256), 0,
+                           ctx->stream, (const T*)x, (T*)y, mask, d);
+        UOCR_LAUNCH_CHECK(ctx);
+    });
+    return UOCR_OK;
+}
+
+int uocr_maxpool2d_bwd(uocr_ctx* ctx, int dtype, const void* dy, const uint8_t* mask, void* dx, int n, int h, int wd,
+                       int c, int kh, int kw, int sh, int sw, int ph, int pw, int oh, int ow) {
+    UOCR_CHECK_CTX(ctx);
+    const PoolDims d{n, h, wd, c, kh, kw, sh, sw, ph, pw, oh, ow};
+    UOCR_REQUIRE(ctx, dy && dx && mask && pool_dims_ok(d));
+    const size_t total = (size_t)n * h * wd * c;
+    UOCR_DISPATCH(ctx, dtype, {
+        hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4)), dim3(256), 0,
+                           ctx->stream, (const T*)dy, mask, (T*)dx, d);
+        UOCR_LAUNCH_CHECK(ctx);
+    });
+    return UOCR_OK;
+}
+
+int uocr_upsample2d_fwd(uocr_ctx* ctx, int dtype, const void* x, void* y, int n, int h, int wd, int c, int sy,
+                        int sx) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, x && y && n > 0 && h > 0 && wd > 0 && c > 0 && sy > 0 && sx > 0);
+    const size_t total = (size_t)n * h * sy * wd * sx * c;
+    UOCR_DISPATCH(ctx, dtype, {
+        hipLaunchKernelGGL((upsample_fwd_kernel<T>), dim3(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4)), dim3(256),
+                           0, ctx->stream, (const T*)x, (T*)y, n, h, wd, c, sy, sx);
+        UOCR_LAUNCH_CHECK(ctx);
+    });
+    return UOCR_OK;
+}
+
+int uocr_upsample2d_bwd(uocr_ctx* ctx, int dtype, const void* dy, void* dx, int n, int h, int wd, int c, int sy,
+                        int sx) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, dy && dx && n > 0 && h > 0 && wd > 0 && c > 0 && sy > 0 && sx > 0);
+    const size_t total = (size_t)n * h * wd * c;
+    UOCR_DISPATCH(ctx, dtype, {
+        hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4)), dim3(256),
+                           0, ctx->stream, (const T*)dy, (T*)dx, n, h, wd, c, sy, sx);
+        UOCR_LAUNCH_CHECK(ctx);
+    });
+    return UOCR_OK;
+}
+
+int uocr_fixed_width_fwd(uocr_ctx* ctx, int dtype, const void* x, void* y, int n, int h, int wd, int c, int width) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, x && y && n > 0 && h > 0 && wd > 0 && c > 0 && width > 0 && wd >= width);
+    const size_t total = (size_t)n * wd * h * width * c;
+    UOCR_DISPATCH(ctx, dtype, {
+        hipLaunchKernelGGL((fixed_width_fwd_kernel<T>), dim3(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4)),
+                           dim3(256), 0, ctx->stream, (const T*)x, (T*)y, n, h, wd, c, width);
+        UOCR_LAUNCH_CHECK(ctx);
+    });
+    return UOCR_OK;
+}
+
+int uocr_fixed_width_bwd(uocr_ctx* ctx, int dtype, const void* dy, void* dx, int n, int h, int wd, int c,
+                         int width) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, dy && dx && n > 0 && h > 0 && wd > 0 && c > 0 && width > 0 && wd >= width);
+    const size_t total = (size_t)n * h * wd * c;
+    UOCR_DISPATCH(ctx, dtype, {
+        hipLaunchKernelGGL((fixed_width_bwd_kernel<T>), dim3(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4)),
+                           dim3(256), 0, ctx->stream, (const T*)dy, (T*)dx, n, h, wd, c, width);
+        UOCR_LAUNCH_CHECK(ctx);
+    });
+    return UOCR_OK;
+}
+
+int uocr_copy_2d(uocr_ctx* ctx, int dtype, void* dst, size_t dst_ld, const void* src, size_t src_ld, size_t rows,
+                 size_t cols) {
+    UOCR_CHECK_CTX(ctx);
+    if (!rows || !cols) return UOCR_OK;
+    UOCR_REQUIRE(ctx, dst && src && dst_ld >= cols && src_ld >= cols);
+    UOCR_DISPATCH(ctx, dtype, {
+        hipLaunchKernelGGL((copy2d_kernel<T>), dim3(uocr_blocks_for(rows * cols, 256, UOCR_MAX_GRID * 4)), dim3(256),
+                           0, ctx->stream, (T*)dst, dst_ld, (const T*)src, src_ld, rows, cols);
+        UOCR_LAUNCH_CHECK(ctx);
+    });
+    return UOCR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// Shared internals of libuniver_hip.so (gfx950 only).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "univer_hip.h"
+
+struct uocr_ctx {
+    int device;
+    hipStream_t stream;
+    bool owns_stream;
+    void* workspace;
+    size_t workspace_bytes;
+    int cu_count;
+    char err[512];
+};
+
+#define UOCR_FAIL(ctx, code, ...)                                   \
+    do {                                                            \
+        if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), __VA_ARGS__); \
+        return (code);                                              \
+    } while (0)
+
+#define UOCR_HIP(ctx, call)                                                              \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            UOCR_FAIL(ctx, UOCR_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                      __FILE__, __LINE__);                                               \
+    } while (0)
+
+#define UOCR_LAUNCH_CHECK(ctx)                                                           \
+    do {                                                                                 \
+        hipError_t e_ = hipGetLastError();                                               \
+        if (e_ != hipSuccess)                                                            \
+            UOCR_FAIL(ctx, UOCR_ERR_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), \
+                      __FILE__, __LINE__);                                               \
+    } while (0)
+
+#define UOCR_REQUIRE(ctx, cond)                                                          \
+    do {                                                                                 \
+        if (!(cond)) UOCR_FAIL(ctx, UOCR_ERR_ARG, "bad argument: %s (%s:%d)", #cond, __FILE__, __LINE__); \
+    } while (0)
+
+#define UOCR_CHECK_CTX(ctx) \
+    do {                    \
+        if (!(ctx)) return UOCR_ERR_ARG; \
+    } while (0)
+
+// dtype dispatch: BODY sees the type alias T
+#define UOCR_DISPATCH(ctx, dtype, ...)                                   \
+    do {                                                                 \
+        if ((dtype) == UOCR_F32) { using T = float; __VA_ARGS__; }       \
+        else if ((dtype) == UOCR_F64) { using T = double; __VA_ARGS__; } \
+        else UOCR_FAIL(ctx, UOCR_ERR_DTYPE, "unknown dtype %d", (int)(dtype)); \
+    } while (0)
+
+static inline int uocr_need_workspace(uocr_ctx* ctx, size_t bytes) {
+    if (bytes > ctx->workspace_bytes)
+        UOCR_FAIL(ctx, UOCR_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", bytes,
+                  ctx->workspace_bytes);
+    return UOCR_OK;
+}
+
+static inline unsigned uocr_blocks_for(size_t items, unsigned per_block, unsigned cap) {
+    size_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+// grid cap for grid-stride HBM-bound kernels: 256 CUs x 8 blocks of 256 threads
+constexpr unsigned UOCR_MAX_GRID = 2048;
+constexpr int UOCR_WAVE = 64;
+
+template <typename T>
+__device__ __forceinline__ T wave_reduce_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_reduce_max(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        T o = __shfl_down(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// block-wide sum of doubles for blocks of up to 1024 threads; result valid in thread 0
+__device__ __forceinline__ double block_reduce_sum(double v, double* smem /* >= 16 doubles */) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    v = wave_reduce_sum(v);
+    __syncthreads();
+    if (lane == 0) smem[wid] = v;
+    __syncthreads();
+    const int nw = (blockDim.x + 63) >> 6;
+    v = (threadIdx.x < (unsigned)nw) ? smem[threadIdx.x] : 0.0;
+    if (wid == 0) v = wave_reduce_sum(v);
+    return v;
+}
+
+// out = (accumulate ? out : 0) + scale * sum(partial[0..count)), one block, deterministic order
+int uocr_finish_sum(uocr_ctx* ctx, const double* partial, int count, double scale, double* out, int accumulate);

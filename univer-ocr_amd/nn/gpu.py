@@ -1,0 +1,340 @@
+"""Array backend of the nn framework on MI355X.
+
+Mirrors the reference's backend switch `CP` (web_app/components/nn/gpu.py:5-29): `CP.cp`,
+`CP.is_gpu_used`, `CP.use_gpu()`, `CP.copy(obj)` (host -> device), `CP.asnumpy(obj)` (device ->
+host).  Where the reference binds `CP.cp` to CuPy and launches numba.cuda kernels, this backend
+owns a `Runtime` (one HIP context of libuniver_hip.so per process = per GPU) and `DeviceArray`s
+whose memory comes from PyTorch-ROCm's caching allocator (plumbing only: no torch op computes
+anything on the hot path).
+
+There is NO host compute path: `CP.use_cpu()` exists for API compatibility and raises, and every
+op raises `HipError` when no MI355X is present.  Without a GPU, DeviceArrays can still be created
+(storage-only, on the host) so that model construction, weight I/O and the data-parallel
+bucketing logic are testable; any kernel call then fails loudly.
+"""
+import os
+
+import numpy as np
+import torch
+
+from ..hip import lib as hiplib
+from ..hip.lib import HipError
+
+_TORCH_DT = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+             np.dtype(np.uint8): torch.uint8, np.dtype(np.int32): torch.int32}
+_NP_DT = {v: k for k, v in _TORCH_DT.items()}
+
+
+class Runtime:
+    """One HIP context (stream + workspace) of libuniver_hip.so; all kernels of the process go
+    through `call`.  The stream is a dedicated torch stream made current, so torch's allocator,
+    H2D/D2H copies, HIP-graph capture and RCCL collectives are ordered with the kernels."""
+
+    def __init__(self, device_index=None):
+        if not torch.cuda.is_available():
+            raise HipError('no HIP device visible: the univer-ocr MI355X backend has no host fallback')
+        self.lib = hiplib.get_lib()
+        if device_index is None:
+            device_index = int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count())
+        self.device_index = device_index
+        self.device = torch.device('cuda', device_index)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        torch.cuda.set_stream(self.stream)
+        import ctypes as C
+        handle = C.c_void_p()
+        ws = int(os.environ.get('UOCR_WORKSPACE_MB', '256')) << 20
+        rc = self.lib.uocr_ctx_create(device_index, ws, C.byref(handle))
+        if rc != 0:
+            raise HipError(f'uocr_ctx_create(device={device_index}) failed with code {rc}')
+        self.ctx = handle
+        self._fn = {}
+        self.call('uocr_ctx_set_stream', C.c_void_p(self.stream.cuda_stream))
+        self.launches = 0
+
+    def call(self, name, *args):
+        fn = self._fn.get(name)
+        if fn is None:
+            fn = self._fn[name] = getattr(self.lib, name)
+        rc = fn(self.ctx, *args)
+        self.launches += 1
+        if rc != 0:
+            msg = self.lib.uocr_last_error(self.ctx)
+            raise HipError(f'{name} failed ({rc}): {msg.decode() if msg else "?"}')
+
+    def use_stream(self, torch_stream):
+        """Route kernels to another torch stream (used while capturing a HIP graph)."""
+        import ctypes as C
+        self.call('uocr_ctx_set_stream', C.c_void_p(torch_stream.cuda_stream))
+
+    def synchronize(self):
+        self.call('uocr_stream_sync')
+
+    def device_info(self):
+        import ctypes as C
+        name = C.create_string_buffer(256)
+        cus, hbm = C.c_int(), C.c_size_t()
+        self.call('uocr_device_info', name, 256, C.byref(cus), C.byref(hbm))
+        return {'name': name.value.decode(), 'cu_count': cus.value, 'hbm_bytes': hbm.value}
+
+
+class DeviceArray:
+    """N-d C-contiguous array in HBM (NHWC for images).  Only what the framework needs: shape /
+    dtype / reshape (a view) / copy / host round trip / `+` for fan-out gradient sums
+    (models.py:218).  All arithmetic happens in libuniver_hip.so."""
+
+    __slots__ = ('t',)
+    __array_priority__ = 100
+
+    def __init__(self, tensor):
+        self.t = tensor
+
+    # -- metadata ---------------------------------------------------------------------------
+    @property
+    def shape(self):
+        return tuple(self.t.shape)
+
+    @property
+    def dtype(self):
+        return _NP_DT[self.t.dtype]
+
+    @property
+    def size(self):
+        return self.t.numel()
+
+    @property
+    def ndim(self):
+        return self.t.dim()
+
+    @property
+    def nbytes(self):
+        return self.t.numel() * self.t.element_size()
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+    @property
+    def code(self):
+        return hiplib.F32 if self.t.dtype == torch.float32 else hiplib.F64
+
+    def __len__(self):
+        return self.t.shape[0]
+
+    def __repr__(self):
+        return f'DeviceArray(shape={self.shape}, dtype={self.dtype}, device={self.t.device})'
+
+    # -- views / copies -----------------------------------------------------------------------
+    def reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        return DeviceArray(self.t.view(*[int(s) for s in shape]))
+
+    def copy(self):
+        return DeviceArray(self.t.clone())
+
+    def numpy(self):
+        return self.t.detach().cpu().numpy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def tolist(self):
+        return self.numpy().tolist()
+
+    def set(self, host):
+        """Overwrite the contents with a host array of the same shape (keeps the storage)."""
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.shape != self.shape:
+            raise ValueError(f'shape mismatch: {host.shape} != {self.shape}')
+        self.t.copy_(torch.from_numpy(host))
+        return self
+
+    def __add__(self, other):
+        if isinstance(other, (int, float)) and other == 0:
+            return self
+        if not isinstance(other, DeviceArray):
+            return NotImplemented
+        return CP.ops.add(self, other)
+
+    __radd__ = __add__
+
+
+class _Random:
+    """CP.cp.random.* of the test scripts (test_gradients.py:65-70): host RNG, then H2D."""
+
+    @staticmethod
+    def randn(*shape):
+        return CP.copy(np.random.randn(*shape))
+
+    @staticmethod
+    def rand(*shape):
+        return CP.copy(np.random.rand(*shape))
+
+    @staticmethod
+    def uniform(low=0.0, high=1.0, size=None):
+        return CP.copy(np.random.uniform(low, high, size))
+
+
+class _ArrayModule:
+    """The slice of the NumPy/CuPy module API the framework and its test scripts use on `CP.cp`."""
+    random = _Random()
+    ndarray = DeviceArray
+
+    @staticmethod
+    def zeros(shape, dtype=None):
+        return CP.zeros(shape, dtype)
+
+    @staticmethod
+    def ones(shape, dtype=None):
+        return CP.full(shape, 1.0, dtype)
+
+    @staticmethod
+    def zeros_like(a):
+        return CP.zeros(a.shape, a.dtype)
+
+    @staticmethod
+    def array(obj, dtype=None):
+        return CP.copy(obj, dtype)
+
+    asarray = array
+
+    @staticmethod
+    def reshape(a, shape):
+        return a.reshape(shape)
+
+    @staticmethod
+    def copy(a):
+        return a.copy()
+
+
+class CP:
+    """Backend switch with the reference's interface (nn/gpu.py:5-29)."""
+    cp = _ArrayModule()
+    is_gpu_used = True
+    dtype = np.dtype(os.environ.get('UOCR_DTYPE', 'float32'))
+    lazy_losses = False          # True: losses stay on the device until float() is called
+    _runtime = None
+    ops = None                   # set by nn/ops.py (kernel wrappers)
+
+    @staticmethod
+    def use_cpu():
+        raise NotImplementedError(
+            'CP.use_cpu(): the MI355X backend ships no host compute path. The NumPy mode of the '
+            'reference (nn/gpu.py:9-12) is the reference itself; tests compare against oracle/.')
+
+    @staticmethod
+    def use_gpu(device_index=None):
+        CP.is_gpu_used = True
+        CP.runtime(device_index)
+
+    @staticmethod
+    def set_dtype(dtype):
+        dt = np.dtype(dtype)
+        if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise HipError(f'unsupported compute dtype {dt}')
+        CP.dtype = dt
+
+    @staticmethod
+    def runtime(device_index=None):
+        if CP._runtime is None:
+            CP._runtime = Runtime(device_index)
+        return CP._runtime
+
+    @staticmethod
+    def has_device():
+        return torch.cuda.is_available()
+
+    @staticmethod
+    def storage_device():
+        if CP._runtime is not None:
+            return CP._runtime.device
+        if torch.cuda.is_available():
+            return CP.runtime().device
+        return torch.device('cpu')      # storage-only mode (no kernels can run)
+
+    # -- allocation -----------------------------------------------------------------------------
+    @staticmethod
+    def empty(shape, dtype=None):
+        dt = CP.dtype if dtype is None else np.dtype(dtype)
+        shape = (shape,) if isinstance(shape, (int, np.integer)) else tuple(int(s) for s in shape)
+        return DeviceArray(torch.empty(shape, dtype=_TORCH_DT[dt], device=CP.storage_device()))
+
+    @staticmethod
+    def zeros(shape, dtype=None):
+        dt = CP.dtype if dtype is None else np.dtype(dtype)
+        shape = (shape,) if isinstance(shape, (int, np.integer)) else tuple(int(s) for s in shape)
+        return DeviceArray(torch.zeros(shape, dtype=_TORCH_DT[dt], device=CP.storage_device()))
+
+    @staticmethod
+    def full(shape, value, dtype=None):
+        dt = CP.dtype if dtype is None else np.dtype(dtype)
+        shape = (shape,) if isinstance(shape, (int, np.integer)) else tuple(int(s) for s in shape)
+        return DeviceArray(torch.full(shape, float(value), dtype=_TORCH_DT[dt], device=CP.storage_device()))
+
+    # -- host <-> device (gpu.py:19-29) ------------------------------------------------------------
+    @staticmethod
+    def copy(obj, dtype=None):
+        """Host array (or DeviceArray) -> new DeviceArray in the compute dtype."""
+        dt = CP.dtype if dtype is None else np.dtype(dtype)
+        if isinstance(obj, DeviceArray):
+            if obj.dtype == dt:
+                return obj.copy()
+            return DeviceArray(obj.t.to(_TORCH_DT[dt]))
+        host = np.ascontiguousarray(np.asarray(obj), dtype=dt)
+        return DeviceArray(torch.from_numpy(host).to(CP.storage_device()))
+
+    @staticmethod
+    def asnumpy(obj):
+        if isinstance(obj, DeviceArray):
+            return obj.numpy()
+        return np.asarray(obj)
+
+
+class DeviceScalar:
+    """A float64 loss value that lives in a device slot until somebody needs the number.  The
+    reference converts every loss with float() right away (losses.py:25,42,57,73 -- one host sync
+    each); with CP.lazy_losses the sync happens once, when the caller formats / adds the value."""
+
+    __slots__ = ('t', '_value')
+
+    def __init__(self, tensor):
+        self.t = tensor          # 0-d or 1-element float64 tensor
+        self._value = None
+
+    def __float__(self):
+        if self._value is None:
+            self._value = float(self.t.item())
+        return self._value
+
+    def __add__(self, other):
+        return float(self) + float(other)
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        return float(self) - float(other)
+
+    def __rsub__(self, other):
+        return float(other) - float(self)
+
+    def __mul__(self, other):
+        return float(self) * float(other)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        return float(self) / float(other)
+
+    def __lt__(self, other):
+        return float(self) < float(other)
+
+    def __gt__(self, other):
+        return float(self) > float(other)
+
+    def __format__(self, spec):
+        return format(float(self), spec)
+
+    def __repr__(self):
+        return repr(float(self))

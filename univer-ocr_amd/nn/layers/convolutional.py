@@ -1,0 +1,108 @@
+"""Convolutional2D and Conv2DToBatchedFixedWidthed (reference: nn/layers/convolutional.py:12-373).
+
+The reference has a NumPy path (Python loop over output pixels, :62-145) and a numba.cuda path
+(:147-288).  Here both directions are single calls into libuniver_hip.so (uocr_conv2d_*).  The
+semantics follow the NumPy path: the `bias` flag is honoured in forward and in db (the numba path
+always adds the bias, :168-169), `padding_value` fills the border and contributes to dw.
+"""
+from .. import ops
+from ..help_func import make_list_if_not, tuplize
+from .layers import BaseLayer, BaseLayerGPU, Param
+
+
+class Convolutional2D(BaseLayerGPU):
+    def __init__(self, kernel_size, in_channels=None, out_channels=None, padding=0, padding_value=0,
+                 stride=1, w=None, b=None, bias=True, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.kernel_size = tuplize('kernel_size', kernel_size, 2)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.padding = tuplize('padding', padding, 2)
+        self.padding_value = padding_value
+        self.stride = tuplize('stride', stride, 2)
+        self.w, self.b, self.bias = w, b, bias
+        self.fused_activation = None          # set by Model when the next layer is fused in
+        if self.input_shapes is None and in_channels is not None:
+            self.input_shapes = [(None, None, None, in_channels)]
+        if self.input_shapes is not None:
+            self.initialize(self.input_shapes)
+        else:
+            self.is_initialized = False
+
+    def initialize(self, input_shapes):
+        """convolutional.py:33-55: w and b come from ONE (kh*kw*cin + 1, cout) draw."""
+        self.input_shapes = input_shapes
+        self.in_channels = input_shapes[0][3]
+        if self.out_channels is None:
+            self.out_channels = self.in_channels
+        kh, kw = self.kernel_size
+        w_shape = (kh, kw, self.in_channels, self.out_channels)
+        b_shape = (self.out_channels,)
+        wb = self.initializer(kh * kw * self.in_channels + 1, self.out_channels)
+        w = wb[:-1, :].reshape(w_shape) if self.w is None else self.w
+        b = wb[-1, :].reshape(b_shape) if self.b is None else self.b
+        w = w.value if isinstance(w, Param) else w
+        b = b.value if isinstance(b, Param) else b
+        assert tuple(w.shape) == w_shape, f'{tuple(w.shape)} != {w_shape}'
+        assert tuple(b.shape) == b_shape, f'{tuple(b.shape)} != {b_shape}'
+        self.w = Param(w, optimizer=self.optimizer)
+        self.b = Param(b, optimizer=self.optimizer)
+        self._init_optimizer()
+        self.is_initialized = True
+
+    def _forward(self, X, mem_id=0):
+        assert X.shape[3] == self.in_channels
+        self._mem[mem_id] = X
+        return ops.conv2d_fwd(X, self.w.value, self.b.value, self.stride, self.padding, self.padding_value,
+                              self.bias)
+
+    def _backward(self, grad, mem_id=0):
+        X = self._mem[mem_id]
+        ops.conv2d_bwd_weight(X, grad, self.w.grad, self.b.grad, self.stride, self.padding, self.padding_value,
+                              self.bias, accumulate=True)
+        return ops.conv2d_bwd_data(grad, self.w.value, X.shape, self.stride, self.padding)
+
+    def get_output_shapes(self, input_shapes):
+        batch, height, width, _ = make_list_if_not(input_shapes)[0]
+        oh, ow = ops.conv_out_hw(height, width, self.kernel_size, self.stride, self.padding)
+        return [(batch, oh, ow, self.out_channels)]
+
+    def changes_receptive_field(self):
+        return True
+
+    def _get_receptive_field(self, axis, position, output_id):
+        assert 0 <= axis < 2, f'Convolutional2D has two axis, found {axis}'
+        assert output_id < self.get_outputs_count(), f'This layer has only {self.get_outputs_count()} outputs'
+        key = (axis, position, output_id)
+        if key not in self._receptive_fields:
+            start = position * self.stride[axis] - self.padding[axis]
+            self._receptive_fields[key] = {0: set(range(start, start + self.kernel_size[axis]))}
+        return self._receptive_fields[key]
+
+    def params(self):
+        return {'w': self.w, 'b': self.b}
+
+
+class Conv2DToBatchedFixedWidthed(BaseLayer):
+    """convolutional.py:330-373: sliding window of `width` columns over the W axis (zero padded by
+    width//2 on the left), every window becomes one batch entry: (B,H,W,C) -> (B*W,H,width,C).
+    The reference loops over B*W slices in Python even on the GPU; here it is one gather kernel
+    forward and one gather kernel backward."""
+
+    def __init__(self, width, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.width = width
+
+    def _forward(self, X, mem_id=0):
+        self.get_output_shapes(X.shape)
+        self._mem[mem_id] = X.shape
+        return ops.fixed_width_fwd(X, self.width)
+
+    def _backward(self, grad, mem_id=0):
+        return ops.fixed_width_bwd(grad, self._mem[mem_id], self.width)
+
+    def get_output_shapes(self, input_shapes):
+        result = []
+        for bs, h, w, ch in make_list_if_not(input_shapes):
+            assert w >= self.width, f'Input width must be >= than output width, found: {w} < {self.width}'
+            result.append((bs * w, h, self.width, ch))
+        return result

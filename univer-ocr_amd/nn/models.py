@@ -1,0 +1,413 @@
+"""Graph executor (reference: nn/models.py:7-502): `Model(layers, relations, loss)` and
+`Sequential(list)` with forward / backward / compute_loss_and_gradients / train / test / predict /
+params / get_weights / set_weights, nested models flattened to 'parent/child' layer names.
+
+The reference walks the DAG with memoised recursion on every call.  This executor compiles the DAG
+once (`initialize`) into a topologically ordered plan, so forward is a flat loop of asynchronous
+kernel launches on one HIP stream; parameters of the whole model are packed into one flat buffer
+(layers.ParamPack), which turns `clear_grads`, `regularize`, `update_grads`, `nan_weights` and the
+data-parallel gradient all-reduce into one launch each.
+
+Semantics kept from the reference:
+  * gradients are cleared when the forward pass starts (models.py:188) and again after the
+    optimizer step in `train` (:250-254);
+  * gradients of a layer consumed by several layers are summed (:218);
+  * `layers_outputs[k]` / `input_grads[k]` hold the model outputs / input gradients of the last call;
+  * `compute_loss_and_gradients` returns {'output_losses': [...], 'regularization_loss': r}.
+"""
+import numpy as np
+
+from . import ops
+from .gpu import CP, DeviceScalar
+from .help_func import make_list_if_not
+from .layers import BaseLayer, ParamPack
+from .losses import SoftmaxCrossEntropy
+from .progress_tracker import track_method
+
+
+class BaseModel(BaseLayer):
+    def compute_loss_and_gradients(self, X, y):
+        raise NotImplementedError()
+
+    def train(self, X, y):
+        raise NotImplementedError()
+
+    def test(self, X, y):
+        raise NotImplementedError()
+
+    def predict(self, X):
+        raise NotImplementedError()
+
+
+def _expand(layers, relations, prefix=''):
+    """Flatten nested models (models.py:109-158).  Returns (leaf_layers, relations) where every
+    relation value is a list of sources; a source is an int (model input) or a leaf layer name."""
+    relations = {dst: list(make_list_if_not(srcs)) for dst, srcs in relations.items()}
+    leaves = {}
+    outputs_of = {}              # sub-model name -> {out_id: [sources]} in the parent's namespace
+    for name, layer in layers.items():
+        if not isinstance(layer, Model):
+            leaves[name] = layer
+            continue
+        sub_leaves, sub_rel = layer.layers, layer.relations
+        parent_inputs = relations[name]
+
+        def translate(src, _name=name, _inputs=parent_inputs):
+            return _inputs[src] if isinstance(src, int) else f'{_name}/{src}'
+        outputs_of[name] = {}
+        for dst, srcs in sub_rel.items():
+            mapped = [translate(s) for s in srcs]
+            if isinstance(dst, int):
+                outputs_of[name][dst] = mapped
+            else:
+                relations[f'{name}/{dst}'] = mapped
+        for sub_name, sub_layer in sub_leaves.items():
+            leaves[f'{name}/{sub_name}'] = sub_layer
+        del relations[name]
+
+    def resolve(src):
+        """A reference to a sub-model means its output(s); they may in turn point at other sub-models."""
+        if isinstance(src, tuple) and len(src) > 1 and src[0] in outputs_of:
+            found = []
+            for out_id in src[1:]:
+                for s in outputs_of[src[0]][out_id]:
+                    found.extend(resolve(s))
+            return found
+        if isinstance(src, str) and src in outputs_of:
+            found = []
+            for out_id in sorted(outputs_of[src]):
+                for s in outputs_of[src][out_id]:
+                    found.extend(resolve(s))
+            return found
+        return [src]
+
+    flat = {}
+    for dst, srcs in relations.items():
+        out = []
+        for s in srcs:
+            out.extend(resolve(s))
+        flat[dst] = out
+    return leaves, flat
+
+
+class Model(BaseModel):
+    def __init__(self, layers, relations, loss=None, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if not isinstance(layers, dict):
+            raise TypeError(f'layers argument must be dict, found: {type(layers).__name__}')
+        if not isinstance(relations, dict):
+            raise TypeError(f'relations argument must be dict, found: {type(relations).__name__}')
+        self.ravelled_layers = layers
+        self.ravelled_relations = relations
+        self.outputs_count = max(k for k in relations if isinstance(k, int)) + 1
+        self.loss = SoftmaxCrossEntropy() if loss is None else loss
+        self.layers_outputs = {}
+        self.input_grads = {}
+        self.relations_backward = {}
+        self.is_initialized = False
+        self._plan = None
+        self._pack = None
+        self._receptive_fields = {}
+        self.layers, self.relations = None, None
+        self.unravel_model()
+
+    # -- structure ---------------------------------------------------------------------------------
+    def unravel_model(self):
+        if self.layers is None:
+            self.layers, self.relations = _expand(self.ravelled_layers, self.ravelled_relations)
+            all_ints = [s for srcs in self.relations.values() for s in srcs if isinstance(s, int)]
+            self.inputs_count = max(all_ints) + 1 if all_ints else 0
+        for name, layer in self.layers.items():
+            layer._set_name(name)
+
+    def get_leaf_layers(self):
+        return self.layers
+
+    def __getitem__(self, key):
+        return self.layers[key]
+
+    def _toposort(self):
+        order, state = [], {}
+
+        def visit(node):
+            if state.get(node) == 2:
+                return
+            if state.get(node) == 1:
+                raise RecursionError(f'Looped on {node} layer, check relations')
+            state[node] = 1
+            for src in self.relations[node]:
+                if not isinstance(src, int):
+                    visit(src)
+            state[node] = 2
+            if not isinstance(node, int):
+                order.append(node)
+        for out in range(self.outputs_count):
+            visit(out)
+        return order
+
+    def initialize(self, input_shapes):
+        """models.py:55-107: propagate shapes, initialise lazily-shaped layers, record consumers."""
+        input_shapes = make_list_if_not(input_shapes)
+        self.input_shapes = input_shapes
+        order = self._toposort()
+        shapes = {}
+        self.relations_backward = {}
+        for node in order + list(range(self.outputs_count)):
+            in_shapes = []
+            for i, src in enumerate(self.relations[node]):
+                in_shapes.append(input_shapes[src] if isinstance(src, int) else shapes[src])
+                self.relations_backward.setdefault(src, {})[node] = i
+            if isinstance(node, int):
+                continue
+            layer = self.layers[node]
+            if not layer.is_initialized:
+                layer.initialize(in_shapes)
+            out = layer.get_output_shapes(in_shapes)
+            shapes[node] = out[0] if isinstance(out, list) else out
+        never = [n for n in self.layers if n not in shapes]
+        if never:
+            print(f'These layers have never been visited: {never}')
+        self._plan = order
+        self._build_pack()
+        self.is_initialized = True
+
+    def _build_pack(self):
+        params = [p for _, p in sorted(self.params().items())]
+        dtypes = {p.value.dtype for p in params}
+        self._pack = ParamPack(params) if params and len(dtypes) == 1 else None
+        self._reg_ranges = None
+
+    @property
+    def pack(self):
+        return self._pack
+
+    # -- forward / backward ----------------------------------------------------------------------------
+    @track_method('forward')
+    def forward(self, inputs):
+        inputs = [ops.as_device(x) for x in make_list_if_not(inputs)]
+        if not self.is_initialized:
+            self.initialize_from_X(inputs)
+        self.clear_param_grads()                      # models.py:188 (per layer there, once here)
+        outputs = {}
+        for node in self._plan:
+            args = [inputs[s] if isinstance(s, int) else outputs[s] for s in self.relations[node]]
+            out = self.layers[node].forward(args)
+            outputs[node] = out[0] if isinstance(out, list) else out
+        for k in range(self.outputs_count):
+            src = self.relations[k][0]
+            outputs[k] = inputs[src] if isinstance(src, int) else outputs[src]
+        self.layers_outputs = outputs
+        return [outputs[k] for k in range(self.outputs_count)]
+
+    @track_method('backward')
+    def backward(self, grads):
+        grads = [ops.as_device(g) for g in make_list_if_not(grads)]
+        grads_mem = {}
+
+        def incoming(node):
+            parts = []
+            for dst, i in self.relations_backward.get(node, {}).items():
+                parts.append(grads[dst] if isinstance(dst, int) else grads_mem[dst][i])
+            total = parts[0]
+            for extra in parts[1:]:
+                total = ops.add(total, extra)         # models.py:218
+            return total
+
+        for node in reversed(self._plan):
+            if node not in self.relations_backward:
+                continue
+            grads_mem[node] = make_list_if_not(self.layers[node].backward(incoming(node)))
+        self.input_grads = {key: incoming(key) for key in range(self.inputs_count)
+                            if key in self.relations_backward}
+        return [self.input_grads[k] for k in range(self.inputs_count)]
+
+    def _loss_func(self, key):
+        return self.loss[key] if isinstance(self.loss, list) else self.loss
+
+    def compute_loss_and_gradients(self, X, y):
+        predicted = self.forward(make_list_if_not(X))
+        y = make_list_if_not(y)
+        losses, gradients = [], []
+        for key in range(self.outputs_count):
+            loss, grad = self._loss_func(key)(predicted[key], ops.as_device(y[key]))
+            losses.append(loss)
+            gradients.append(grad)
+        self.backward(gradients)
+        return {'output_losses': losses, 'regularization_loss': self.regularize()}
+
+    def train(self, X, y):
+        losses = self.compute_loss_and_gradients(X, y)
+        self.update_grads()
+        self.clear_grads()
+        return losses
+
+    def test(self, X, y):
+        predicted = self.forward(make_list_if_not(X))
+        y = make_list_if_not(y)
+        return {'output_losses': [self._loss_func(k).value_only(predicted[k], ops.as_device(y[k]))
+                                  for k in range(self.outputs_count)]}
+
+    def predict(self, X):
+        return self.forward(X)
+
+    # -- parameters --------------------------------------------------------------------------------------
+    def params(self):
+        return {f'{lname}/{pname}': param
+                for lname, layer in self.layers.items() for pname, param in layer.params().items()}
+
+    def clear_param_grads(self):
+        if self._pack is not None:
+            self._pack.zero_grad()
+        else:
+            for layer in self.layers.values():
+                layer.clear_grads()
+
+    def clear_grads(self):
+        self.clear_param_grads()
+        self.input_grads = {}
+
+    def update_grads(self):
+        if not self.trainable:
+            return
+        pack = self._pack
+        if pack is not None and all(layer.trainable for layer in self.layers.values()):
+            optimizer = pack.same_optimizer()
+            if optimizer is not None:
+                optimizer.update_pack(pack)           # one fused launch for the whole model
+                return
+        for layer in self.layers.values():
+            layer.update_grads()
+
+    def regularize(self):
+        """models.py:472-476.  All regularised parameters add their loss into one device slot;
+        one host sync at the end (none with CP.lazy_losses)."""
+        layers = [layer for layer in self.layers.values() if layer.regularizer is not None and layer.params()]
+        if not layers:
+            return 0
+        slot = CP.zeros((1,), np.float64)
+        for layer in layers:
+            layer.regularize(slot)
+        return DeviceScalar(slot.t) if CP.lazy_losses else float(slot.t.item())
+
+    def get_weights(self):
+        weights = {name: layer.get_weights() for name, layer in self.layers.items()}
+        return {name: w for name, w in weights.items() if w != {}}
+
+    def set_weights(self, weights):
+        for name, layer in self.layers.items():
+            layer_weights = weights.get(name)
+            if layer_weights is not None:
+                layer.set_weights(layer_weights)
+
+    def nan_weights(self):
+        if self._pack is not None:
+            return ops.has_nan(self._pack.value)
+        return any(layer.nan_weights() for layer in self.layers.values())
+
+    def count_parameters(self):
+        return sum(layer.count_parameters() for layer in self.layers.values())
+
+    # -- shapes --------------------------------------------------------------------------------------------
+    def get_all_output_shapes(self, input_shapes):
+        input_shapes = make_list_if_not(input_shapes)
+
+        def clean(shapes):
+            return [tuple(int(v) for v in s) for s in make_list_if_not(shapes)]
+        per_layer, extra = {}, {}
+        for node in self._plan if self._plan is not None else self._toposort():
+            ins = []
+            for src in self.relations[node]:
+                s = input_shapes[src] if isinstance(src, int) else per_layer[src]
+                ins.append(s[0] if isinstance(s, list) else s)
+            out, more = self.layers[node].get_all_output_shapes(ins)
+            per_layer[node] = clean(out)
+            extra.update({f'{node}/{k}': clean(v) for k, v in more.items()})
+        result = []
+        for k in range(self.outputs_count):
+            src = self.relations[k][0]
+            result.append(input_shapes[src] if isinstance(src, int) else per_layer[src][0])
+        extra.update(per_layer)
+        return clean(result), extra
+
+    def get_output_shapes(self, input_shapes):
+        return self.get_all_output_shapes(input_shapes)[0]
+
+    def get_outputs_count(self):
+        return self.outputs_count
+
+    def is_fully_convolutional(self):
+        return all(layer.is_fully_convolutional() for layer in self.layers.values())
+
+    def changes_receptive_field(self):
+        return any(layer.changes_receptive_field() for layer in self.layers.values())
+
+    # -- receptive fields (models.py:340-432) -------------------------------------------------------------------
+    def _field_of(self, node, axis, position, memo):
+        """{input_key: set of input positions} that position `position` of node's output sees."""
+        key = (node, axis, position)
+        if key in memo:
+            return memo[key]
+        points = {0: {position}} if isinstance(node, int) else \
+            self.layers[node]._get_receptive_field(axis, position, 0)
+        result = {k: set() for k in range(self.inputs_count)}
+        for src_id, src in enumerate(self.relations[node]):
+            pts = points.get(src_id, points.get(0, set())) if not isinstance(node, int) else points[0]
+            if isinstance(src, int):
+                result[src].update(pts)
+                continue
+            for p in pts:
+                for in_key, found in self._field_of(src, axis, p, memo).items():
+                    result[in_key].update(found)
+        memo[key] = result
+        return result
+
+    def _get_receptive_field(self, axis, position, output_id):
+        return self._field_of(self.relations[output_id][0], axis, position, {})
+
+    def get_receptive_fields(self):
+        assert self.is_initialized, 'The model must be initialized before calling this method'
+        assert self.is_fully_convolutional(), \
+            'This method is only available for Fully Convolutional Networks (FCN)'
+        memo, result = {}, {}
+        for name, layer in self.layers.items():
+            if not layer.changes_receptive_field():
+                continue
+            fy, fx = self._field_of(name, 0, 0, memo), self._field_of(name, 1, 0, memo)
+            result[name] = {}
+            for in_id in fy:
+                ys, xs = fy[in_id], fx[in_id]
+                if not ys or not xs:
+                    continue
+                result[name][f'input {in_id}'] = {
+                    'cnt': (len(ys), len(xs)),
+                    'y': (min(ys), max(ys)), 'x': (min(xs), max(xs)),
+                    'is_solid_y': len(ys) == max(ys) - min(ys) + 1,
+                    'is_solid_x': len(xs) == max(xs) - min(xs) + 1,
+                }
+        for layer in self.layers.values():
+            layer._clear_receptive_fields_info()
+        return result
+
+    def init_progress_tracker(self, progress_tracker, model_name='model'):
+        if self.name is None:
+            self.name = model_name
+        self.progress_tracker = progress_tracker
+        self.progress_tracker.register_layer(self.name)
+        for layer in self.layers.values():
+            layer.init_progress_tracker(progress_tracker, None)
+
+
+class Sequential(Model):
+    """models.py:487-502: layer i is named '<i>_<ClassName>' and fed by layer i-1."""
+
+    def __init__(self, layers, *args, **kwargs):
+        if not isinstance(layers, list):
+            raise TypeError(f'layers argument must be list, found: {type(layers).__name__}')
+        named, relations, prev = {}, {}, 0
+        for i, layer in enumerate(layers):
+            name = f'{i}_{type(layer).__name__}'
+            named[name] = layer
+            relations[name] = prev
+            prev = name
+        relations[0] = prev
+        super().__init__(layers=named, relations=relations, *args, **kwargs)

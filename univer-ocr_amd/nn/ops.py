@@ -1,0 +1,321 @@
+"""Kernel wrappers: DeviceArray in, DeviceArray out, every byte of arithmetic in libuniver_hip.so.
+
+This is the seam that replaces the reference's per-layer `_forward_gpu/_backward_gpu` closures
+(layers/layers.py:169-197) and its CuPy expressions.  Output shapes follow the reference's
+get_output_shapes; arrays returned are always NEW allocations, as in the reference.
+"""
+import math
+
+import numpy as np
+
+from ..hip import lib as hiplib
+from ..hip.lib import HipError
+from .gpu import CP, DeviceArray, DeviceScalar
+
+ACT_CODES = {None: hiplib.ACT_NONE, 'relu': hiplib.ACT_RELU, 'leaky': hiplib.ACT_LEAKY,
+             'sigmoid': hiplib.ACT_SIGMOID}
+
+
+def _rt():
+    return CP.runtime()
+
+
+def _same_dtype(*arrays):
+    code = arrays[0].code
+    for a in arrays[1:]:
+        if a.code != code:
+            raise HipError('mixed dtypes in one op: ' + ', '.join(str(x.dtype) for x in arrays))
+    return code
+
+
+def as_device(x):
+    """Accept host arrays at the layer boundary (the reference's layers accept whatever CP.cp is)."""
+    if isinstance(x, DeviceArray):
+        return x
+    return CP.copy(x)
+
+
+# ---- Convolutional2D ---------------------------------------------------------------------------
+def conv_out_hw(h, w, ks, stride, padding):
+    """convolutional.py:290-301."""
+    oh = math.floor((h + 2 * padding[0] - (ks[0] - 1) - 1) / stride[0] + 1)
+    ow = math.floor((w + 2 * padding[1] - (ks[1] - 1) - 1) / stride[1] + 1)
+    return oh, ow
+
+
+def _conv_dims(x_shape, w_shape, stride, padding):
+    n, h, wd, cin = x_shape
+    kh, kw, wcin, cout = w_shape
+    if cin != wcin:
+        raise AssertionError(f'channels mismatch: input has {cin}, weights expect {wcin}')
+    oh, ow = conv_out_hw(h, wd, (kh, kw), stride, padding)
+    if oh <= 0 or ow <= 0:
+        raise HipError(f'convolution output is empty for input {x_shape}, kernel {(kh, kw)}')
+    return (n, h, wd, cin, cout, kh, kw, stride[0], stride[1], padding[0], padding[1], oh, ow)
+
+
+def conv2d_fwd(x, w, b, stride, padding, pad_value=0.0, bias=True, act=None, alpha=0.0):
+    dims = _conv_dims(x.shape, w.shape, stride, padding)
+    code = _same_dtype(x, w, b)
+    y = CP.empty((dims[0], dims[11], dims[12], dims[4]), x.dtype)
+    _rt().call('uocr_conv2d_fwd', code, x.ptr, w.ptr, b.ptr, y.ptr, *dims, float(pad_value),
+               int(bool(bias)), ACT_CODES[act], float(alpha))
+    return y
+
+
+def conv2d_bwd_data(dy, w, x_shape, stride, padding):
+    dims = _conv_dims(x_shape, w.shape, stride, padding)
+    code = _same_dtype(dy, w)
+    if dy.shape != (dims[0], dims[11], dims[12], dims[4]):
+        raise AssertionError(f'grad shape {dy.shape} does not match the layer output')
+    dx = CP.empty(x_shape, dy.dtype)
+    _rt().call('uocr_conv2d_bwd_data', code, dy.ptr, w.ptr, dx.ptr, *dims)
+    return dx
+
+
+def conv2d_bwd_weight(x, dy, dw, db, stride, padding, pad_value=0.0, bias=True, accumulate=True):
+    dims = _conv_dims(x.shape, dw.shape, stride, padding)
+    code = _same_dtype(x, dy, dw, db)
+    _rt().call('uocr_conv2d_bwd_weight', code, x.ptr, dy.ptr, dw.ptr, db.ptr, *dims, float(pad_value),
+               int(bool(bias)), int(bool(accumulate)))
+
+
+# ---- MaxPool2D ------------------------------------------------------------------------------------
+def pool_out_hw(h, w, ks, stride, padding, ceil_mode):
+    """maxpool.py:204-216."""
+    rnd = math.ceil if ceil_mode else math.floor
+    return (rnd((h + 2 * padding[0] - (ks[0] - 1) - 1) / stride[0] + 1),
+            rnd((w + 2 * padding[1] - (ks[1] - 1) - 1) / stride[1] + 1))
+
+
+def maxpool2d_fwd(x, ks, stride, padding, ceil_mode=False):
+    n, h, wd, c = x.shape
+    oh, ow = pool_out_hw(h, wd, ks, stride, padding, ceil_mode)
+    y = CP.empty((n, oh, ow, c), x.dtype)
+    mask = CP.empty((n, ks[0] * oh, ks[1] * ow, c), np.uint8)
+    _rt().call('uocr_maxpool2d_fwd', x.code, x.ptr, y.ptr, mask.ptr, n, h, wd, c, ks[0], ks[1], stride[0],
+               stride[1], padding[0], padding[1], oh, ow)
+    return y, mask
+
+
+def maxpool2d_bwd(dy, mask, x_shape, ks, stride, padding):
+    n, h, wd, c = x_shape
+    oh, ow = dy.shape[1], dy.shape[2]
+    dx = CP.empty(x_shape, dy.dtype)
+    _rt().call('uocr_maxpool2d_bwd', dy.code, dy.ptr, mask.ptr, dx.ptr, n, h, wd, c, ks[0], ks[1], stride[0],
+               stride[1], padding[0], padding[1], oh, ow)
+    return dx
+
+
+# ---- Upsample2D -----------------------------------------------------------------------------------
+def upsample2d_fwd(x, scale):
+    n, h, wd, c = x.shape
+    y = CP.empty((n, h * scale[0], wd * scale[1], c), x.dtype)
+    _rt().call('uocr_upsample2d_fwd', x.code, x.ptr, y.ptr, n, h, wd, c, scale[0], scale[1])
+    return y
+
+
+def upsample2d_bwd(dy, x_shape, scale):
+    n, h, wd, c = x_shape
+    if dy.shape != (n, h * scale[0], wd * scale[1], c):
+        raise AssertionError(f'grad shape {dy.shape} does not match the upsampled shape')
+    dx = CP.empty(x_shape, dy.dtype)
+    _rt().call('uocr_upsample2d_bwd', dy.code, dy.ptr, dx.ptr, n, h, wd, c, scale[0], scale[1])
+    return dx
+
+
+# ---- activations -----------------------------------------------------------------------------------
+def act_fwd(kind, x, alpha=0.0):
+    y = CP.empty(x.shape, x.dtype)
+    _rt().call('uocr_act_fwd', x.code, ACT_CODES[kind], float(alpha), x.ptr, y.ptr, x.size)
+    return y
+
+
+def act_bwd(kind, x, dy, alpha=0.0):
+    code = _same_dtype(x, dy)
+    if x.size != dy.size:
+        raise AssertionError(f'grad size {dy.shape} != input size {x.shape}')
+    dx = CP.empty(dy.shape, dy.dtype)
+    _rt().call('uocr_act_bwd', code, ACT_CODES[kind], float(alpha), x.ptr, dy.ptr, dx.ptr, x.size)
+    return dx
+
+
+# ---- FullyConnected ---------------------------------------------------------------------------------
+def dense_fwd(x, w):
+    m, n_in = x.shape
+    if w.shape[0] != n_in + 1:
+        raise AssertionError(f'weights {w.shape} do not fit input {x.shape} (bias row included)')
+    y = CP.empty((m, w.shape[1]), x.dtype)
+    _rt().call('uocr_dense_fwd', _same_dtype(x, w), x.ptr, w.ptr, y.ptr, m, n_in, w.shape[1])
+    return y
+
+
+def dense_bwd(x, w, dy, dw, accumulate=True, need_dx=True):
+    m, n_in = x.shape
+    n_out = w.shape[1]
+    code = _same_dtype(x, w, dy, dw)
+    dx = CP.empty((m, n_in), dy.dtype) if need_dx else None
+    _rt().call('uocr_dense_bwd', code, x.ptr, w.ptr, dy.ptr, dx.ptr if need_dx else None, dw.ptr, m, n_in,
+               n_out, int(bool(accumulate)))
+    return dx
+
+
+# ---- Conv2DToBatchedFixedWidthed -------------------------------------------------------------------
+def fixed_width_fwd(x, width):
+    n, h, wd, c = x.shape
+    y = CP.empty((n * wd, h, width, c), x.dtype)
+    _rt().call('uocr_fixed_width_fwd', x.code, x.ptr, y.ptr, n, h, wd, c, width)
+    return y
+
+
+def fixed_width_bwd(dy, x_shape, width):
+    n, h, wd, c = x_shape
+    dx = CP.empty(x_shape, dy.dtype)
+    _rt().call('uocr_fixed_width_bwd', dy.code, dy.ptr, dx.ptr, n, h, wd, c, width)
+    return dx
+
+
+# ---- Concat / sums -----------------------------------------------------------------------------------
+def concat(arrays, axis=-1):
+    nd = arrays[0].ndim
+    axis = axis % nd
+    lead = arrays[0].shape[:axis]
+    rows = int(np.prod(lead)) if lead else 1
+    tails = [int(np.prod(a.shape[axis:])) for a in arrays]
+    out_shape = list(arrays[0].shape)
+    out_shape[axis] = sum(a.shape[axis] for a in arrays)
+    out = CP.empty(out_shape, arrays[0].dtype)
+    total = sum(tails)
+    off = 0
+    esz = out.t.element_size()
+    for a, cols in zip(arrays, tails):
+        _same_dtype(out, a)
+        _rt().call('uocr_copy_2d', out.code, out.ptr + off * esz, total, a.ptr, cols, rows, cols)
+        off += cols
+    return out
+
+
+def split(array, shapes, axis=-1):
+    """Inverse of concat: slices of `array` with the given shapes along `axis` (Concat.backward)."""
+    nd = array.ndim
+    axis = axis % nd
+    rows = int(np.prod(array.shape[:axis])) if axis else 1
+    total = int(np.prod(array.shape[axis:]))
+    outs, off = [], 0
+    esz = array.t.element_size()
+    for shp in shapes:
+        cols = int(np.prod(shp[axis:]))
+        out = CP.empty(shp, array.dtype)
+        _rt().call('uocr_copy_2d', out.code, out.ptr, cols, array.ptr + off * esz, total, rows, cols)
+        outs.append(out)
+        off += cols
+    return outs
+
+
+def add(a, b):
+    if a.shape != b.shape:
+        raise AssertionError(f'cannot add {a.shape} and {b.shape}')
+    out = CP.empty(a.shape, a.dtype)
+    _rt().call('uocr_add', _same_dtype(a, b), a.ptr, b.ptr, out.ptr, a.size)
+    return out
+
+
+def axpy(alpha, x, y):
+    _rt().call('uocr_axpy', _same_dtype(x, y), float(alpha), x.ptr, y.ptr, x.size)
+
+
+def scale_(x, alpha):
+    _rt().call('uocr_scale', x.code, float(alpha), x.ptr, x.size)
+
+
+def fill_(x, value):
+    _rt().call('uocr_fill', x.code, x.ptr, float(value), x.size)
+
+
+def zero_(x):
+    _rt().call('uocr_memset_zero', x.ptr, x.nbytes)
+
+
+def u8_to_float(src_u8, scale=1.0 / 255.0, dtype=None):
+    out = CP.empty(src_u8.shape, CP.dtype if dtype is None else dtype)
+    _rt().call('uocr_u8_to_float', out.code, src_u8.ptr, out.ptr, float(scale), out.size)
+    return out
+
+
+# ---- losses --------------------------------------------------------------------------------------------
+def _loss_slot():
+    return CP.empty((1,), np.float64)
+
+
+def _finish_loss(slot):
+    return DeviceScalar(slot.t) if CP.lazy_losses else float(slot.t.item())
+
+
+def seg_loss(kind, pred, gt, need_grad=True):
+    n, h, w, c = pred.shape
+    if gt.shape != pred.shape:
+        raise AssertionError(f'ground truth {gt.shape} != prediction {pred.shape}')
+    grad = CP.empty(pred.shape, pred.dtype) if need_grad else None
+    slot = _loss_slot()
+    _rt().call('uocr_seg_loss', _same_dtype(pred, gt), hiplib.LOSS_DICE if kind == 'dice' else hiplib.LOSS_JACCARD,
+               pred.ptr, gt.ptr, grad.ptr if need_grad else None, slot.ptr, n, h * w, c)
+    return _finish_loss(slot), grad
+
+
+def softmax_ce(pred, gt, need_grad=True):
+    m, c = pred.shape
+    if gt.shape != pred.shape:
+        raise AssertionError(f'ground truth {gt.shape} != prediction {pred.shape}')
+    grad = CP.empty(pred.shape, pred.dtype) if need_grad else None
+    slot = _loss_slot()
+    _rt().call('uocr_softmax_ce', _same_dtype(pred, gt), pred.ptr, gt.ptr, grad.ptr if need_grad else None,
+               slot.ptr, m, c)
+    return _finish_loss(slot), grad
+
+
+def sigmoid_ce(pred, gt, need_grad=True):
+    if gt.shape != pred.shape:
+        raise AssertionError(f'ground truth {gt.shape} != prediction {pred.shape}')
+    grad = CP.empty(pred.shape, pred.dtype) if need_grad else None
+    slot = _loss_slot()
+    _rt().call('uocr_sigmoid_ce', _same_dtype(pred, gt), pred.ptr, gt.ptr, grad.ptr if need_grad else None,
+               slot.ptr, gt.shape[0], pred.size)
+    return _finish_loss(slot), grad
+
+
+def regularize(kind, w, grad, strength, slot=None, accumulate=False):
+    """grad += dR/dw; returns the loss (or adds it into `slot` when given)."""
+    own = slot is None
+    if own:
+        slot = _loss_slot()
+    _rt().call('uocr_l2_reg' if kind == 'l2' else 'uocr_l1_reg', _same_dtype(w, grad), w.ptr, grad.ptr, w.size,
+               float(strength), slot.ptr, int(bool(accumulate)))
+    return _finish_loss(slot) if own else None
+
+
+# ---- optimizers ------------------------------------------------------------------------------------------
+def adam_step(w, g, v, a, lr, beta1, beta2, eps):
+    _rt().call('uocr_adam_step', _same_dtype(w, g, v, a), w.ptr, g.ptr, v.ptr, a.ptr, w.size, float(lr),
+               float(beta1), float(beta2), float(eps))
+
+
+def momentum_step(w, g, v, lr, momentum):
+    _rt().call('uocr_momentum_step', _same_dtype(w, g, v), w.ptr, g.ptr, v.ptr, w.size, float(lr), float(momentum))
+
+
+def rmsprop_step(w, g, a, lr, rho, eps):
+    _rt().call('uocr_rmsprop_step', _same_dtype(w, g, a), w.ptr, g.ptr, a.ptr, w.size, float(lr), float(rho),
+               float(eps))
+
+
+def has_nan(x):
+    flag = CP.empty((1,), np.int32)
+    _rt().call('uocr_has_nan', x.code, x.ptr, x.size, flag.ptr)
+    return bool(flag.t.item())
+
+
+class _Ops:
+    add = staticmethod(add)
+
+
+CP.ops = _Ops
