@@ -49,8 +49,8 @@ class Runtime:
             raise HipError(f'uocr_ctx_create(device={device_index}) failed with code {rc}')
         self.ctx = handle
         self._fn = {}
-        self.call('uocr_ctx_set_stream', C.c_void_p(self.stream.cuda_stream))
         self.launches = 0
+        self.call('uocr_ctx_set_stream', C.c_void_p(self.stream.cuda_stream))
 
     def call(self, name, *args):
         fn = self._fn.get(name)
