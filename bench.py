@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: document-images/sec (fwd+bwd+optimizer) on 256x512 synthetic pages.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one train step of every my_model net on one device-resident synthetic batch
+(BASELINE.json configs[2]: fwd+bwd+SGD, batch 32 per GPU, 256x512 pages): Monochrome, Paragraph and
+Line on (32,256,512,1) pages, Char on (32,32,64,1) line strips; forward, loss, backward, L2,
+optimizer update for each.  Data parallel over N GPUs = N x 32 pages per step (weak scaling), one
+RCCL all-reduce per net per step.  Rank 0 prints ONE JSON line with the whole-job images/s, the
+roofline of the dominant kernel (timed live with HIP events around each of its launches in the
+timed region) and the CPU baseline (oracle/ restatement timed on this box's host cores).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+class KernelProbe:
+    """HIP-event pairs around every launch of one C-ABI entry point whose int arguments match;
+    events are recorded on the stream the kernel is launched on (the ctx stream)."""
+
+    def __init__(self, runtime, name, match):
+        self.rt, self.name, self.match = runtime, name, match
+        self.pairs, self.pool = [], []
+        self.enabled = False
+        self._orig = runtime.call
+        runtime.call = self._call
+
+    def _event(self):
+        if self.pool:
+            return self.pool.pop()
+        ev = ctypes.c_void_p()
+        assert self.rt.lib.uocr_event_create(ctypes.byref(ev)) == 0
+        return ev
+
+    def _call(self, name, *args):
+        if self.enabled and name == self.name and self.match(args):
+            a, b = self._event(), self._event()
+            self._orig('uocr_event_record', a)
+            self._orig(name, *args)
+            self._orig('uocr_event_record', b)
+            self.pairs.append((a, b))
+        else:
+            self._orig(name, *args)
+
+    def mean_ms(self):
+        total, ms = 0.0, ctypes.c_float()
+        for a, b in self.pairs:
+            assert self.rt.lib.uocr_event_elapsed_ms_sync(a, b, ctypes.byref(ms)) == 0
+            total += ms.value
+        return total / max(1, len(self.pairs)), len(self.pairs)
+
+
+def cpu_baseline(height, width, char_width, optimizer, lr, budget_s=12.0):
+    """The oracle (NumPy restatement of the reference, float64) on a bounded sample of the SAME
+    workload: train steps of the four nets on 2 pages + 2 line strips, host cores of this box."""
+    import numpy as np
+
+    from oracle import nn_oracle as O
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    sample = 2
+    data = make_page_batch(sample, height, width, char_width, seed=1234)
+    rng = np.random.default_rng(0)
+    nets = {}
+    for name in ('Monochrome', 'Paragraph', 'Line', 'Char'):
+        spec, _ = O.NET_SPECS[name]()
+        nets[name] = O.make_net(name, O.kaiming_uniform_weights(spec, rng))
+    feeds = {'Monochrome': ('image', 'monochrome'), 'Paragraph': ('monochrome', 'paragraph'),
+             'Line': ('monochrome', 'line'), 'Char': ('char_lines', 'char_labels')}
+    opts = {n: (O.MomentumState(lr, 0.0) if optimizer == 'sgd' else O.AdamState(lr)) for n in nets}
+
+    def one_step():
+        for name, net in nets.items():
+            x, y = feeds[name]
+            net.train_step(data[x], data[y], opts[name])
+    one_step()                                   # warm-up (page-in, BLAS threads)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        one_step()
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or steps >= 8:
+            break
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:   # noqa: BLE001
+        threads = os.cpu_count() or 1
+    return {'value': round(sample * steps / el, 3), 'unit': 'images/s', 'cores': int(threads),
+            'host_cpus': os.cpu_count(), 'kind': 'port',
+            'sample': f'{steps} train steps of the 4 nets on {sample} pages {height}x{width} + {sample} line '
+                      f'strips 32x{char_width}, float64 NumPy oracle (im2col+BLAS), {el:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='pages per GPU per step')
+    ap.add_argument('--height', type=int, default=256)
+    ap.add_argument('--width', type=int, default=512)
+    ap.add_argument('--char-width', type=int, default=64)
+    ap.add_argument('--optimizer', default='sgd', choices=['sgd', 'adam'])
+    ap.add_argument('--lr', type=float, default=0.0015)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-overlap', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    from univer_ocr_amd.my_model.trainer import PageTrainer
+    from univer_ocr_amd.nn import CP
+
+    CP.use_gpu(local_rank)
+    CP.set_dtype('float32')
+    CP.lazy_losses = True                        # losses stay on the device; fetched after the loop
+    rt = CP.runtime()
+
+    trainer = PageTrainer(args.batch, args.height, args.width, args.char_width, args.optimizer, args.lr,
+                          seed=0, overlap=not args.no_overlap)
+    layers = make_page_batch(args.batch, args.height, args.width, args.char_width, seed=1234 + rank)
+    context = trainer.make_context(layers)       # inputs resident in HBM before the timed region
+
+    # dominant kernel (profiles/): dw/db of Monochrome conv_2 (3x3, 16->1) -- reads the 16-channel
+    # activation (B*H*W*16*4 B) and dy (B*H*W*4 B) once: algorithmic bytes = 4*B*H*W*(16+1) + 4*(144+1)
+    npix = args.batch * args.height * args.width
+    probe = KernelProbe(rt, 'uocr_conv2d_bwd_weight',
+                        lambda a: a[8] == 16 and a[9] == 1 and a[10] == 3 and a[11] == 3)
+    dominant = {'kernel': 'conv2d_bwd_weight 3x3 16->1 (Monochrome/conv_2 dw,db)',
+                'bytes': 4.0 * npix * 17 + 4 * 145}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        losses = trainer.step(context)
+    barrier()
+    probe.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = trainer.step(context)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    probe.enabled = False
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    final = {n: [float(v) for v in l['output_losses']] for n, l in losses.items()}
+
+    if rank == 0:
+        kernel_ms, launches = probe.mean_ms()
+        achieved = dominant['bytes'] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        images = args.batch * world * args.steps
+        out = {
+            'metric': 'document-images/sec (fwd+bwd) on 256x512 synthetic pages',
+            'value': round(images / elapsed, 2),
+            'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': f'BASELINE configs[2]: my_model train step (fwd+loss+bwd+L2+{args.optimizer.upper()}) of '
+                            f'Monochrome+Paragraph+Line on ({args.batch},{args.height},{args.width},1) pages and Char on '
+                            f'({args.batch},32,{args.char_width},1) line strips per GPU',
+                'batch_per_gpu': args.batch, 'global_batch': args.batch * world,
+                'page': [args.height, args.width], 'optimizer': args.optimizer,
+                'parallelism': f'dp{world}', 'grad_allreduce': 'rccl, 1 flat buffer per net' if world > 1 else None,
+                'final_losses': final,
+            },
+            'roofline': {'bound': 'hbm', 'kernel': dominant['kernel'], 'achieved': round(achieved, 1),
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                         'traffic': None, 'avg_launch_us': round(kernel_ms * 1e3, 2), 'launches_timed': launches,
+                         'algorithmic_bytes_per_launch': dominant['bytes']},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.height, args.width, args.char_width, args.optimizer, args.lr)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -6,6 +6,13 @@ struct ConvDims {
     int n, h, w, cin, cout, kh, kw, sh, sw, ph, pw, oh, ow;
 };
 
+// f32 MFMA implicit GEMM (gemm_mfma.hip); which: 0 fwd, 1 dgrad, 2 wgrad
+bool uocr_conv_mfma_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d, int which);
+int uocr_conv_fwd_mfma(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
+                       double pad_value, int use_bias, int act, double act_alpha);
+int uocr_conv_dgrad_mfma(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d);
+int uocr_conv_wgrad_mfma(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
+                         double pad_value, int use_bias, int accumulate);
 // generic direct kernels (conv.hip): any shape, f32 / f64
 int uocr_conv_fwd_generic(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* b, void* y,
                           const ConvDims& d, double pad_value, int use_bias, int act, double act_alpha);

@@ -19,6 +19,8 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->workspace = nullptr;
     ctx->workspace_bytes = 0;
     ctx->owns_stream = true;
+    ctx->opt_mfma = 1;
+    ctx->opt_fast = 1;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return UOCR_ERR_HIP;
@@ -56,6 +58,15 @@ int uocr_ctx_set_stream(uocr_ctx* ctx, void* hip_stream) {
         ctx->owns_stream = false;
     }
     ctx->stream = (hipStream_t)hip_stream;
+    return UOCR_OK;
+}
+
+int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, key != nullptr);
+    if (!strcmp(key, "mfma")) ctx->opt_mfma = value;
+    else if (!strcmp(key, "fast_paths")) ctx->opt_fast = value;
+    else UOCR_FAIL(ctx, UOCR_ERR_ARG, "unknown option '%s'", key);
     return UOCR_OK;
 }
 

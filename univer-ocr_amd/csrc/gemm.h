@@ -14,5 +14,7 @@ struct GemmArgs {
 };
 
 int uocr_gemm_generic(uocr_ctx* ctx, int dtype, const GemmArgs& g);
+bool uocr_gemm_mfma_eligible(uocr_ctx* ctx, int dtype, const GemmArgs& g);
+int uocr_gemm_mfma(uocr_ctx* ctx, const GemmArgs& g);
 // dispatcher: MFMA path when eligible, else generic
 int uocr_gemm(uocr_ctx* ctx, int dtype, const GemmArgs& g);

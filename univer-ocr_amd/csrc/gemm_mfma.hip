@@ -1,0 +1,531 @@
+// float32 MFMA GEMM core for gfx950 and the implicit-GEMM forms of Convolutional2D / FullyConnected
+// built on it.  Roofline: MFMA (v_mfma_f32_32x32x2_f32: exact f32, 64 FLOP/clk/SIMD, 157 TF peak).
+//
+//   C[M x N] = A[M x D] . B[D x N]   (D = "depth", the summed index)
+//
+// Block tile BM x 64 (BM = 128: 4 waves of 32x64; BM = 64: 2x2 waves of 32x32), depth tile 32,
+// 256 threads.  A and B tiles are staged global -> registers -> LDS (double buffered, one barrier
+// per depth tile): the loads of tile t+1 are issued before the MFMAs of tile t and written to LDS
+// after them.  A is m-major in LDS with a row stride of 33 floats (conflict-free ds_read_b32 for
+// the 32x32x2 A fragment: lane l reads A[l&31][k + (l>>5)]), B is depth-major with 64-float rows
+// (lane l reads B[k + (l>>5)][l&31]).  B is ALWAYS a row-major [D][N] matrix in memory (weights
+// that are needed transposed are transposed once per call into the workspace -- they are <= 2 MB);
+// A is produced by a loader functor, which is where the im2col / transposed-conv / bias-column
+// logic lives -- nothing is materialised in HBM.
+//
+// Split-D: when M x N has too few tiles to fill 256 CUs (dw of the 64-channel convs: 15 tiles),
+// gridDim.z blocks each sum a slice of D into a float32 slab in the workspace and a second kernel
+// adds the slabs in a fixed order (deterministic) and applies the epilogue.
+#include "conv_dims.h"
+#include "gemm.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BN = 64;
+constexpr int BD = 32;          // depth tile
+constexpr int LDA = BD + 1;     // LDS row stride of the A tile (floats)
+
+struct alignas(16) F4 {
+    float v[4];
+};
+
+__device__ __forceinline__ F4 f4_zero() { return F4{{0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ F4 f4_fill(float x) { return F4{{x, x, x, x}}; }
+
+// ---------------------------------------------------------------------------------------------
+// epilogue
+// ---------------------------------------------------------------------------------------------
+struct Epilogue {
+    float* c;            // C[i*ldc + j]
+    long ldc;
+    const float* bias;   // per column, may be null
+    int act;             // UOCR_ACT_*
+    float alpha;
+    int accumulate;      // C += value
+    // conv dw/db: rows >= split_row go to c2[j] instead (the bias row of [x~,1]^T.dy)
+    int split_row;       // -1 = disabled
+    float* c2;
+};
+
+__device__ __forceinline__ float act_apply(float v, int act, float alpha) {
+    switch (act) {
+        case UOCR_ACT_RELU: return v * (v >= 0.f ? 1.f : 0.f);
+        case UOCR_ACT_LEAKY: return v * ((v >= 0.f ? 1.f : 0.f) + alpha * (v < 0.f ? 1.f : 0.f));
+        case UOCR_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ void epilogue_store(const Epilogue& e, int i, int j, float v) {
+    if (e.bias) v += e.bias[j];
+    v = act_apply(v, e.act, e.alpha);
+    float* dst = (e.split_row >= 0 && i >= e.split_row) ? e.c2 + j : e.c + (long)i * e.ldc + j;
+    *dst = e.accumulate ? *dst + v : v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// B operand: row-major [D][N]
+// ---------------------------------------------------------------------------------------------
+struct BRowMajor {
+    const float* b;
+    long ld;
+    int rows, n;       // valid extent
+    int vec_ok;        // rows 16-byte aligned (ld % 4 == 0, base aligned)
+    __device__ __forceinline__ F4 load(int d, int j) const {
+        if (d >= rows || j >= n) return f4_zero();
+        const float* p = b + (long)d * ld + j;
+        if (vec_ok && j + 3 < n) return *reinterpret_cast<const F4*>(p);
+        F4 r = f4_zero();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (j + q < n) r.v[q] = p[q];
+        return r;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// A loaders.  DEPTH_CONTIG loaders give A(i, d0..d0+3); the others give A(i0..i0+3, d).
+// ---------------------------------------------------------------------------------------------
+// dense forward / dense dx: A(i,d) = a[i*ld + d]; optional virtual last column of ones ([x,1])
+struct ARowMajor {
+    static constexpr bool DEPTH_CONTIG = true;
+    const float* a;
+    long ld;
+    int m, stored;     // stored = number of stored columns; column `stored` is the ones column
+    int ones_col;
+    int vec_ok;
+    struct Row {
+        const float* p;
+        bool ok;
+    };
+    __device__ __forceinline__ Row prep(int i) const { return Row{a + (long)i * ld, i < m}; }
+    __device__ __forceinline__ F4 load(const Row& r, int tile, int kq) const {
+        const int d0 = tile * BD + kq * 4;
+        if (!r.ok) return f4_zero();
+        if (vec_ok && d0 + 3 < stored) return *reinterpret_cast<const F4*>(r.p + d0);
+        F4 out = f4_zero();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int d = d0 + q;
+            if (d < stored) out.v[q] = r.p[d];
+            else if (ones_col && d == stored) out.v[q] = 1.f;
+        }
+        return out;
+    }
+};
+
+// dense dw: A(i,d) = a[d*ld + i] (= x^T); optional virtual last ROW of ones ([x,1]^T)
+struct AColMajor {
+    static constexpr bool DEPTH_CONTIG = false;
+    const float* a;
+    long ld;
+    int stored_rows;   // rows i < stored_rows are stored; row `stored_rows` is the ones row
+    int ones_row;
+    int depth;
+    int vec_ok;
+    struct Row {
+        int i0;
+    };
+    __device__ __forceinline__ Row prep(int i0) const { return Row{i0}; }
+    __device__ __forceinline__ F4 load(const Row& r, int d) const {
+        if (d >= depth) return f4_zero();
+        const float* p = a + (long)d * ld + r.i0;
+        if (vec_ok && r.i0 + 3 < stored_rows) return *reinterpret_cast<const F4*>(p);
+        F4 out = f4_zero();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = r.i0 + q;
+            if (i < stored_rows) out.v[q] = p[q];
+            else if (ones_row && i == stored_rows) out.v[q] = 1.f;
+        }
+        return out;
+    }
+};
+
+// conv forward: rows = output pixels, depth = (ky,kx,ic); requires cin % 32 == 0
+struct AConvFwd {
+    static constexpr bool DEPTH_CONTIG = true;
+    const float* x;
+    ConvDims d;
+    float pad;
+    int m;             // n*oh*ow
+    struct Row {
+        long base;     // offset of x[b, iy0, ix0, 0] (may be negative)
+        int iy0, ix0;
+        bool ok;
+    };
+    __device__ __forceinline__ Row prep(int i) const {
+        Row r;
+        r.ok = i < m;
+        const int p = r.ok ? i : 0;
+        const int ox = p % d.ow;
+        const int t = p / d.ow;
+        const int oy = t % d.oh, b = t / d.oh;
+        r.iy0 = oy * d.sh - d.ph;
+        r.ix0 = ox * d.sw - d.pw;
+        r.base = (((long)b * d.h + r.iy0) * d.w + r.ix0) * d.cin;
+        return r;
+    }
+    __device__ __forceinline__ F4 load(const Row& r, int tile, int kq) const {
+        const int cpt = d.cin / BD;
+        const int kk = tile / cpt, c0 = (tile - kk * cpt) * BD + kq * 4;
+        const int ky = kk / d.kw, kx = kk - ky * d.kw;
+        if (!r.ok) return f4_zero();
+        const int iy = r.iy0 + ky, ix = r.ix0 + kx;
+        if (iy < 0 || iy >= d.h || ix < 0 || ix >= d.w) return f4_fill(pad);
+        return *reinterpret_cast<const F4*>(x + r.base + ((long)ky * d.w + kx) * d.cin + c0);
+    }
+};
+
+// conv dx: rows = input pixels, depth = (ky,kx,oc); requires cout % 32 == 0
+struct AConvDgrad {
+    static constexpr bool DEPTH_CONTIG = true;
+    const float* dy;
+    ConvDims d;
+    int m;             // n*h*w
+    struct Row {
+        int b, y, x;
+        bool ok;
+    };
+    __device__ __forceinline__ Row prep(int i) const {
+        Row r;
+        r.ok = i < m;
+        const int p = r.ok ? i : 0;
+        r.x = p % d.w;
+        const int t = p / d.w;
+        r.y = t % d.h;
+        r.b = t / d.h;
+        return r;
+    }
+    __device__ __forceinline__ F4 load(const Row& r, int tile, int kq) const {
+        const int cpt = d.cout / BD;
+        const int kk = tile / cpt, c0 = (tile - kk * cpt) * BD + kq * 4;
+        const int ky = kk / d.kw, kx = kk - ky * d.kw;
+        if (!r.ok) return f4_zero();
+        const int ty = r.y + d.ph - ky, tx = r.x + d.pw - kx;
+        if (ty < 0 || tx < 0) return f4_zero();
+        const int gy = ty / d.sh, gx = tx / d.sw;
+        if (gy * d.sh != ty || gx * d.sw != tx || gy >= d.oh || gx >= d.ow) return f4_zero();
+        return *reinterpret_cast<const F4*>(dy + (((long)r.b * d.oh + gy) * d.ow + gx) * d.cout + c0);
+    }
+};
+
+// conv dw/db: rows = (ky,kx,ic) [+ one bias row], depth = output pixels; requires cin % 4 == 0
+struct AConvWgrad {
+    static constexpr bool DEPTH_CONTIG = false;
+    const float* x;
+    ConvDims d;
+    float pad;
+    int K;             // kh*kw*cin
+    int use_bias;
+    int depth;         // n*oh*ow
+    struct Row {
+        int ky, kx, ic0;
+        int kind;      // 0 = weights rows, 1 = bias row group, 2 = beyond
+    };
+    __device__ __forceinline__ Row prep(int i0) const {
+        Row r;
+        if (i0 < K) {
+            const int kk = i0 / d.cin;
+            r.ic0 = i0 - kk * d.cin;
+            r.ky = kk / d.kw;
+            r.kx = kk - r.ky * d.kw;
+            r.kind = 0;
+        } else {
+            r.ky = r.kx = r.ic0 = 0;
+            r.kind = (i0 == K && use_bias) ? 1 : 2;
+        }
+        return r;
+    }
+    __device__ __forceinline__ F4 load(const Row& r, int p) const {
+        if (p >= depth || r.kind == 2) return f4_zero();
+        if (r.kind == 1) return F4{{1.f, 0.f, 0.f, 0.f}};
+        const int ox = p % d.ow;
+        const int t = p / d.ow;
+        const int oy = t % d.oh, b = t / d.oh;
+        const int iy = oy * d.sh - d.ph + r.ky, ix = ox * d.sw - d.pw + r.kx;
+        if (iy < 0 || iy >= d.h || ix < 0 || ix >= d.w) return f4_fill(pad);
+        return *reinterpret_cast<const F4*>(x + (((long)b * d.h + iy) * d.w + ix) * d.cin + r.ic0);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------
+template <int BM, typename ALoader>
+__global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, Epilogue ep, int M, int N,
+                                                        int ntiles, int tiles_per_split, float* slabs) {
+    constexpr int WM = BM / 32;            // waves along M: 4 or 2
+    constexpr int WN = 4 / WM;             // waves along N: 1 or 2
+    constexpr int NB = (BN / WN) / 32;     // 32x32 blocks per wave along N: 2 or 1
+    constexpr int A_PASSES = BM / 32;      // depth-contiguous staging: 32 rows per pass
+    constexpr int AM_GROUPS = BM / 4;      // m-contiguous staging: float4 groups along M
+    constexpr int AM_ROWS = 256 / AM_GROUPS;   // depth rows covered per pass: 8 or 16
+    constexpr int AM_PASSES = BD / AM_ROWS;    // 4 or 2
+    constexpr int A_REGS = ALoader::DEPTH_CONTIG ? A_PASSES : AM_PASSES;
+
+    __shared__ float As[2][BM * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BD * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int t_begin = blockIdx.z * tiles_per_split;
+    const int t_end = min(ntiles, t_begin + tiles_per_split);
+
+    // ---- staging assignment ----
+    typename ALoader::Row rows[ALoader::DEPTH_CONTIG ? A_PASSES : 1];
+    int a_kq = 0, a_r = 0, a_iq = 0, a_pr = 0;
+    if constexpr (ALoader::DEPTH_CONTIG) {
+        a_kq = tid & 7;
+        a_r = tid >> 3;
+#pragma unroll
+        for (int s = 0; s < A_PASSES; ++s) rows[s] = A.prep(m0 + a_r + 32 * s);
+    } else {
+        a_iq = tid % AM_GROUPS;
+        a_pr = tid / AM_GROUPS;
+        rows[0] = A.prep(m0 + a_iq * 4);
+    }
+    const int b_nq = tid & 15, b_kr = tid >> 4;
+
+    F4 areg[A_REGS], breg[2];
+    auto load_tile = [&](int t) {
+        if constexpr (ALoader::DEPTH_CONTIG) {
+#pragma unroll
+            for (int s = 0; s < A_PASSES; ++s) areg[s] = A.load(rows[s], t, a_kq);
+        } else {
+#pragma unroll
+            for (int s = 0; s < AM_PASSES; ++s) areg[s] = A.load(rows[0], t * BD + a_pr + AM_ROWS * s);
+        }
+        breg[0] = B.load(t * BD + b_kr, n0 + b_nq * 4);
+        breg[1] = B.load(t * BD + b_kr + 16, n0 + b_nq * 4);
+    };
+    auto store_tile = [&](int buf) {
+        float* as = As[buf];
+        if constexpr (ALoader::DEPTH_CONTIG) {
+#pragma unroll
+            for (int s = 0; s < A_PASSES; ++s)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) as[(a_r + 32 * s) * LDA + a_kq * 4 + q] = areg[s].v[q];
+        } else {
+#pragma unroll
+            for (int s = 0; s < AM_PASSES; ++s)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) as[(a_iq * 4 + q) * LDA + a_pr + AM_ROWS * s] = areg[s].v[q];
+        }
+        *reinterpret_cast<F4*>(&Bs[buf][b_kr * BN + b_nq * 4]) = breg[0];
+        *reinterpret_cast<F4*>(&Bs[buf][(b_kr + 16) * BN + b_nq * 4]) = breg[1];
+    };
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    const int wm = wave % WM, wn = wave / WM;
+    const int fi = wm * 32 + (lane & 31);        // A fragment row of this lane
+    const int fk = lane >> 5;                    // depth offset inside a 2-deep MFMA step
+    const int fj = wn * (BN / WN) + (lane & 31); // B fragment column (first 32x32 block)
+
+    if (t_begin < t_end) {
+        load_tile(t_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        const bool more = t + 1 < t_end;
+        if (more) load_tile(t + 1);
+        const float* as = As[buf];
+        const float* bs = Bs[buf];
+#pragma unroll
+        for (int k = 0; k < BD; k += 2) {
+            const float a = as[fi * LDA + k + fk];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float b = bs[(k + fk) * BN + fj + nb * 32];
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nb], 0, 0, 0);
+            }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int j = n0 + fj + nb * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (i < M && j < N) {
+                if (slabs) slabs[((long)blockIdx.z * M + i) * N + j] = acc[nb][r];
+                else epilogue_store(ep, i, j, acc[nb][r]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nsplit, int M, int N,
+                                                          Epilogue ep) {
+    const long total = (long)M * N;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int z = 0; z < nsplit; ++z) v += slabs[(long)z * total + idx];
+        epilogue_store(ep, (int)(idx / N), (int)(idx % N), v);
+    }
+}
+
+// out[c*rows + r] = in[r*cols + c]  (weights are small: <= 2 MB)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        int rows, int cols) {
+    const long total = (long)rows * cols;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx / rows), r = (int)(idx % rows);
+        out[idx] = in[(long)r * cols + c];
+    }
+}
+
+// wt[(kk*cout + oc)*cin + ic] = w[(kk*cin + ic)*cout + oc]
+__global__ __launch_bounds__(256) void conv_weight_transpose_kernel(const float* __restrict__ w,
+                                                                    float* __restrict__ wt, int kk_count, int cin,
+                                                                    int cout) {
+    const long total = (long)kk_count * cin * cout;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ic = (int)(idx % cin);
+        const long t = idx / cin;
+        const int oc = (int)(t % cout), kk = (int)(t / cout);
+        wt[idx] = w[((long)kk * cin + ic) * cout + oc];
+    }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// workspace layout for this file: [0, half) split-D slabs, [half, end) transposed weights
+inline float* ws_slabs(uocr_ctx* ctx) { return (float*)ctx->workspace; }
+inline float* ws_aux(uocr_ctx* ctx) { return (float*)((char*)ctx->workspace + ctx->workspace_bytes / 2); }
+inline size_t ws_half(uocr_ctx* ctx) { return ctx->workspace_bytes / 2; }
+
+template <typename ALoader>
+int launch_mfma(uocr_ctx* ctx, const ALoader& A, const BRowMajor& B, const Epilogue& ep, int M, int N, int depth,
+                bool allow_split) {
+    const int ntiles = (depth + BD - 1) / BD;
+    const int bm = ((long)((M + 127) / 128) * ((N + BN - 1) / BN) >= 512) ? 128 : 64;
+    const int gm = (M + bm - 1) / bm, gn = (N + BN - 1) / BN;
+    int nsplit = 1;
+    if (allow_split && gm * gn < 256 && ntiles >= 8) {
+        nsplit = (512 + gm * gn - 1) / (gm * gn);
+        if (nsplit > ntiles / 4) nsplit = ntiles / 4;
+        if (nsplit > 32) nsplit = 32;
+        const size_t per = (size_t)M * N * sizeof(float);
+        if ((size_t)nsplit * per > ws_half(ctx)) nsplit = (int)(ws_half(ctx) / per);
+        if (nsplit < 1) nsplit = 1;
+    }
+    const int tps = (ntiles + nsplit - 1) / nsplit;
+    nsplit = (ntiles + tps - 1) / tps;
+    float* slabs = nsplit > 1 ? ws_slabs(ctx) : nullptr;
+    const dim3 grid(gm, gn, nsplit), block(256);
+    if (bm == 128)
+        hipLaunchKernelGGL((mfma_gemm_kernel<128, ALoader>), grid, block, 0, ctx->stream, A, B, ep, M, N, ntiles, tps,
+                           slabs);
+    else
+        hipLaunchKernelGGL((mfma_gemm_kernel<64, ALoader>), grid, block, 0, ctx->stream, A, B, ep, M, N, ntiles, tps,
+                           slabs);
+    UOCR_LAUNCH_CHECK(ctx);
+    if (nsplit > 1) {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(uocr_blocks_for((size_t)M * N, 256, 1024)), dim3(256), 0,
+                           ctx->stream, (const float*)slabs, nsplit, M, N, ep);
+        UOCR_LAUNCH_CHECK(ctx);
+    }
+    return UOCR_OK;
+}
+
+inline Epilogue plain_epilogue(float* c, long ldc, int accumulate) {
+    return Epilogue{c, ldc, nullptr, UOCR_ACT_NONE, 0.f, accumulate, -1, nullptr};
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// entry points used by the dispatchers (gemm_dispatch.hip, conv_api.hip)
+// ---------------------------------------------------------------------------------------------
+bool uocr_gemm_mfma_eligible(uocr_ctx* ctx, int dtype, const GemmArgs& g) {
+    if (dtype != UOCR_F32 || ctx->opt_mfma == 0) return false;
+    const bool a_row = (g.a_cs == 1), a_col = (g.a_rs == 1 && !a_row);
+    if (!(a_row || a_col)) return false;
+    if (!(g.b_cs == 1 || g.b_rs == 1)) return false;
+    if (g.b_cs != 1 && (g.b_cs != g.depth || (size_t)g.n * g.depth * sizeof(float) > ws_half(ctx))) return false;
+    if (ctx->opt_mfma == 2) return true;
+    return (double)g.m * g.n * g.depth >= 4.0e6 && g.n >= 32 && g.m >= 32;
+}
+
+int uocr_gemm_mfma(uocr_ctx* ctx, const GemmArgs& g) {
+    // B must be row-major [depth][n]; a transposed B (dense dx: w[:-1]^T) is transposed into the workspace
+    BRowMajor B;
+    if (g.b_cs == 1) {
+        B = BRowMajor{(const float*)g.b, g.b_rs, g.depth, g.n, (g.b_rs % 4 == 0 && aligned16(g.b)) ? 1 : 0};
+    } else {
+        float* bt = ws_aux(ctx);     // B(p,j) = b[p + j*b_cs]: stored as [n][b_cs]; take its transpose
+        // in[r = j][c = p] with cols = b_cs (only the first `depth` columns are used) -> out[p*n + j]
+        hipLaunchKernelGGL(transpose_kernel, dim3(uocr_blocks_for((size_t)g.n * g.depth, 256, 1024)), dim3(256), 0,
+                           ctx->stream, (const float*)g.b, bt, g.n, (int)g.b_cs);
+        UOCR_LAUNCH_CHECK(ctx);
+        // transpose_kernel wrote out[c*rows + r] for c < cols = b_cs; rows = n  => out[p*n + j]
+        B = BRowMajor{bt, g.n, g.depth, g.n, (g.n % 4 == 0) ? 1 : 0};
+    }
+    const Epilogue ep = plain_epilogue((float*)g.c, g.ldc, g.accumulate);
+    if (g.a_cs == 1) {
+        const int stored = g.a_ones_col ? g.depth - 1 : g.depth;
+        ARowMajor A{(const float*)g.a, g.a_rs, g.m, stored, g.a_ones_col, (g.a_rs % 4 == 0 && aligned16(g.a)) ? 1 : 0};
+        return launch_mfma(ctx, A, B, ep, g.m, g.n, g.depth, true);
+    }
+    const int stored_rows = g.a_ones_row ? g.m - 1 : g.m;
+    AColMajor A{(const float*)g.a, g.a_cs, stored_rows, g.a_ones_row, g.depth, (g.a_cs % 4 == 0 && aligned16(g.a)) ? 1 : 0};
+    return launch_mfma(ctx, A, B, ep, g.m, g.n, g.depth, true);
+}
+
+bool uocr_conv_mfma_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d, int which /*0 fwd, 1 dgrad, 2 wgrad*/) {
+    if (dtype != UOCR_F32 || ctx->opt_mfma == 0) return false;
+    if (d.cout % 4 || d.cin % 4) return false;
+    if (which == 0 && d.cin % BD) return false;
+    if (which == 1 && d.cout % BD) return false;
+    if (which == 1 && (size_t)d.kh * d.kw * d.cin * d.cout * sizeof(float) > ws_half(ctx)) return false;
+    if (ctx->opt_mfma == 2) return true;
+    return d.cin >= 16 && d.cout >= 16;
+}
+
+int uocr_conv_fwd_mfma(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
+                       double pad_value, int use_bias, int act, double act_alpha) {
+    const int M = d.n * d.oh * d.ow, K = d.kh * d.kw * d.cin;
+    AConvFwd A{(const float*)x, d, (float)pad_value, M};
+    BRowMajor B{(const float*)w, d.cout, K, d.cout, aligned16(w) ? 1 : 0};
+    Epilogue ep{(float*)y, d.cout, use_bias ? (const float*)b : nullptr, act, (float)act_alpha, 0, -1, nullptr};
+    return launch_mfma(ctx, A, B, ep, M, d.cout, K, false);
+}
+
+int uocr_conv_dgrad_mfma(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d) {
+    const int M = d.n * d.h * d.w, D = d.kh * d.kw * d.cout;
+    float* wt = ws_aux(ctx);
+    hipLaunchKernelGGL(conv_weight_transpose_kernel, dim3(uocr_blocks_for((size_t)D * d.cin, 256, 1024)), dim3(256),
+                       0, ctx->stream, (const float*)w, wt, d.kh * d.kw, d.cin, d.cout);
+    UOCR_LAUNCH_CHECK(ctx);
+    AConvDgrad A{(const float*)dy, d, M};
+    BRowMajor B{wt, d.cin, D, d.cin, 1};
+    const Epilogue ep = plain_epilogue((float*)dx, d.cin, 0);
+    return launch_mfma(ctx, A, B, ep, M, d.cin, D, false);
+}
+
+int uocr_conv_wgrad_mfma(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
+                         double pad_value, int use_bias, int accumulate) {
+    const int K = d.kh * d.kw * d.cin, P = d.n * d.oh * d.ow;
+    const int M = K + (use_bias ? 1 : 0);
+    AConvWgrad A{(const float*)x, d, (float)pad_value, K, use_bias, P};
+    BRowMajor B{(const float*)dy, d.cout, P, d.cout, aligned16(dy) ? 1 : 0};
+    Epilogue ep{(float*)dw, d.cout, nullptr, UOCR_ACT_NONE, 0.f, accumulate, use_bias ? K : -1, (float*)db};
+    int rc = launch_mfma(ctx, A, B, ep, M, d.cout, P, true);
+    if (rc) return rc;
+    if (!use_bias && !accumulate) UOCR_HIP(ctx, hipMemsetAsync(db, 0, (size_t)d.cout * sizeof(float), ctx->stream));
+    return UOCR_OK;
+}

@@ -14,6 +14,8 @@ struct uocr_ctx {
     void* workspace;
     size_t workspace_bytes;
     int cu_count;
+    int opt_mfma;        // 0 = never, 1 = auto (default), 2 = whenever eligible (tests)
+    int opt_fast;        // 0 = generic kernels only, 1 = shape-specialised fast paths (default)
     char err[512];
 };
 

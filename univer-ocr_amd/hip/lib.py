@@ -41,6 +41,7 @@ _PROTOS = {
     'uocr_ctx_destroy': [_ctx],
     'uocr_ctx_set_stream': [_ctx, _vp],
     'uocr_ctx_reserve_workspace': [_ctx, _sz],
+    'uocr_ctx_set_option': [_ctx, C.c_char_p, _i],
     'uocr_malloc': [_ctx, _sz, C.POINTER(_vp)],
     'uocr_free': [_ctx, _vp],
     'uocr_memset_zero': [_ctx, _vp, _sz],

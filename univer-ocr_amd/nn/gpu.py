@@ -67,6 +67,11 @@ class Runtime:
         import ctypes as C
         self.call('uocr_ctx_set_stream', C.c_void_p(torch_stream.cuda_stream))
 
+    def set_option(self, key, value):
+        """Kernel selection knobs of the C ABI: 'mfma' (0 never / 1 auto / 2 whenever eligible),
+        'fast_paths' (0 generic kernels only / 1 shape-specialised)."""
+        self.call('uocr_ctx_set_option', key.encode(), int(value))
+
     def synchronize(self):
         self.call('uocr_stream_sync')
 

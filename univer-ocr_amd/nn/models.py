@@ -107,6 +107,9 @@ class Model(BaseModel):
         self.is_initialized = False
         self._plan = None
         self._pack = None
+        self.grad_sync = None            # set by parallel.DataParallel
+        self.defer_grad_sync = False     # True: the all-reduce is waited for in train_finish()
+        self._pending_losses = None
         self._receptive_fields = {}
         self.layers, self.relations = None, None
         self.unravel_model()
@@ -224,7 +227,7 @@ class Model(BaseModel):
     def _loss_func(self, key):
         return self.loss[key] if isinstance(self.loss, list) else self.loss
 
-    def compute_loss_and_gradients(self, X, y):
+    def _forward_loss_backward(self, X, y):
         predicted = self.forward(make_list_if_not(X))
         y = make_list_if_not(y)
         losses, gradients = [], []
@@ -233,10 +236,32 @@ class Model(BaseModel):
             losses.append(loss)
             gradients.append(grad)
         self.backward(gradients)
+        if self.grad_sync is not None:
+            self.grad_sync(self)                      # data parallel: RCCL all-reduce of pack.grad
+        return losses
+
+    def compute_loss_and_gradients(self, X, y):
+        losses = self._forward_loss_backward(X, y)
+        if self.grad_sync is not None and self.defer_grad_sync:
+            self.grad_sync.__self__.wait(self)
         return {'output_losses': losses, 'regularization_loss': self.regularize()}
 
     def train(self, X, y):
         losses = self.compute_loss_and_gradients(X, y)
+        self.update_grads()
+        self.clear_grads()
+        return losses
+
+    # two-phase train step: lets a data-parallel driver overlap this model's gradient all-reduce
+    # with the next model's forward/backward (parallel.DataParallel, my_model/trainer.py)
+    def train_begin(self, X, y):
+        self._pending_losses = self._forward_loss_backward(X, y)
+
+    def train_finish(self):
+        if self.grad_sync is not None and self.defer_grad_sync:
+            self.grad_sync.__self__.wait(self)
+        losses = {'output_losses': self._pending_losses, 'regularization_loss': self.regularize()}
+        self._pending_losses = None
         self.update_grads()
         self.clear_grads()
         return losses
