@@ -119,3 +119,46 @@ def test_mfma_identity_with_asymmetric_b(f32):
     CP.runtime().set_option('mfma', 2)
     y = CP.asnumpy(ops.dense_fwd(CP.copy(X), CP.copy(w)))
     assert np.array_equal(y, (w[:n] + 1000.0).astype(np.float32))
+
+
+FAST_SHAPES = [
+    # (x shape, kernel, cout, stride, padding): the nine instantiated my_model configurations, on
+    # odd-sized images (partial 64x4 tiles, several row bands, border taps) with pad_value 0.25
+    ((3, 37, 83, 1), (3, 3), 16, (1, 1), (1, 1)),
+    ((3, 37, 83, 16), (3, 3), 1, (1, 1), (1, 1)),
+    ((2, 41, 77, 1), (5, 5), 1, (2, 2), (2, 2)),
+    ((2, 41, 77, 1), (5, 5), 1, (1, 1), (2, 2)),
+    ((2, 41, 77, 1), (5, 5), 4, (2, 2), (2, 2)),
+    ((2, 41, 77, 4), (5, 5), 4, (2, 2), (2, 2)),
+    ((2, 41, 77, 4), (5, 5), 4, (1, 1), (2, 2)),
+    ((2, 41, 77, 4), (5, 5), 2, (1, 1), (2, 2)),
+    ((3, 32, 70, 1), (5, 3), 64, (2, 1), (0, 1)),
+    ((5, 64, 130, 16), (3, 3), 1, (1, 1), (1, 1)),     # more rows than one band per image
+]
+
+
+@pytest.mark.parametrize('case', range(len(FAST_SHAPES)))
+@pytest.mark.parametrize('pad_value,bias', [(0.0, True), (0.25, False)])
+def test_fast_conv_kernels_against_oracle(case, pad_value, bias, f32):
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    xs, ks, cout, st, pd = FAST_SHAPES[case]
+    rng = np.random.default_rng(90 + case)
+    X = rng.standard_normal(xs)
+    w = rng.standard_normal((*ks, xs[3], cout)) * 0.2
+    b = rng.standard_normal(cout)
+    ref_y = O.conv2d_fwd(X, w, b, st, pd, pad_value, bias)
+    g = rng.standard_normal(ref_y.shape)
+    ref_dx, ref_dw, ref_db = O.conv2d_bwd(X, w, g, st, pd, pad_value, bias)
+    results = {}
+    for mode in ('fast', 'generic'):
+        CP.runtime().set_option('fast_paths', 1 if mode == 'fast' else 0)
+        CP.runtime().set_option('mfma', 0)
+        results[mode] = run_conv(CP, ops, X, w, b, g, st, pd, pad_value, bias)
+        y, dx, dw, db = results[mode]
+        check(y, ref_y, 1e-5, f'{mode} y')
+        check(dx, ref_dx, 1e-5, f'{mode} dx')
+        check(dw, ref_dw + 0.5, 2e-5, f'{mode} dw')
+        check(db, ref_db + 0.25, 2e-5, f'{mode} db')
+    # the two kernels must have actually been different code paths yet agree closely
+    check(results['fast'][0], CP.asnumpy(results['generic'][0]).astype(np.float64), 1e-5, 'fast vs generic y')

@@ -27,6 +27,8 @@ int uocr_conv2d_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, cons
     if (rc) return rc;
     UOCR_REQUIRE(ctx, x && w && y && (b || !use_bias));
     UOCR_REQUIRE(ctx, act >= UOCR_ACT_NONE && act <= UOCR_ACT_SIGMOID);
+    if (uocr_conv_fast_eligible(ctx, dtype, d, x, y, w))
+        return uocr_conv_fwd_fast(ctx, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
     if (uocr_conv_mfma_eligible(ctx, dtype, d, 0))
         return uocr_conv_fwd_mfma(ctx, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
     return uocr_conv_fwd_generic(ctx, dtype, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
@@ -39,6 +41,7 @@ int uocr_conv2d_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, const void* w
     int rc = check_dims(ctx, d);
     if (rc) return rc;
     UOCR_REQUIRE(ctx, dy && w && dx);
+    if (uocr_conv_fast_eligible(ctx, dtype, d, dy, dx, w)) return uocr_conv_dgrad_fast(ctx, dy, w, dx, d);
     if (uocr_conv_mfma_eligible(ctx, dtype, d, 1)) return uocr_conv_dgrad_mfma(ctx, dy, w, dx, d);
     return uocr_conv_dgrad_generic(ctx, dtype, dy, w, dx, d);
 }
@@ -51,6 +54,8 @@ int uocr_conv2d_bwd_weight(uocr_ctx* ctx, int dtype, const void* x, const void* 
     int rc = check_dims(ctx, d);
     if (rc) return rc;
     UOCR_REQUIRE(ctx, x && dy && dw && db);
+    if (uocr_conv_fast_eligible(ctx, dtype, d, x, dy, dw))
+        return uocr_conv_wgrad_fast(ctx, x, dy, dw, db, d, pad_value, use_bias, accumulate);
     if (uocr_conv_mfma_eligible(ctx, dtype, d, 2))
         return uocr_conv_wgrad_mfma(ctx, x, dy, dw, db, d, pad_value, use_bias, accumulate);
     return uocr_conv_wgrad_generic(ctx, dtype, x, dy, dw, db, d, pad_value, use_bias, accumulate);
