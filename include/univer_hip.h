@@ -119,6 +119,11 @@ int uocr_act_fwd(uocr_ctx* ctx, int dtype, int kind, double alpha, const void* x
 int uocr_act_bwd(uocr_ctx* ctx, int dtype, int kind, double alpha, const void* x, const void* dy,
                  void* dx, size_t count);
 
+/* same gradient computed from the layer's OUTPUT y (conv + activation fused: the pre-activation is
+ * never stored).  kind = UOCR_ACT_LEAKY (alpha > 0: sign(y) == sign(x)) or UOCR_ACT_SIGMOID (y(1-y)) */
+int uocr_act_bwd_from_output(uocr_ctx* ctx, int dtype, int kind, double alpha, const void* y, const void* dy,
+                             void* dx, size_t count);
+
 /* ---- FullyConnected (layers/layers.py:307-363) -------------------------------------------- */
 int uocr_dense_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, void* y,
                    int m, int n_in, int n_out);

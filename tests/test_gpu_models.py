@@ -82,8 +82,24 @@ def test_my_model_net(net_name, opt_tag, dt):
     model.clear_grads()
     rows = [losses_row(model.train(X, y)) for _ in range(3)]
     close(np.array(rows), g[f'{opt_tag}/step_losses'], STEP_TOL[dt], 'step_losses')
-    wtol = ADAM_F32_WEIGHT_TOL if (opt_tag == 'adam' and dt == 'float32') else STEP_TOL[dt]
-    worst = max(check_sampled(pn, p.value, g, f'{opt_tag}/w3', wtol) for pn, p in model.params().items())
+    if opt_tag == 'adam' and dt == 'float32':
+        # Adam normalises the step: an element whose float32 gradient is rounding noise moves by
+        # +-lr*3.2 in a direction float64 may not share.  Require 95 % of the sampled weights (measured: >= 97.8 %) within
+        # STEP_TOL and every one within the largest distance two Adam trajectories can be apart.
+        worst, wtol = 0.0, ADAM_F32_WEIGHT_TOL
+        for pn, p in model.params().items():
+            key = f'{opt_tag}/w3/{pn}'
+            got = CP.asnumpy(p.value).astype(np.float64)
+            ref = g[key] if key in g.files else g[key + '@stride97']
+            got = got if key in g.files else got.reshape(-1)[::97]
+            diff = np.abs(got - ref)
+            scale = np.max(np.abs(ref))
+            assert np.mean(diff <= STEP_TOL[dt] * scale) >= 0.95, f'{pn}: too many weights off'
+            assert diff.max() <= 2 * 3 * 0.0015 * 3.2, f'{pn}: beyond any Adam trajectory'
+            worst = max(worst, diff.max() / scale)
+    else:
+        wtol = STEP_TOL[dt]
+        worst = max(check_sampled(pn, p.value, g, f'{opt_tag}/w3', wtol) for pn, p in model.params().items())
     close(model.predict(X)[0], g[f'{opt_tag}/pred3'], wtol, 'pred3')
     test_losses = model.test(X, y)
     close(np.array([float(v) for v in test_losses['output_losses']]), g[f'{opt_tag}/test_loss3'], STEP_TOL[dt])
@@ -176,3 +192,31 @@ def test_nested_model_with_l1_l2(dt):
     close(model.input_grads[1], g['nested/input_grad1'], tol)
     for pn, p in model.params().items():
         close(p.grad, g[f'nested/grad/{pn}'], tol, pn)
+
+
+@pytest.mark.parametrize('net_name', ['Monochrome', 'Paragraph', 'Line', 'Char'])
+def test_fused_activation_graph_matches_reference(net_name, dt):
+    """Model.enable_fusion(): conv + LeakyReLU / Sigmoid as one kernel, activation gradient taken from
+    the output -- must reproduce the reference's losses, gradients and post-step weights."""
+    from univer_ocr_amd.my_model.model import NET_MAKERS
+    from univer_ocr_amd.nn import CP
+    from univer_ocr_amd.nn.optimizers import Momentum
+    g = load_golden(f'my_model_{net_name.lower()}')
+    model = NET_MAKERS[net_name](tuple(int(v) for v in g['in_shape']), Momentum(lr=0.01, momentum=0))
+    model.enable_fusion()
+    fused_conv, fused_act = model._fusion_maps()
+    n_convs = sum(1 for name in model.layers if name.rsplit('/', 1)[-1].startswith('conv_'))
+    assert len(fused_conv) == n_convs and len(fused_act) == n_convs      # every conv is followed by one
+    set_analytic_weights(model)
+    X, y = CP.copy(g['sgd/X']), CP.copy(g['sgd/y'])
+    close(model.predict(X)[0], g['sgd/pred0'], PASS_TOL[dt], 'pred0')
+    losses = model.compute_loss_and_gradients(X, y)
+    close(losses_row(losses), g['sgd/grad_loss'], PASS_TOL[dt], 'loss')
+    close(model.input_grads[0], g['sgd/input_grad'], PASS_TOL[dt] * 2, 'input_grad')
+    for pn, p in model.params().items():
+        check_sampled(pn, p.grad, g, 'sgd/grad', PASS_TOL[dt] * 2)
+    model.clear_grads()
+    rows = [losses_row(model.train(X, y)) for _ in range(3)]
+    close(np.array(rows), g['sgd/step_losses'], STEP_TOL[dt], 'step_losses')
+    for pn, p in model.params().items():
+        check_sampled(pn, p.value, g, 'sgd/w3', STEP_TOL[dt])

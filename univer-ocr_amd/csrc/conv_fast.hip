@@ -79,15 +79,20 @@ struct FastDims {
 };
 
 // ---------------------------------------------------------------------------------------------
-// forward: block (64, 4) = 64 x 4 output pixels of image blockIdx.z; COB output channels per thread
+// forward: block (64, 4); a thread computes COB output channels of one pixel and NQ = COUT / COB
+// adjacent lanes share a pixel, so one wave stores 64 * COB contiguous floats per instruction
+// (with one lane per pixel and COUT = 16 every store instruction would touch 64 B per lane at a
+// 64 B stride: 4 partial-line store instructions per wave instead of 4 full ones)
 // ---------------------------------------------------------------------------------------------
 template <int KH, int KW, int CIN, int COUT, int SH, int SW, int COB>
 __global__ __launch_bounds__(256) void conv_fwd_fast(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ y,
                                                      FastDims d, float pad, int use_bias, int act, float alpha) {
-    const int ox = blockIdx.x * 64 + threadIdx.x;
-    const int oy = (blockIdx.y / (COUT / COB)) * 4 + threadIdx.y;
-    const int oc0 = (blockIdx.y % (COUT / COB)) * COB;
+    constexpr int NQ = COUT / COB;     // lanes per pixel
+    constexpr int PXW = 64 / NQ;       // pixels per wave row
+    const int ox = blockIdx.x * PXW + threadIdx.x / NQ;
+    const int oy = blockIdx.y * 4 + threadIdx.y;
+    const int oc0 = (threadIdx.x % NQ) * COB;
     const int b = blockIdx.z;
     if (ox >= d.ow || oy >= d.oh) return;
     float acc[COB];
@@ -166,22 +171,31 @@ __global__ __launch_bounds__(256) void conv_dgrad_fast(const float* __restrict__
 // [kyg*KYR, (kyg+1)*KYR) and output channels [ocg*COB, (ocg+1)*COB).
 // accumulator a = ((kyl*KW + kx)*CIN + c)*COB + o ; db accumulators (tap group 0 only) follow.
 // ---------------------------------------------------------------------------------------------
+// One step per template instance: with the step as a runtime-looking loop variable hipcc (ROCm 7.2)
+// leaves acc[] in scratch memory for NP = 64 / 128 (528 B/lane of scratch traffic per FMA).
+template <int NP, int S>
+__device__ __forceinline__ void reduce_scatter_step(float (&acc)[NP], int lane) {
+    constexpr int bit = 32 >> S;
+    constexpr int half = NP >> (S + 1);
+    const bool up = lane & bit;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+        const float send = up ? acc[i] : acc[i + half];
+        const float keep = up ? acc[i + half] : acc[i];
+        acc[i] = keep + __shfl_xor(send, bit, 64);
+    }
+}
+
 template <int NP>
 __device__ __forceinline__ void lane_reduce_scatter(float (&acc)[NP], int lane) {
     // after the 6 steps lane L holds, in acc[0 .. NP/64), the full 64-lane sums of the original
     // indices base(L) + r with base(L) = sum_s bit_{5-s}(L) * NP / 2^(s+1)
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const int bit = 32 >> s;
-        const int half = NP >> (s + 1);
-        const bool up = lane & bit;
-#pragma unroll
-        for (int i = 0; i < half; ++i) {
-            const float send = up ? acc[i] : acc[i + half];
-            const float keep = up ? acc[i + half] : acc[i];
-            acc[i] = keep + __shfl_xor(send, bit, 64);
-        }
-    }
+    reduce_scatter_step<NP, 0>(acc, lane);
+    reduce_scatter_step<NP, 1>(acc, lane);
+    reduce_scatter_step<NP, 2>(acc, lane);
+    reduce_scatter_step<NP, 3>(acc, lane);
+    reduce_scatter_step<NP, 4>(acc, lane);
+    reduce_scatter_step<NP, 5>(acc, lane);
 }
 
 template <int KH, int KW, int CIN, int COUT, int SH, int SW, int KYR, int COB>
@@ -293,7 +307,8 @@ struct FastConv {
 
     static int fwd(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
                    double pad, int use_bias, int act, double alpha) {
-        const dim3 grid((d.ow + 63) / 64, ((d.oh + 3) / 4) * (COUT / COB), d.n), block(64, 4);
+        constexpr int PXW = 64 / (COUT / COB);
+        const dim3 grid((d.ow + PXW - 1) / PXW, (d.oh + 3) / 4, d.n), block(64, 4);
         hipLaunchKernelGGL((conv_fwd_fast<KH, KW, CIN, COUT, SH, SW, COB>), grid, block, 0, ctx->stream,
                            (const float*)x, (const float*)w, (const float*)b, (float*)y, dims(d), (float)pad, use_bias,
                            act, (float)alpha);
@@ -336,7 +351,7 @@ struct FastConv {
 
 // the my_model shapes:        KH KW CIN COUT SH SW  fwd-COB  wgrad-KYR  wgrad-COB
 #define UOCR_FAST_CONVS(X)                                                        \
-    X(3, 3, 1, 16, 1, 1, 16, 3, 16) /* Monochrome conv_1 */                       \
+    X(3, 3, 1, 16, 1, 1, 4, 3, 16)  /* Monochrome conv_1 */                       \
     X(3, 3, 16, 1, 1, 1, 1, 3, 1)   /* Monochrome conv_2 */                       \
     X(5, 5, 1, 1, 2, 2, 1, 5, 1)    /* Paragraph down_1/2 */                      \
     X(5, 5, 1, 1, 1, 1, 1, 5, 1)    /* Paragraph up_2, up_1, end */               \
@@ -344,7 +359,7 @@ struct FastConv {
     X(5, 5, 4, 4, 2, 2, 4, 1, 4)    /* Line down_2 */                             \
     X(5, 5, 4, 4, 1, 1, 4, 1, 4)    /* Line up_2, up_1 */                         \
     X(5, 5, 4, 2, 1, 1, 2, 1, 2)    /* Line end */                                \
-    X(5, 3, 1, 64, 2, 1, 16, 5, 8)  /* Char conv_1 */
+    X(5, 3, 1, 64, 2, 1, 4, 5, 8)   /* Char conv_1 */
 
 }  // namespace
 

@@ -123,6 +123,18 @@ struct SigmoidBwd {
     }
 };
 
+// backward from the layer's OUTPUT y (used when the activation is fused into the producing conv and
+// its input is never stored): leaky  y >= 0 <=> x >= 0 for alpha > 0;  sigmoid'  = y (1 - y)
+template <typename T>
+struct LeakyBwdFromOut {
+    T alpha;
+    __device__ T operator()(const T* a) const { return a[1] * (a[0] >= T(0) ? T(1) : alpha); }
+};
+template <typename T>
+struct SigmoidBwdFromOut {
+    __device__ T operator()(const T* a) const { return a[1] * a[0] * (T(1) - a[0]); }
+};
+
 template <typename T>
 struct AddOp {
     __device__ T operator()(const T* a) const { return a[0] + a[1]; }
@@ -320,6 +332,20 @@ int uocr_act_bwd(uocr_ctx* ctx, int dtype, int kind, double alpha, const void* x
             case UOCR_ACT_SIGMOID: return launch_map(ctx, a, count, SigmoidBwd<T>{});
             default: UOCR_FAIL(ctx, UOCR_ERR_ARG, "unknown activation kind %d", kind);
         }
+    });
+    return UOCR_OK;
+}
+
+int uocr_act_bwd_from_output(uocr_ctx* ctx, int dtype, int kind, double alpha, const void* y, const void* dy,
+                             void* dx, size_t count) {
+    UOCR_CHECK_CTX(ctx);
+    if (!count) return UOCR_OK;
+    UOCR_REQUIRE(ctx, y && dy && dx);
+    UOCR_REQUIRE(ctx, kind == UOCR_ACT_SIGMOID || (kind == UOCR_ACT_LEAKY && alpha > 0.0));
+    UOCR_DISPATCH(ctx, dtype, {
+        MapArgs<T, 2> a{(T*)dx, {(const T*)y, (const T*)dy}};
+        if (kind == UOCR_ACT_LEAKY) return launch_map(ctx, a, count, LeakyBwdFromOut<T>{(T)alpha});
+        return launch_map(ctx, a, count, SigmoidBwdFromOut<T>{});
     });
     return UOCR_OK;
 }

@@ -63,6 +63,7 @@ _PROTOS = {
     'uocr_upsample2d_bwd': [_ctx, _i, _vp, _vp] + [_i] * 6,
     'uocr_act_fwd': [_ctx, _i, _i, _d, _vp, _vp, _sz],
     'uocr_act_bwd': [_ctx, _i, _i, _d, _vp, _vp, _vp, _sz],
+    'uocr_act_bwd_from_output': [_ctx, _i, _i, _d, _vp, _vp, _vp, _sz],
     'uocr_dense_fwd': [_ctx, _i, _vp, _vp, _vp, _i, _i, _i],
     'uocr_dense_bwd': [_ctx, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     'uocr_fixed_width_fwd': [_ctx, _i, _vp, _vp] + [_i] * 5,

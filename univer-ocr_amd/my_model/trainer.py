@@ -27,7 +27,7 @@ def make_optimizer(name, lr):
 class PageTrainer:
     def __init__(self, batch, height=256, width=512, char_width=64, optimizer='sgd', lr=0.0015, seed=0,
                  nets=('Monochrome', 'Paragraph', 'Line', 'Char'), data_parallel=None, overlap=True,
-                 init='kaiming_normal'):
+                 init='kaiming_normal', fuse=True):
         np.random.seed(seed)                        # kaiming_uniform draws from the NumPy global RNG
         self.batch = batch
         self.optimizer = make_optimizer(optimizer, lr)
@@ -39,6 +39,8 @@ class PageTrainer:
         keep = [c for c in self.model_system.components if c.name in nets]
         self.model_system.components = keep
         self.models = {n: m for n, m in self.models.items() if n in nets}
+        for model in self.models.values():
+            model.enable_fusion(fuse)            # conv + LeakyReLU / Sigmoid as one forward kernel
         self.dp = None
         if data_parallel is None:
             data_parallel = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1

@@ -7,6 +7,7 @@ always adds the bias, :168-169), `padding_value` fills the border and contribute
 """
 from .. import ops
 from ..help_func import make_list_if_not, tuplize
+from ..progress_tracker import track_method
 from .layers import BaseLayer, BaseLayerGPU, Param
 
 
@@ -60,6 +61,27 @@ class Convolutional2D(BaseLayerGPU):
         ops.conv2d_bwd_weight(X, grad, self.w.grad, self.b.grad, self.stride, self.padding, self.padding_value,
                               self.bias, accumulate=True)
         return ops.conv2d_bwd_data(grad, self.w.value, X.shape, self.stride, self.padding)
+
+    # conv + following activation as ONE forward kernel (Model.enable_fusion): the pre-activation
+    # tensor is never written; backward recovers the activation gradient from the output
+    @track_method('forward')
+    def forward_fused(self, inputs, activation):
+        X = ops.as_device(make_list_if_not(inputs)[0])
+        assert X.shape[3] == self.in_channels
+        self._mem[0] = X
+        y = ops.conv2d_fwd(X, self.w.value, self.b.value, self.stride, self.padding, self.padding_value,
+                           self.bias, act=activation.kind, alpha=activation.alpha)
+        self._fused_out = y
+        return [y]
+
+    @track_method('backward')
+    def backward_fused(self, grads, activation):
+        grad = ops.as_device(make_list_if_not(grads)[0])
+        grad = ops.act_bwd_from_output(activation.kind, self._fused_out, grad, activation.alpha)
+        result = [self._backward(grad, 0)]
+        self._fused_out = None
+        self.clear_memory()
+        return result
 
     def get_output_shapes(self, input_shapes):
         batch, height, width, _ = make_list_if_not(input_shapes)[0]

@@ -192,9 +192,16 @@ class Model(BaseModel):
             self.initialize_from_X(inputs)
         self.clear_param_grads()                      # models.py:188 (per layer there, once here)
         outputs = {}
+        fused_conv, fused_act = self._fusion_maps()
         for node in self._plan:
+            if node in fused_act:                     # activation absorbed into its producing conv
+                outputs[node] = outputs[fused_act[node]]
+                continue
             args = [inputs[s] if isinstance(s, int) else outputs[s] for s in self.relations[node]]
-            out = self.layers[node].forward(args)
+            if node in fused_conv:
+                out = self.layers[node].forward_fused(args, self.layers[fused_conv[node]])
+            else:
+                out = self.layers[node].forward(args)
             outputs[node] = out[0] if isinstance(out, list) else out
         for k in range(self.outputs_count):
             src = self.relations[k][0]
@@ -216,13 +223,52 @@ class Model(BaseModel):
                 total = ops.add(total, extra)         # models.py:218
             return total
 
+        fused_conv, fused_act = self._fusion_maps()
         for node in reversed(self._plan):
             if node not in self.relations_backward:
                 continue
-            grads_mem[node] = make_list_if_not(self.layers[node].backward(incoming(node)))
+            if node in fused_act:                     # its gradient is applied inside the conv's backward
+                grads_mem[node] = [incoming(node)]
+            elif node in fused_conv:
+                grads_mem[node] = make_list_if_not(
+                    self.layers[node].backward_fused(incoming(node), self.layers[fused_conv[node]]))
+            else:
+                grads_mem[node] = make_list_if_not(self.layers[node].backward(incoming(node)))
         self.input_grads = {key: incoming(key) for key in range(self.inputs_count)
                             if key in self.relations_backward}
         return [self.input_grads[k] for k in range(self.inputs_count)]
+
+    # -- conv + activation fusion (graph level; reference: none -- every layer is its own pass) -----
+    def enable_fusion(self, on=True):
+        """Run every Convolutional2D whose ONLY consumer is a LeakyRelu(alpha > 0) / Sigmoid as one
+        kernel with the activation in the epilogue.  Results are the same tensors the unfused graph
+        produces for the activation layers; the conv's pre-activation output is not materialised
+        (layers_outputs[conv] then aliases the activation output)."""
+        self.fuse_activations = bool(on)
+        self._fusion = None
+        return self
+
+    def _fusion_maps(self):
+        if not getattr(self, 'fuse_activations', False):
+            return {}, {}
+        if self._fusion is None:
+            from .layers import Convolutional2D, LeakyRelu, Sigmoid
+            fused_conv, fused_act = {}, {}
+            for node in self._plan:
+                layer = self.layers[node]
+                consumers = self.relations_backward.get(node, {})
+                if not isinstance(layer, Convolutional2D) or len(consumers) != 1:
+                    continue
+                (dst, _), = consumers.items()
+                if isinstance(dst, int) or self.relations[dst] != [node]:
+                    continue
+                act = self.layers[dst]
+                ok = isinstance(act, Sigmoid) or (isinstance(act, LeakyRelu) and act.alpha > 0)
+                if ok and type(act) in (Sigmoid, LeakyRelu):
+                    fused_conv[node] = dst
+                    fused_act[dst] = node
+            self._fusion = (fused_conv, fused_act)
+        return self._fusion
 
     def _loss_func(self, key):
         return self.loss[key] if isinstance(self.loss, list) else self.loss
@@ -310,9 +356,34 @@ class Model(BaseModel):
         if not layers:
             return 0
         slot = CP.zeros((1,), np.float64)
-        for layer in layers:
-            layer.regularize(slot)
+        if self._pack is not None:
+            # neighbouring parameters with the same regulariser are one range of the flat pack
+            # (alignment gaps hold zeros and contribute nothing): one launch per range
+            for (kind, strength), lo, hi in self._regularizer_ranges():
+                ops.regularize(kind, self._pack.view_of(self._pack.value, lo, hi - lo, (hi - lo,)),
+                               self._pack.view_of(self._pack.grad, lo, hi - lo, (hi - lo,)), strength, slot, True)
+        else:
+            for layer in layers:
+                layer.regularize(slot)
         return DeviceScalar(slot.t) if CP.lazy_losses else float(slot.t.item())
+
+    def _regularizer_ranges(self):
+        if self._reg_ranges is None:
+            owner = {id(p): layer for layer in self.layers.values() for p in layer.params().values()}
+            ranges = []
+            entries = self._pack.entries
+            for idx, (p, off, size) in enumerate(entries):
+                end = entries[idx + 1][1] if idx + 1 < len(entries) else self._pack.total
+                reg = owner[id(p)].regularizer
+                if reg is None:
+                    continue
+                key = (reg.kind, reg.reg_strength)
+                if ranges and ranges[-1][0] == key and ranges[-1][2] == off:
+                    ranges[-1][2] = end
+                else:
+                    ranges.append([key, off, end])
+            self._reg_ranges = ranges
+        return self._reg_ranges
 
     def get_weights(self):
         weights = {name: layer.get_weights() for name, layer in self.layers.items()}

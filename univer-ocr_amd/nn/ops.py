@@ -140,6 +140,13 @@ def act_bwd(kind, x, dy, alpha=0.0):
     return dx
 
 
+def act_bwd_from_output(kind, y, dy, alpha=0.0):
+    code = _same_dtype(y, dy)
+    dx = CP.empty(dy.shape, dy.dtype)
+    _rt().call('uocr_act_bwd_from_output', code, ACT_CODES[kind], float(alpha), y.ptr, dy.ptr, dx.ptr, y.size)
+    return dx
+
+
 # ---- FullyConnected ---------------------------------------------------------------------------------
 def dense_fwd(x, w):
     m, n_in = x.shape
