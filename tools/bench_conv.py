@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark of Convolutional2D at the my_model workload shapes (batch 32,
+256x512 pages): HIP-event time, algorithmic bytes and achieved GB/s (HBM roofline 8 TB/s spec,
+~6.3 TB/s measured copy) or TFLOP/s (f32 MFMA roofline 157 TF) for forward, dx and dw/db.
+
+    python tools/bench_conv.py [--reps 20] [--batch 32] [--option mfma=1] [--filter mono]
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+
+LAYERS = [
+    # name, H, W, cin, cout, kernel, stride, padding
+    ('mono.conv_1', 256, 512, 1, 16, (3, 3), (1, 1), (1, 1)),
+    ('mono.conv_2', 256, 512, 16, 1, (3, 3), (1, 1), (1, 1)),
+    ('para.down_1', 256, 512, 1, 1, (5, 5), (2, 2), (2, 2)),
+    ('para.down_2', 128, 256, 1, 1, (5, 5), (2, 2), (2, 2)),
+    ('para.up_2', 128, 256, 1, 1, (5, 5), (1, 1), (2, 2)),
+    ('para.up_1/end', 256, 512, 1, 1, (5, 5), (1, 1), (2, 2)),
+    ('line.down_1', 256, 512, 1, 4, (5, 5), (2, 2), (2, 2)),
+    ('line.down_2', 128, 256, 4, 4, (5, 5), (2, 2), (2, 2)),
+    ('line.up_2', 128, 256, 4, 4, (5, 5), (1, 1), (2, 2)),
+    ('line.up_1', 256, 512, 4, 4, (5, 5), (1, 1), (2, 2)),
+    ('line.end', 256, 512, 4, 2, (5, 5), (1, 1), (2, 2)),
+    ('char.conv_1', 32, 64, 1, 64, (5, 3), (2, 1), (0, 1)),
+    ('char.conv_2', 14, 64, 64, 64, (5, 3), (2, 1), (0, 1)),
+    ('char.conv_3', 5, 64, 64, 64, (5, 3), (2, 1), (0, 1)),
+    ('wide 3x3 64->64', 256, 512, 64, 64, (3, 3), (1, 1), (1, 1)),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--filter', default='')
+    ap.add_argument('--option', action='append', default=[])
+    args = ap.parse_args()
+    from univer_ocr_amd.nn import CP, ops
+    CP.use_gpu(0)
+    rt = CP.runtime()
+    for opt in args.option:
+        k, v = opt.split('=')
+        rt.set_option(k, int(v))
+    ev = [ctypes.c_void_p() for _ in range(2)]
+    for e in ev:
+        assert rt.lib.uocr_event_create(ctypes.byref(e)) == 0
+
+    def timed(fn):
+        fn()
+        rt.synchronize()
+        rt.call('uocr_event_record', ev[0])
+        for _ in range(args.reps):
+            fn()
+        rt.call('uocr_event_record', ev[1])
+        ms = ctypes.c_float()
+        assert rt.lib.uocr_event_elapsed_ms_sync(ev[0], ev[1], ctypes.byref(ms)) == 0
+        return ms.value * 1e3 / args.reps
+
+    rng = np.random.default_rng(0)
+    print(f'{"layer":18s} {"op":6s} {"us":>9s} {"MB":>8s} {"GB/s":>8s} {"GFLOP":>8s} {"TF/s":>7s}')
+    for name, h, w, cin, cout, ks, st, pd in LAYERS:
+        if args.filter not in name:
+            continue
+        n = args.batch
+        x = CP.copy(rng.standard_normal((n, h, w, cin)).astype(np.float32))
+        wt = CP.copy((rng.standard_normal((*ks, cin, cout)) * 0.1).astype(np.float32))
+        b = CP.copy(rng.standard_normal(cout).astype(np.float32))
+        y = ops.conv2d_fwd(x, wt, b, st, pd)
+        oh, ow = y.shape[1], y.shape[2]
+        g = CP.copy(rng.standard_normal(y.shape).astype(np.float32))
+        dw, db = CP.zeros(wt.shape), CP.zeros(b.shape)
+        in_b, out_b, w_b = 4 * n * h * w * cin, 4 * n * oh * ow * cout, 4 * wt.size
+        flop = 2.0 * n * oh * ow * cout * ks[0] * ks[1] * cin
+        runs = [('fwd', lambda: ops.conv2d_fwd(x, wt, b, st, pd), in_b + out_b + w_b),
+                ('dgrad', lambda: ops.conv2d_bwd_data(g, wt, x.shape, st, pd), in_b + out_b + w_b),
+                ('wgrad', lambda: ops.conv2d_bwd_weight(x, g, dw, db, st, pd), in_b + out_b + w_b)]
+        for op, fn, nbytes in runs:
+            us = timed(fn)
+            print(f'{name:18s} {op:6s} {us:9.1f} {nbytes / 1e6:8.1f} {nbytes / us / 1e3:8.0f} {flop / 1e9:8.2f} '
+                  f'{flop / us / 1e6:7.2f}')
+        del x, y, g
+
+
+if __name__ == '__main__':
+    main()

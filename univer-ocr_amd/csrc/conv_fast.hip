@@ -79,91 +79,445 @@ struct FastDims {
 };
 
 // ---------------------------------------------------------------------------------------------
-// forward: block (64, 4); a thread computes COB output channels of one pixel and NQ = COUT / COB
-// adjacent lanes share a pixel, so one wave stores 64 * COB contiguous floats per instruction
-// (with one lane per pixel and COUT = 16 every store instruction would touch 64 B per lane at a
-// 64 B stride: 4 partial-line store instructions per wave instead of 4 full ones)
+// forward: block (64, 4); a thread computes COB output channels of PY vertically adjacent pixels
+// (register tiling: the (PY-1)*SH + KH input rows are loaded once and feed all PY outputs, which
+// cuts the L1 re-read traffic of a KHxKW window from KH*KW to ((PY-1)*SH+KH)*KW/PY loads per pixel;
+// these kernels were L1-bandwidth bound, not HBM bound, with one pixel per thread).
+// NQ = COUT / COB adjacent lanes share a pixel, so one wave stores 64 * COB contiguous floats.
 // ---------------------------------------------------------------------------------------------
-template <int KH, int KW, int CIN, int COUT, int SH, int SW, int COB>
+template <int KH, int KW, int CIN, int COUT, int SH, int SW, int COB, int PY>
 __global__ __launch_bounds__(256) void conv_fwd_fast(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ y,
                                                      FastDims d, float pad, int use_bias, int act, float alpha) {
     constexpr int NQ = COUT / COB;     // lanes per pixel
     constexpr int PXW = 64 / NQ;       // pixels per wave row
+    constexpr int ROWS = (PY - 1) * SH + KH;
     const int ox = blockIdx.x * PXW + threadIdx.x / NQ;
-    const int oy = blockIdx.y * 4 + threadIdx.y;
+    const int oy0 = (blockIdx.y * 4 + threadIdx.y) * PY;
     const int oc0 = (threadIdx.x % NQ) * COB;
     const int b = blockIdx.z;
-    if (ox >= d.ow || oy >= d.oh) return;
-    float acc[COB];
+    const float* __restrict__ wl = w;   // scalar-cache operands (fine for the shapes left on this kernel)
+    const bool valid = ox < d.ow && oy0 < d.oh;
+    if (!valid) return;
+    float acc[PY][COB];
 #pragma unroll
-    for (int o = 0; o < COB; ++o) acc[o] = 0.f;
-    const int iy0 = oy * SH - d.ph, ix0 = ox * SW - d.pw;
+    for (int p = 0; p < PY; ++p)
+#pragma unroll
+        for (int o = 0; o < COB; ++o) acc[p][o] = 0.f;
+    const int iy0 = oy0 * SH - d.ph, ix0 = ox * SW - d.pw;
     const float* xb = x + (size_t)b * d.h * d.w * CIN;
 #pragma unroll
-    for (int ky = 0; ky < KH; ++ky) {
-        const int iy = iy0 + ky;
+    for (int r = 0; r < ROWS; ++r) {
+        const int iy = iy0 + r;
         const bool row_ok = iy >= 0 && iy < d.h;
+        const int iyc = min(max(iy, 0), d.h - 1);
 #pragma unroll
         for (int kx = 0; kx < KW; ++kx) {
             const int ix = ix0 + kx;
+            // unconditional load from a clamped address + select: a per-tap branch would put every
+            // load in its own divergent region (s_waitcnt vmcnt(0) per tap, no loads in flight)
             float xv[CIN];
-            if (row_ok && ix >= 0 && ix < d.w) {
-                load_vec<CIN>(xb + ((size_t)iy * d.w + ix) * CIN, xv);
-            } else {
+            load_vec<CIN>(xb + ((size_t)iyc * d.w + min(max(ix, 0), d.w - 1)) * CIN, xv);
+            if (!(row_ok && ix >= 0 && ix < d.w)) {
 #pragma unroll
                 for (int c = 0; c < CIN; ++c) xv[c] = pad;
             }
 #pragma unroll
-            for (int c = 0; c < CIN; ++c)
+            for (int p = 0; p < PY; ++p) {
+                const int ky = r - p * SH;          // compile-time after unrolling
+                if (ky >= 0 && ky < KH) {
 #pragma unroll
-                for (int o = 0; o < COB; ++o) acc[o] += xv[c] * w[((ky * KW + kx) * CIN + c) * COUT + oc0 + o];
-        }
-    }
-    float out[COB];
+                    for (int c = 0; c < CIN; ++c)
 #pragma unroll
-    for (int o = 0; o < COB; ++o) {
-        float v = acc[o];
-        if (use_bias) v += bias[oc0 + o];
-        out[o] = act_apply(v, act, alpha);
-    }
-    store_vec<COB>(y + (((size_t)b * d.oh + oy) * d.ow + ox) * COUT + oc0, out);
-}
-
-// ---------------------------------------------------------------------------------------------
-// backward data: block (64, 4) = 64 x 4 INPUT pixels; all CIN channels per thread
-// ---------------------------------------------------------------------------------------------
-template <int KH, int KW, int CIN, int COUT, int SH, int SW>
-__global__ __launch_bounds__(256) void conv_dgrad_fast(const float* __restrict__ dy, const float* __restrict__ w,
-                                                       float* __restrict__ dx, FastDims d) {
-    const int ix = blockIdx.x * 64 + threadIdx.x;
-    const int iy = blockIdx.y * 4 + threadIdx.y;
-    const int b = blockIdx.z;
-    if (ix >= d.w || iy >= d.h) return;
-    float acc[CIN];
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
-    const float* gb = dy + (size_t)b * d.oh * d.ow * COUT;
-#pragma unroll
-    for (int ky = KH - 1; ky >= 0; --ky) {
-        const int ty = iy + d.ph - ky;
-        const int gy = SH == 1 ? ty : ty / SH;
-        const bool row_ok = ty >= 0 && gy < d.oh && (SH == 1 || gy * SH == ty);
-#pragma unroll
-        for (int kx = KW - 1; kx >= 0; --kx) {
-            const int tx = ix + d.pw - kx;
-            const int gx = SW == 1 ? tx : tx / SW;
-            if (row_ok && tx >= 0 && gx < d.ow && (SW == 1 || gx * SW == tx)) {
-                float g[COUT];
-                load_vec<COUT>(gb + ((size_t)gy * d.ow + gx) * COUT, g);
-#pragma unroll
-                for (int c = 0; c < CIN; ++c)
-#pragma unroll
-                    for (int o = 0; o < COUT; ++o) acc[c] += g[o] * w[((ky * KW + kx) * CIN + c) * COUT + o];
+                        for (int o = 0; o < COB; ++o)
+                            acc[p][o] += xv[c] * wl[((ky * KW + kx) * CIN + c) * COUT + oc0 + o];
+                }
             }
         }
     }
-    store_vec<CIN>(dx + (((size_t)b * d.h + iy) * d.w + ix) * CIN, acc);
+#pragma unroll
+    for (int p = 0; p < PY; ++p) {
+        if (!valid || oy0 + p >= d.oh) break;
+        float out[COB];
+#pragma unroll
+        for (int o = 0; o < COB; ++o) {
+            float v = acc[p][o];
+            if (use_bias) v += bias[oc0 + o];
+            out[o] = act_apply(v, act, alpha);
+        }
+        store_vec<COB>(y + (((size_t)b * d.oh + oy0 + p) * d.ow + ox) * COUT + oc0, out);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward data: block (64, 4); a thread computes all CIN channels of PY vertically adjacent INPUT
+// pixels.  Stride 1: the PY + KH - 1 rows of dy that the PY pixels see are loaded once.
+// Stride > 1: PY must be 1 (taps are predicated on the stride phase of each lane).
+// ---------------------------------------------------------------------------------------------
+template <int KH, int KW, int CIN, int COUT, int SH, int SW, int PY>
+__global__ __launch_bounds__(256) void conv_dgrad_fast(const float* __restrict__ dy, const float* __restrict__ w,
+                                                       float* __restrict__ dx, FastDims d) {
+    static_assert(PY == 1 || (SH == 1 && SW == 1), "row tiling of dgrad needs stride 1");
+    const int ix = blockIdx.x * 64 + threadIdx.x;
+    const int iy0 = (blockIdx.y * 4 + threadIdx.y) * PY;
+    const int b = blockIdx.z;
+    const float* __restrict__ wl = w;
+    const bool valid = ix < d.w && iy0 < d.h;
+    if (!valid) return;
+    float acc[PY][CIN];
+#pragma unroll
+    for (int p = 0; p < PY; ++p)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) acc[p][c] = 0.f;
+    const float* gb = dy + (size_t)b * d.oh * d.ow * COUT;
+    if constexpr (SH == 1 && SW == 1) {
+        constexpr int ROWS = PY + KH - 1;
+        const int gy0 = iy0 + d.ph - (KH - 1);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int gy = gy0 + r;
+            const bool row_ok = gy >= 0 && gy < d.oh;
+            const int gyc = min(max(gy, 0), d.oh - 1);
+#pragma unroll
+            for (int kx = KW - 1; kx >= 0; --kx) {
+                const int gx = ix + d.pw - kx;
+                float g[COUT];   // clamped unconditional load + select (see conv_fwd_fast)
+                load_vec<COUT>(gb + ((size_t)gyc * d.ow + min(max(gx, 0), d.ow - 1)) * COUT, g);
+                if (!(row_ok && gx >= 0 && gx < d.ow)) {
+#pragma unroll
+                    for (int o = 0; o < COUT; ++o) g[o] = 0.f;
+                }
+#pragma unroll
+                for (int p = 0; p < PY; ++p) {
+                    const int ky = p + (KH - 1) - r;   // compile-time after unrolling
+                    if (ky >= 0 && ky < KH) {
+#pragma unroll
+                        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                            for (int o = 0; o < COUT; ++o)
+                                acc[p][c] += g[o] * wl[((ky * KW + kx) * CIN + c) * COUT + o];
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int ky = KH - 1; ky >= 0; --ky) {
+            const int ty = iy0 + d.ph - ky;
+            const int gy = ty / SH;
+            const bool row_ok = ty >= 0 && gy < d.oh && gy * SH == ty;
+#pragma unroll
+            for (int kx = KW - 1; kx >= 0; --kx) {
+                const int tx = ix + d.pw - kx;
+                const int gx = tx / SW;
+                // strided: most taps miss the stride phase of a lane, so a branch (no load at all)
+                // beats the clamped unconditional load here (Char conv_1 dx: 16 us vs 94 us)
+                if (row_ok && tx >= 0 && gx < d.ow && gx * SW == tx) {
+                    float g[COUT];
+                    load_vec<COUT>(gb + ((size_t)gy * d.ow + gx) * COUT, g);
+#pragma unroll
+                    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                        for (int o = 0; o < COUT; ++o) acc[0][c] += g[o] * wl[((ky * KW + kx) * CIN + c) * COUT + o];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PY; ++p) {
+        if (!valid || iy0 + p >= d.h) break;
+        store_vec<CIN>(dx + (((size_t)b * d.h + iy0 + p) * d.w + ix) * CIN, acc[p]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-loop kernels for the few-channel (COUT <= 4 / CIN <= 16) convs.  Structure chosen from the ISA:
+//   * the tap-ROW loop (ky) is a real loop (not unrolled), so only one row of weights
+//     (KW*CIN*COUT <= 80 values) is live: they stay in SGPRs (s_load from the uniform pointer
+//     w + ky*row) and feed v_fmac directly -- fully unrolled, the 400 weights of a 5x5x4x4 kernel
+//     overflow the ~100 SGPRs and every FMA pays 3.4 v_readlane; through LDS/VGPRs they cost an
+//     LDS read per 4 FMAs and 256 VGPRs (occupancy 1);
+//   * a thread owns PX horizontally adjacent pixels: the (PX-1)*SW + KW input vectors of a row are
+//     loaded once and reused by all PX*KW taps, so L1 traffic per pixel drops from KW to
+//     ((PX-1)*SW + KW)/PX loads per row, and every weight is reused PX times from its SGPR.
+// ---------------------------------------------------------------------------------------------
+template <int KH, int KW, int CIN, int COUT, int SH, int SW, int PX>
+__global__ __launch_bounds__(256) void conv_fwd_px(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ y,
+                                                   FastDims d, float pad, int use_bias, int act, float alpha) {
+    constexpr int NXV = (PX - 1) * SW + KW;
+    const int ox0 = (blockIdx.x * 64 + threadIdx.x) * PX;
+    const int oy = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z;
+    if (ox0 >= d.ow || oy >= d.oh) return;
+    float acc[PX][COUT];
+#pragma unroll
+    for (int p = 0; p < PX; ++p)
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) acc[p][o] = 0.f;
+    const int ix0 = ox0 * SW - d.pw;
+    const float* xb = x + (size_t)b * d.h * d.w * CIN;
+#pragma unroll 1
+    for (int ky = 0; ky < KH; ++ky) {
+        const int iy = oy * SH - d.ph + ky;
+        const bool row_ok = iy >= 0 && iy < d.h;
+        const float* xr = xb + (size_t)min(max(iy, 0), d.h - 1) * d.w * CIN;
+        const float* wr = w + ky * (KW * CIN * COUT);
+        float xv[NXV][CIN];
+#pragma unroll
+        for (int j = 0; j < NXV; ++j) {
+            const int ix = ix0 + j;
+            load_vec<CIN>(xr + (size_t)min(max(ix, 0), d.w - 1) * CIN, xv[j]);
+            if (!(row_ok && ix >= 0 && ix < d.w)) {
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) xv[j][c] = pad;
+            }
+        }
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) {
+                    const float wv = wr[(kx * CIN + c) * COUT + o];
+#pragma unroll
+                    for (int p = 0; p < PX; ++p) acc[p][o] += xv[p * SW + kx][c] * wv;
+                }
+    }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        if (ox0 + p >= d.ow) break;
+        float out[COUT];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            float v = acc[p][o];
+            if (use_bias) v += bias[o];
+            out[o] = act_apply(v, act, alpha);
+        }
+        store_vec<COUT>(y + (((size_t)b * d.oh + oy) * d.ow + ox0 + p) * COUT, out);
+    }
+}
+
+// stride-1 backward data with the same structure: dx[y, x0+p, c] = sum_{ky,kx,o} dy[y+ph-ky, x0+p+pw-kx, o] w[ky,kx,c,o]
+template <int KH, int KW, int CIN, int COUT, int PX>
+__global__ __launch_bounds__(256) void conv_dgrad_px(const float* __restrict__ dy, const float* __restrict__ w,
+                                                     float* __restrict__ dx, FastDims d) {
+    constexpr int NG = PX + KW - 1;
+    const int ix0 = (blockIdx.x * 64 + threadIdx.x) * PX;
+    const int iy = blockIdx.y * 4 + threadIdx.y;
+    const int b = blockIdx.z;
+    if (ix0 >= d.w || iy >= d.h) return;
+    float acc[PX][CIN];
+#pragma unroll
+    for (int p = 0; p < PX; ++p)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) acc[p][c] = 0.f;
+    const float* gb = dy + (size_t)b * d.oh * d.ow * COUT;
+    const int gx0 = ix0 + d.pw - (KW - 1);
+#pragma unroll 1
+    for (int ky = KH - 1; ky >= 0; --ky) {
+        const int gy = iy + d.ph - ky;
+        const bool row_ok = gy >= 0 && gy < d.oh;
+        const float* gr = gb + (size_t)min(max(gy, 0), d.oh - 1) * d.ow * COUT;
+        const float* wr = w + ky * (KW * CIN * COUT);
+        float g[NG][COUT];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int gx = gx0 + j;
+            load_vec<COUT>(gr + (size_t)min(max(gx, 0), d.ow - 1) * COUT, g[j]);
+            if (!(row_ok && gx >= 0 && gx < d.ow)) {
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) g[j][o] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) {
+                    const float wv = wr[(kx * CIN + c) * COUT + o];
+#pragma unroll
+                    for (int p = 0; p < PX; ++p) acc[p][c] += g[p + (KW - 1) - kx][o] * wv;
+                }
+    }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        if (ix0 + p >= d.w) break;
+        store_vec<CIN>(dx + (((size_t)b * d.h + iy) * d.w + ix0 + p) * CIN, acc[p]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 16-channel <-> 1-channel 3x3 convs of the Monochrome net (conv_2 forward / dw, conv_1 dx): the
+// 16-channel tensor (268 MB at 32x256x512) is read through a KHxKW window.  Four adjacent lanes
+// share a pixel, each owns one channel quad: every load instruction of a wave is 64 x 16 B fully
+// contiguous (one lane per pixel reads 16 B at a 64 B stride -> 4x the cache-line accesses), the
+// lane keeps its KH*KW*4 weights in VGPRs for the whole thread (no weight traffic at all), PY
+// vertically adjacent outputs share the loaded rows, and the 4 partial sums of a pixel are
+// combined with two DPP-class shuffles.
+//   FLIP = false: y[p]  = sum_{ky,kx,c} x[p + (ky,kx) - pad, c] * w[ky,kx,c]        (forward, COUT = 1)
+//   FLIP = true : dx[p] = sum_{ky,kx,o} dy[p - (ky,kx) + pad, o] * w[ky,kx,o]       (dx, CIN = 1)
+// (both weight tensors are the flat array w[(ky*KW + kx)*16 + ch])
+// ---------------------------------------------------------------------------------------------
+template <int KH, int KW, int PY, bool FLIP>
+__global__ __launch_bounds__(256) void conv_c16_reduce(const float* __restrict__ src, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ dst,
+                                                       int n, int h, int wd, int ph, int pw, float pad, int use_bias,
+                                                       int act, float alpha) {
+    constexpr int C = 16, ROWS = PY + KH - 1;
+    const int q = threadIdx.x & 3;
+    const int ox = blockIdx.x * 16 + (threadIdx.x >> 2);
+    const int oy0 = (blockIdx.y * 4 + threadIdx.y) * PY;
+    const int b = blockIdx.z;
+    float wreg[KH][KW][4];
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const int sky = FLIP ? KH - 1 - ky : ky, skx = FLIP ? KW - 1 - kx : kx;
+            const float4 t = *reinterpret_cast<const float4*>(w + (sky * KW + skx) * C + q * 4);
+            wreg[ky][kx][0] = t.x;
+            wreg[ky][kx][1] = t.y;
+            wreg[ky][kx][2] = t.z;
+            wreg[ky][kx][3] = t.w;
+        }
+    // same-size stride-1 window: source row = oy - PH + r, PH = pad (forward) or KH-1-pad (flipped)
+    const int PH = FLIP ? KH - 1 - ph : ph, PW = FLIP ? KW - 1 - pw : pw;
+    float acc[PY];
+#pragma unroll
+    for (int p = 0; p < PY; ++p) acc[p] = 0.f;
+    const float* sb = src + (size_t)b * h * wd * C + q * 4;
+    const int oxc = min(ox, wd - 1);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int iy = oy0 - PH + r;
+        const bool row_ok = iy >= 0 && iy < h;
+        const float* sr = sb + (size_t)min(max(iy, 0), h - 1) * wd * C;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const int ix = oxc - PW + kx;
+            float4 v = *reinterpret_cast<const float4*>(sr + (size_t)min(max(ix, 0), wd - 1) * C);
+            if (!(row_ok && ix >= 0 && ix < wd)) v = make_float4(pad, pad, pad, pad);
+#pragma unroll
+            for (int p = 0; p < PY; ++p) {
+                const int ky = r - p;      // compile-time after unrolling
+                if (ky >= 0 && ky < KH)
+                    acc[p] += v.x * wreg[ky][kx][0] + v.y * wreg[ky][kx][1] + v.z * wreg[ky][kx][2] +
+                              v.w * wreg[ky][kx][3];
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PY; ++p) {
+        float v = acc[p];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        if (q == 0 && ox < wd && oy0 + p < h) {
+            if (use_bias) v += bias[0];
+            dst[((size_t)b * h + oy0 + p) * wd + ox] = act_apply(v, act, alpha);
+        }
+    }
+}
+
+// dw[ky,kx,c] (+ db) of the 16 -> 1 conv, x-stationary: dw[ky,kx,c] = sum_q x[q,c] * dy[q - (ky,kx) + pad].
+// A lane (input pixel q, channel quad) loads its 16 B of x exactly ONCE (64 lanes = 1 KiB contiguous)
+// and the 1-channel dy at the KH*KW shifted positions (4 B each, L1 hits), so the 268 MB tensor
+// crosses L1 once instead of KH*KW times.  Needs padding_value == 0 (the padded border then
+// contributes nothing) and a same-size output.  36 + 1 accumulators per lane; all-reduce over the
+// 16 pixels of a wave by xor-shuffles 4..32, LDS over the 4 waves, partial[blk][quad][KH*KW*4 + 1].
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void conv_c16_wgrad(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      float* __restrict__ partial, int h, int wd, int ph, int pw,
+                                                      int rows_per_block, int nbands) {
+    constexpr int C = 16, NA = KH * KW * 4 + 1;
+    __shared__ float red[4][4][NA];
+    const int q = threadIdx.x & 3, pl = threadIdx.x >> 2, wv = threadIdx.y;
+    const int band = blockIdx.x % nbands, b = blockIdx.x / nbands;
+    const int row0 = band * rows_per_block, row1 = min(h, row0 + rows_per_block);
+    float acc[KH][KW][4], accb = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[ky][kx][j] = 0.f;
+    const float* xb = x + (size_t)b * h * wd * C + q * 4;
+    const float* gb = dy + (size_t)b * h * wd;
+    for (int iy = row0 + wv; iy < row1; iy += 4) {
+        for (int ix = pl; ix < wd; ix += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(xb + ((size_t)iy * wd + ix) * C);
+            accb += gb[(size_t)iy * wd + ix];
+#pragma unroll
+            for (int ky = 0; ky < KH; ++ky) {
+                const int oy = iy + ph - ky;
+                const bool row_ok = oy >= 0 && oy < h;
+                const float* gr = gb + (size_t)min(max(oy, 0), h - 1) * wd;
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx) {
+                    const int ox = ix + pw - kx;
+                    float g = gr[min(max(ox, 0), wd - 1)];
+                    if (!(row_ok && ox >= 0 && ox < wd)) g = 0.f;
+                    acc[ky][kx][0] += v.x * g;
+                    acc[ky][kx][1] += v.y * g;
+                    acc[ky][kx][2] += v.z * g;
+                    acc[ky][kx][3] += v.w * g;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = acc[ky][kx][j];
+#pragma unroll
+                for (int m = 4; m < 64; m <<= 1) t += __shfl_xor(t, m, 64);
+                acc[ky][kx][j] = t;
+            }
+#pragma unroll
+    for (int m = 4; m < 64; m <<= 1) accb += __shfl_xor(accb, m, 64);
+    if (pl == 0) {
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) red[wv][q][(ky * KW + kx) * 4 + j] = acc[ky][kx][j];
+        red[wv][q][NA - 1] = accb;
+    }
+    __syncthreads();
+    const int tid = wv * 64 + threadIdx.x;
+    float* out = partial + (size_t)blockIdx.x * 4 * NA;
+    for (int a = tid; a < 4 * NA; a += 256) {
+        const int qq = a / NA, i = a % NA;
+        out[a] = red[0][qq][i] + red[1][qq][i] + red[2][qq][i] + red[3][qq][i];
+    }
+}
+
+// block per (accumulator, quad): float64 sum of the block partials into dw[tap*16 + q*4 + j] / db
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void conv_c16_wgrad_finish(const float* __restrict__ partial, float* __restrict__ dw,
+                                                             float* __restrict__ db, int nblocks, int use_bias,
+                                                             int accumulate) {
+    constexpr int NA = KH * KW * 4 + 1;
+    __shared__ double smem[16];
+    const int i = blockIdx.x, q = blockIdx.y;
+    double s = 0.0;
+    for (int blk = threadIdx.x; blk < nblocks; blk += blockDim.x) s += (double)partial[((size_t)blk * 4 + q) * NA + i];
+    s = block_reduce_sum(s, smem);
+    if (threadIdx.x != 0) return;
+    float* dst;
+    if (i < NA - 1) {
+        dst = dw + (i / 4) * 16 + q * 4 + (i % 4);
+    } else {
+        if (q != 0) return;      // every quad lane summed dy: keep quad 0's copy
+        dst = db;
+        if (!use_bias) s = 0.0;
+    }
+    *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -207,11 +561,12 @@ struct WgradCfg {
     static constexpr int OCG = COUT / COB;              // output-channel groups
 };
 
-template <int KH, int KW, int CIN, int COUT, int SH, int SW, int KYR, int COB>
+template <int KH, int KW, int CIN, int COUT, int SH, int SW, int KYR, int COB, int PY, bool CLAMP>
 __global__ __launch_bounds__(256) void conv_wgrad_fast(const float* __restrict__ x, const float* __restrict__ dy,
                                                        float* __restrict__ partial, FastDims d, float pad,
                                                        int rows_per_block, int nbands) {
     using C = WgradCfg<KH, KW, CIN, COUT, SH, SW, KYR, COB>;
+    constexpr int ROWS = (PY - 1) * SH + KYR;      // input rows feeding PY vertically adjacent outputs
     __shared__ float red[4][C::NP];
     const int lane = threadIdx.x, wv = threadIdx.y;
     const int band = blockIdx.x % nbands, b = blockIdx.x / nbands;
@@ -224,33 +579,59 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast(const float* __restrict__
     for (int a = 0; a < C::NP; ++a) acc[a] = 0.f;
     const float* xb = x + (size_t)b * d.h * d.w * CIN;
     const float* gb = dy + (size_t)b * d.oh * d.ow * COUT + oc0;
-    for (int oy = row0 + wv; oy < row1; oy += 4) {
+    for (int oy = row0 + wv * PY; oy < row1; oy += 4 * PY) {
         for (int ox = lane; ox < d.ow; ox += 64) {
-            float g[COB];
-            load_vec<COB>(gb + ((size_t)oy * d.ow + ox) * COUT, g);
-            if (kyg == 0) {
+            float g[PY][COB];
 #pragma unroll
-                for (int o = 0; o < COB; ++o) acc[C::NW + o] += g[o];
+            for (int p = 0; p < PY; ++p) {
+                if (oy + p < row1) {
+                    load_vec<COB>(gb + ((size_t)(oy + p) * d.ow + ox) * COUT, g[p]);
+                } else {
+#pragma unroll
+                    for (int o = 0; o < COB; ++o) g[p][o] = 0.f;
+                }
+                if (kyg == 0) {
+#pragma unroll
+                    for (int o = 0; o < COB; ++o) acc[C::NW + o] += g[p][o];
+                }
             }
             const int iy0 = oy * SH - d.ph + ky0, ix0 = ox * SW - d.pw;
 #pragma unroll
-            for (int kyl = 0; kyl < KYR; ++kyl) {
-                const int iy = iy0 + kyl;
+            for (int r = 0; r < ROWS; ++r) {
+                const int iy = iy0 + r;
                 const bool row_ok = iy >= 0 && iy < d.h;
+                const int iyc = min(max(iy, 0), d.h - 1);
 #pragma unroll
                 for (int kx = 0; kx < KW; ++kx) {
                     const int ix = ix0 + kx;
+                    // measured per shape: the clamped unconditional load is 1.3-2x faster for the
+                    // CIN = 4 kernels and 3.5x SLOWER for the CIN = 1 5x5 kernel than the branch
                     float xv[CIN];
-                    if (row_ok && ix >= 0 && ix < d.w) {
-                        load_vec<CIN>(xb + ((size_t)iy * d.w + ix) * CIN, xv);
-                    } else {
+                    if constexpr (CLAMP) {
+                        load_vec<CIN>(xb + ((size_t)iyc * d.w + min(max(ix, 0), d.w - 1)) * CIN, xv);
+                        if (!(row_ok && ix >= 0 && ix < d.w)) {
 #pragma unroll
-                        for (int c = 0; c < CIN; ++c) xv[c] = pad;
+                            for (int c = 0; c < CIN; ++c) xv[c] = pad;
+                        }
+                    } else {
+                        if (row_ok && ix >= 0 && ix < d.w) {
+                            load_vec<CIN>(xb + ((size_t)iy * d.w + ix) * CIN, xv);
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < CIN; ++c) xv[c] = pad;
+                        }
                     }
 #pragma unroll
-                    for (int c = 0; c < CIN; ++c)
+                    for (int p = 0; p < PY; ++p) {
+                        const int kyl = r - p * SH;      // compile-time after unrolling
+                        if (kyl >= 0 && kyl < KYR) {
 #pragma unroll
-                        for (int o = 0; o < COB; ++o) acc[((kyl * KW + kx) * CIN + c) * COB + o] += xv[c] * g[o];
+                            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                                for (int o = 0; o < COB; ++o)
+                                    acc[((kyl * KW + kx) * CIN + c) * COB + o] += xv[c] * g[p][o];
+                        }
+                    }
                 }
             }
         }
@@ -298,7 +679,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_finish(const float* __res
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-template <int KH, int KW, int CIN, int COUT, int SH, int SW, int COB, int KYR, int WCOB>
+template <int KH, int KW, int CIN, int COUT, int SH, int SW, int COB, int PY, int DPY, int KYR, int WCOB, int WPY, int FPX,
+          int DPX>
 struct FastConv {
     static bool match(const ConvDims& d) {
         return d.kh == KH && d.kw == KW && d.cin == CIN && d.cout == COUT && d.sh == SH && d.sw == SW;
@@ -307,19 +689,35 @@ struct FastConv {
 
     static int fwd(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
                    double pad, int use_bias, int act, double alpha) {
-        constexpr int PXW = 64 / (COUT / COB);
-        const dim3 grid((d.ow + PXW - 1) / PXW, (d.oh + 3) / 4, d.n), block(64, 4);
-        hipLaunchKernelGGL((conv_fwd_fast<KH, KW, CIN, COUT, SH, SW, COB>), grid, block, 0, ctx->stream,
-                           (const float*)x, (const float*)w, (const float*)b, (float*)y, dims(d), (float)pad, use_bias,
-                           act, (float)alpha);
+        if constexpr (FPX > 0) {
+            const int groups = (d.ow + FPX - 1) / FPX;
+            const dim3 grid((groups + 63) / 64, (d.oh + 3) / 4, d.n), block(64, 4);
+            hipLaunchKernelGGL((conv_fwd_px<KH, KW, CIN, COUT, SH, SW, FPX>), grid, block, 0, ctx->stream,
+                               (const float*)x, (const float*)w, (const float*)b, (float*)y, dims(d), (float)pad,
+                               use_bias, act, (float)alpha);
+        } else {
+            constexpr int PXW = 64 / (COUT / COB);
+            const dim3 grid((d.ow + PXW - 1) / PXW, (d.oh + 4 * PY - 1) / (4 * PY), d.n), block(64, 4);
+            hipLaunchKernelGGL((conv_fwd_fast<KH, KW, CIN, COUT, SH, SW, COB, PY>), grid, block, 0, ctx->stream,
+                               (const float*)x, (const float*)w, (const float*)b, (float*)y, dims(d), (float)pad,
+                               use_bias, act, (float)alpha);
+        }
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
 
     static int dgrad(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d) {
-        const dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, d.n), block(64, 4);
-        hipLaunchKernelGGL((conv_dgrad_fast<KH, KW, CIN, COUT, SH, SW>), grid, block, 0, ctx->stream,
-                           (const float*)dy, (const float*)w, (float*)dx, dims(d));
+        if constexpr (DPX > 0) {
+            static_assert(DPX == 0 || (SH == 1 && SW == 1), "conv_dgrad_px is stride 1 only");
+            const int groups = (d.w + DPX - 1) / DPX;
+            const dim3 grid((groups + 63) / 64, (d.h + 3) / 4, d.n), block(64, 4);
+            hipLaunchKernelGGL((conv_dgrad_px<KH, KW, CIN, COUT, DPX>), grid, block, 0, ctx->stream,
+                               (const float*)dy, (const float*)w, (float*)dx, dims(d));
+        } else {
+            const dim3 grid((d.w + 63) / 64, (d.h + 4 * DPY - 1) / (4 * DPY), d.n), block(64, 4);
+            hipLaunchKernelGGL((conv_dgrad_fast<KH, KW, CIN, COUT, SH, SW, DPY>), grid, block, 0, ctx->stream,
+                               (const float*)dy, (const float*)w, (float*)dx, dims(d));
+        }
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
@@ -328,16 +726,17 @@ struct FastConv {
                      double pad, int use_bias, int accumulate) {
         using C = WgradCfg<KH, KW, CIN, COUT, SH, SW, KYR, WCOB>;
         // bands of output rows: ~512 blocks per (tap group, channel group), at least 4 rows each
+        constexpr int RQ = 4 * WPY;       // rows consumed per block iteration
         int rows = (d.n * d.oh + 511) / 512;
-        rows = ((rows + 3) / 4) * 4;
-        if (rows > d.oh) rows = ((d.oh + 3) / 4) * 4;
+        rows = ((rows + RQ - 1) / RQ) * RQ;
+        if (rows > d.oh) rows = ((d.oh + RQ - 1) / RQ) * RQ;
         const int nbands = (d.oh + rows - 1) / rows;
         const int nblocks = nbands * d.n, ngroups = C::KYG * C::OCG;
         const size_t bytes = (size_t)nblocks * ngroups * C::NP * sizeof(float);
         int rc = uocr_need_workspace(ctx, bytes);
         if (rc) return rc;
         float* partial = (float*)ctx->workspace;
-        hipLaunchKernelGGL((conv_wgrad_fast<KH, KW, CIN, COUT, SH, SW, KYR, WCOB>), dim3(nblocks, ngroups),
+        hipLaunchKernelGGL((conv_wgrad_fast<KH, KW, CIN, COUT, SH, SW, KYR, WCOB, WPY, (CIN >= 4)>), dim3(nblocks, ngroups),
                            dim3(64, 4), 0, ctx->stream, (const float*)x, (const float*)dy, partial, dims(d),
                            (float)pad, rows, nbands);
         UOCR_LAUNCH_CHECK(ctx);
@@ -349,17 +748,18 @@ struct FastConv {
     }
 };
 
-// the my_model shapes:        KH KW CIN COUT SH SW  fwd-COB  wgrad-KYR  wgrad-COB
-#define UOCR_FAST_CONVS(X)                                                        \
-    X(3, 3, 1, 16, 1, 1, 4, 3, 16)  /* Monochrome conv_1 */                       \
-    X(3, 3, 16, 1, 1, 1, 1, 3, 1)   /* Monochrome conv_2 */                       \
-    X(5, 5, 1, 1, 2, 2, 1, 5, 1)    /* Paragraph down_1/2 */                      \
-    X(5, 5, 1, 1, 1, 1, 1, 5, 1)    /* Paragraph up_2, up_1, end */               \
-    X(5, 5, 1, 4, 2, 2, 4, 5, 4)    /* Line down_1 */                             \
-    X(5, 5, 4, 4, 2, 2, 4, 1, 4)    /* Line down_2 */                             \
-    X(5, 5, 4, 4, 1, 1, 4, 1, 4)    /* Line up_2, up_1 */                         \
-    X(5, 5, 4, 2, 1, 1, 2, 1, 2)    /* Line end */                                \
-    X(5, 3, 1, 64, 2, 1, 4, 5, 8)   /* Char conv_1 */
+// the my_model shapes:  KH KW CIN COUT SH SW | legacy fwd: COB PY | legacy dgrad: PY | wgrad: KYR COB PY |
+//                        row-loop kernels: fwd PX, dgrad PX (0 = use the legacy kernel)
+#define UOCR_FAST_CONVS(X)                                                                         \
+    X(3, 3, 1, 16, 1, 1, 4, 2, 4, 3, 16, 1, 0, 4) /* Monochrome conv_1: dgrad re-reads 16-ch dy */ \
+    X(3, 3, 16, 1, 1, 1, 1, 4, 1, 1, 1, 1, 4, 2)  /* Monochrome conv_2: fwd/wgrad re-read 16-ch x */ \
+    X(5, 5, 1, 1, 2, 2, 1, 1, 1, 5, 1, 1, 4, 0)   /* Paragraph down_1/2 */                         \
+    X(5, 5, 1, 1, 1, 1, 1, 4, 4, 5, 1, 1, 4, 4)   /* Paragraph up_2, up_1, end */                  \
+    X(5, 5, 1, 4, 2, 2, 4, 1, 1, 5, 4, 1, 4, 0)   /* Line down_1 */                                \
+    X(5, 5, 4, 4, 2, 2, 4, 2, 1, 1, 4, 1, 4, 0)   /* Line down_2 */                                \
+    X(5, 5, 4, 4, 1, 1, 4, 4, 4, 1, 4, 1, 4, 4)   /* Line up_2, up_1 */                            \
+    X(5, 5, 4, 2, 1, 1, 2, 4, 4, 1, 2, 1, 4, 4)   /* Line end */                                   \
+    X(5, 3, 1, 64, 2, 1, 4, 1, 1, 5, 8, 1, 0, 0)  /* Char conv_1 */
 
 }  // namespace
 
@@ -367,18 +767,34 @@ bool uocr_conv_fast_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d, const 
                              const void* p2) {
     if (dtype != UOCR_F32 || !ctx->opt_fast) return false;
     if (!aligned16(p0) || !aligned16(p1) || !aligned16(p2)) return false;
-#define X(KH, KW, CIN, COUT, SH, SW, COB, KYR, WCOB) \
-    if (FastConv<KH, KW, CIN, COUT, SH, SW, COB, KYR, WCOB>::match(d)) return true;
+#define X(KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX) \
+    if (FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::match(d)) return true;
     UOCR_FAST_CONVS(X)
 #undef X
     return false;
 }
 
+namespace {
+inline bool is_c16_same(const ConvDims& d, int cin, int cout) {
+    return d.kh == 3 && d.kw == 3 && d.cin == cin && d.cout == cout && d.sh == 1 && d.sw == 1 && d.oh == d.h &&
+           d.ow == d.w;
+}
+}  // namespace
+
 int uocr_conv_fwd_fast(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
                        double pad_value, int use_bias, int act, double act_alpha) {
-#define X(KH, KW, CIN, COUT, SH, SW, COB, KYR, WCOB)                        \
-    if (FastConv<KH, KW, CIN, COUT, SH, SW, COB, KYR, WCOB>::match(d))      \
-        return FastConv<KH, KW, CIN, COUT, SH, SW, COB, KYR, WCOB>::fwd(ctx, x, w, b, y, d, pad_value, use_bias, act, \
+    if (is_c16_same(d, 16, 1)) {
+        constexpr int PY = 4;
+        const dim3 grid((d.w + 15) / 16, (d.h + 4 * PY - 1) / (4 * PY), d.n), block(64, 4);
+        hipLaunchKernelGGL((conv_c16_reduce<3, 3, PY, false>), grid, block, 0, ctx->stream, (const float*)x,
+                           (const float*)w, (const float*)b, (float*)y, d.n, d.h, d.w, d.ph, d.pw, (float)pad_value,
+                           use_bias, act, (float)act_alpha);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
+#define X(KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX)                        \
+    if (FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::match(d))      \
+        return FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::fwd(ctx, x, w, b, y, d, pad_value, use_bias, act, \
                                                                         act_alpha);
     UOCR_FAST_CONVS(X)
 #undef X
@@ -386,9 +802,18 @@ int uocr_conv_fwd_fast(uocr_ctx* ctx, const void* x, const void* w, const void* 
 }
 
 int uocr_conv_dgrad_fast(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d) {
-#define X(KH, KW, CIN, COUT, SH, SW, COB, KYR, WCOB)                   \
-    if (FastConv<KH, KW, CIN, COUT, SH, SW, COB, KYR, WCOB>::match(d)) \
-        return FastConv<KH, KW, CIN, COUT, SH, SW, COB, KYR, WCOB>::dgrad(ctx, dy, w, dx, d);
+    if (is_c16_same(d, 1, 16)) {
+        constexpr int PY = 4;
+        const dim3 grid((d.w + 15) / 16, (d.h + 4 * PY - 1) / (4 * PY), d.n), block(64, 4);
+        hipLaunchKernelGGL((conv_c16_reduce<3, 3, PY, true>), grid, block, 0, ctx->stream, (const float*)dy,
+                           (const float*)w, (const float*)nullptr, (float*)dx, d.n, d.h, d.w, d.ph, d.pw, 0.f, 0,
+                           (int)UOCR_ACT_NONE, 0.f);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
+#define X(KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX)                   \
+    if (FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::match(d)) \
+        return FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::dgrad(ctx, dy, w, dx, d);
     UOCR_FAST_CONVS(X)
 #undef X
     UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "no fast conv kernel for this shape");
@@ -396,9 +821,26 @@ int uocr_conv_dgrad_fast(uocr_ctx* ctx, const void* dy, const void* w, void* dx,
 
 int uocr_conv_wgrad_fast(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
                          double pad_value, int use_bias, int accumulate) {
-#define X(KH, KW, CIN, COUT, SH, SW, COB, KYR, WCOB)                   \
-    if (FastConv<KH, KW, CIN, COUT, SH, SW, COB, KYR, WCOB>::match(d)) \
-        return FastConv<KH, KW, CIN, COUT, SH, SW, COB, KYR, WCOB>::wgrad(ctx, x, dy, dw, db, d, pad_value, use_bias, \
+    if (is_c16_same(d, 16, 1) && pad_value == 0.0) {
+        constexpr int NA = 3 * 3 * 4 + 1;
+        int rows = (d.n * d.h + 2047) / 2048;
+        rows = ((rows + 3) / 4) * 4;
+        if (rows > d.h) rows = ((d.h + 3) / 4) * 4;
+        const int nbands = (d.h + rows - 1) / rows, nblocks = nbands * d.n;
+        int rc = uocr_need_workspace(ctx, (size_t)nblocks * 4 * NA * sizeof(float));
+        if (rc) return rc;
+        float* partial = (float*)ctx->workspace;
+        hipLaunchKernelGGL((conv_c16_wgrad<3, 3>), dim3(nblocks), dim3(64, 4), 0, ctx->stream, (const float*)x,
+                           (const float*)dy, partial, d.h, d.w, d.ph, d.pw, rows, nbands);
+        UOCR_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL((conv_c16_wgrad_finish<3, 3>), dim3(NA, 4), dim3(256), 0, ctx->stream,
+                           (const float*)partial, (float*)dw, (float*)db, nblocks, use_bias, accumulate);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
+#define X(KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX)                   \
+    if (FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::match(d)) \
+        return FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::wgrad(ctx, x, dy, dw, db, d, pad_value, use_bias, \
                                                                           accumulate);
     UOCR_FAST_CONVS(X)
 #undef X
