@@ -87,7 +87,11 @@ int uocr_conv2d_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, cons
 /* dx (unpadded input shape), overwritten (convolutional.py:101-145 dx part; GPU :203-219,239-250) */
 int uocr_conv2d_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, const void* w, void* dx,
                          int n, int h, int wd, int cin, int cout, int kh, int kw, int sh, int sw,
-                         int ph, int pw, int oh, int ow);
+                         int ph, int pw, int oh, int ow,
+                         /* optional epilogue dx *= act'(x_act): x_act = this conv's INPUT when that input is
+                          * the output of a (fused) LeakyReLU / Sigmoid -- folds that layer's backward
+                          * (layers.py:400-402, 412-415) into this store; act = UOCR_ACT_NONE: off */
+                         const void* x_act, int act, double act_alpha);
 /* dw (+)= x~^T.dy, db (+)= sum dy (only when use_bias: bias_vec = bias*ones, convolutional.py:113,125);
  * the padded border contributes pad_value to dw (:124-128; GPU :221-237).  accumulate!=0 adds
  * into dw/db (`self.w.grad += dw_total`, :137-138), 0 overwrites. */

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void conv_fwd_generic(const T* __restrict__ x,
 // (gy, gx ascending = ky, kx descending), the order the reference scatter-adds them (:121-134).
 template <typename T, int CB>
 __global__ __launch_bounds__(256) void conv_dgrad_generic(const T* __restrict__ dy, const T* __restrict__ w,
-                                                          T* __restrict__ dx, ConvDims d) {
+                                                          T* __restrict__ dx, ConvDims d, const T* __restrict__ mask_y,
+                                                          int mask_act, T mask_alpha) {
     const int nib = d.cin / CB;
     const size_t total = (size_t)d.n * d.h * d.w * nib;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -120,7 +121,11 @@ __global__ __launch_bounds__(256) void conv_dgrad_generic(const T* __restrict__ 
         }
         Pack<T, CB> out;
 #pragma unroll
-        for (int j = 0; j < CB; ++j) out.v[j] = acc[j];
+        for (int j = 0; j < CB; ++j) {
+            out.v[j] = acc[j];
+            if (mask_act != UOCR_ACT_NONE)
+                out.v[j] *= act_grad_from_output<T>(mask_y[pix * d.cin + ic0 + j], mask_act, mask_alpha);
+        }
         *reinterpret_cast<Pack<T, CB>*>(dx + pix * d.cin + ic0) = out;
     }
 }
@@ -200,13 +205,14 @@ int fwd_generic(uocr_ctx* ctx, const void* x, const void* w, const void* b, void
 }
 
 template <typename T>
-int dgrad_generic(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d) {
+int dgrad_generic(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d, const ActMask& mask) {
     int cb = (d.cin % 4 == 0) ? 4 : (d.cin % 2 == 0 ? 2 : 1);
     while (cb > 1 && (reinterpret_cast<uintptr_t>(dx) % (sizeof(T) * cb))) cb >>= 1;
     const size_t total = (size_t)d.n * d.h * d.w * (d.cin / cb);
     const dim3 grid(uocr_blocks_for(total, 256, 1u << 20)), block(256);
 #define LAUNCH_DG(CB) \
-    hipLaunchKernelGGL((conv_dgrad_generic<T, CB>), grid, block, 0, ctx->stream, (const T*)dy, (const T*)w, (T*)dx, d)
+    hipLaunchKernelGGL((conv_dgrad_generic<T, CB>), grid, block, 0, ctx->stream, (const T*)dy, (const T*)w, (T*)dx, d, \
+                       (const T*)mask.y, mask.act, (T)mask.alpha)
     if (cb == 4) LAUNCH_DG(4);
     else if (cb == 2) LAUNCH_DG(2);
     else LAUNCH_DG(1);
@@ -250,8 +256,9 @@ int uocr_conv_fwd_generic(uocr_ctx* ctx, int dtype, const void* x, const void* w
     return UOCR_OK;
 }
 
-int uocr_conv_dgrad_generic(uocr_ctx* ctx, int dtype, const void* dy, const void* w, void* dx, const ConvDims& d) {
-    UOCR_DISPATCH(ctx, dtype, { return dgrad_generic<T>(ctx, dy, w, dx, d); });
+int uocr_conv_dgrad_generic(uocr_ctx* ctx, int dtype, const void* dy, const void* w, void* dx, const ConvDims& d,
+                            const ActMask& mask) {
+    UOCR_DISPATCH(ctx, dtype, { return dgrad_generic<T>(ctx, dy, w, dx, d, mask); });
     return UOCR_OK;
 }
 

@@ -35,15 +35,18 @@ int uocr_conv2d_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, cons
 }
 
 int uocr_conv2d_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, const void* w, void* dx, int n, int h, int wd,
-                         int cin, int cout, int kh, int kw, int sh, int sw, int ph, int pw, int oh, int ow) {
+                         int cin, int cout, int kh, int kw, int sh, int sw, int ph, int pw, int oh, int ow,
+                         const void* x_act, int act, double act_alpha) {
     UOCR_CHECK_CTX(ctx);
     const ConvDims d{n, h, wd, cin, cout, kh, kw, sh, sw, ph, pw, oh, ow};
     int rc = check_dims(ctx, d);
     if (rc) return rc;
     UOCR_REQUIRE(ctx, dy && w && dx);
-    if (uocr_conv_fast_eligible(ctx, dtype, d, dy, dx, w)) return uocr_conv_dgrad_fast(ctx, dy, w, dx, d);
-    if (uocr_conv_mfma_eligible(ctx, dtype, d, 1)) return uocr_conv_dgrad_mfma(ctx, dy, w, dx, d);
-    return uocr_conv_dgrad_generic(ctx, dtype, dy, w, dx, d);
+    UOCR_REQUIRE(ctx, act == UOCR_ACT_NONE || (x_act && (act == UOCR_ACT_SIGMOID || (act == UOCR_ACT_LEAKY && act_alpha > 0))));
+    const ActMask mask{act == UOCR_ACT_NONE ? nullptr : x_act, act, act_alpha};
+    if (uocr_conv_fast_eligible(ctx, dtype, d, dy, dx, w)) return uocr_conv_dgrad_fast(ctx, dy, w, dx, d, mask);
+    if (uocr_conv_mfma_eligible(ctx, dtype, d, 1)) return uocr_conv_dgrad_mfma(ctx, dy, w, dx, d, mask);
+    return uocr_conv_dgrad_generic(ctx, dtype, dy, w, dx, d, mask);
 }
 
 int uocr_conv2d_bwd_weight(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db, int n, int h,

@@ -6,11 +6,21 @@ struct ConvDims {
     int n, h, w, cin, cout, kh, kw, sh, sw, ph, pw, oh, ow;
 };
 
+// optional epilogue of backward-data: dx *= act'(y) evaluated from the activation OUTPUT y that is
+// this conv's input tensor (same shape as dx).  Folds the backward pass of a preceding fused
+// conv+LeakyReLU/Sigmoid into this kernel's store (act = UOCR_ACT_NONE: plain dx).
+struct ActMask {
+    const void* y;
+    int act;
+    double alpha;
+};
+
 // f32 MFMA implicit GEMM (gemm_mfma.hip); which: 0 fwd, 1 dgrad, 2 wgrad
 bool uocr_conv_mfma_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d, int which);
 int uocr_conv_fwd_mfma(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
                        double pad_value, int use_bias, int act, double act_alpha);
-int uocr_conv_dgrad_mfma(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d);
+int uocr_conv_dgrad_mfma(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d,
+                         const ActMask& mask);
 int uocr_conv_wgrad_mfma(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
                          double pad_value, int use_bias, int accumulate);
 // shape-specialised direct kernels for the skinny my_model convs (conv_fast.hip), f32
@@ -18,12 +28,14 @@ bool uocr_conv_fast_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d, const 
                              const void* p2);
 int uocr_conv_fwd_fast(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
                        double pad_value, int use_bias, int act, double act_alpha);
-int uocr_conv_dgrad_fast(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d);
+int uocr_conv_dgrad_fast(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d,
+                         const ActMask& mask);
 int uocr_conv_wgrad_fast(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
                          double pad_value, int use_bias, int accumulate);
 // generic direct kernels (conv.hip): any shape, f32 / f64
 int uocr_conv_fwd_generic(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* b, void* y,
                           const ConvDims& d, double pad_value, int use_bias, int act, double act_alpha);
-int uocr_conv_dgrad_generic(uocr_ctx* ctx, int dtype, const void* dy, const void* w, void* dx, const ConvDims& d);
+int uocr_conv_dgrad_generic(uocr_ctx* ctx, int dtype, const void* dy, const void* w, void* dx, const ConvDims& d,
+                            const ActMask& mask);
 int uocr_conv_wgrad_generic(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db,
                             const ConvDims& d, double pad_value, int use_bias, int accumulate);

@@ -78,6 +78,17 @@ struct FastDims {
     int n, h, w, oh, ow, ph, pw;
 };
 
+// dx epilogue: v[c] *= act'(y[off + c]) from the activation output y (ActMask, conv_dims.h)
+template <int C>
+__device__ __forceinline__ void apply_mask(float (&v)[C], const float* __restrict__ mask_y, size_t off, int act,
+                                           float alpha) {
+    if (act == UOCR_ACT_NONE) return;
+    float m[C];
+    load_vec<C>(mask_y + off, m);
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] *= act_grad_from_output<float>(m[c], act, alpha);
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward: block (64, 4); a thread computes COB output channels of PY vertically adjacent pixels
 // (register tiling: the (PY-1)*SH + KH input rows are loaded once and feed all PY outputs, which
@@ -156,7 +167,8 @@ __global__ __launch_bounds__(256) void conv_fwd_fast(const float* __restrict__ x
 // ---------------------------------------------------------------------------------------------
 template <int KH, int KW, int CIN, int COUT, int SH, int SW, int PY>
 __global__ __launch_bounds__(256) void conv_dgrad_fast(const float* __restrict__ dy, const float* __restrict__ w,
-                                                       float* __restrict__ dx, FastDims d) {
+                                                       float* __restrict__ dx, FastDims d,
+                                                       const float* __restrict__ mask_y, int mask_act, float mask_alpha) {
     static_assert(PY == 1 || (SH == 1 && SW == 1), "row tiling of dgrad needs stride 1");
     const int ix = blockIdx.x * 64 + threadIdx.x;
     const int iy0 = (blockIdx.y * 4 + threadIdx.y) * PY;
@@ -226,7 +238,9 @@ __global__ __launch_bounds__(256) void conv_dgrad_fast(const float* __restrict__
 #pragma unroll
     for (int p = 0; p < PY; ++p) {
         if (!valid || iy0 + p >= d.h) break;
-        store_vec<CIN>(dx + (((size_t)b * d.h + iy0 + p) * d.w + ix) * CIN, acc[p]);
+        const size_t off = (((size_t)b * d.h + iy0 + p) * d.w + ix) * CIN;
+        apply_mask<CIN>(acc[p], mask_y, off, mask_act, mask_alpha);
+        store_vec<CIN>(dx + off, acc[p]);
     }
 }
 
@@ -301,7 +315,8 @@ __global__ __launch_bounds__(256) void conv_fwd_px(const float* __restrict__ x, 
 // stride-1 backward data with the same structure: dx[y, x0+p, c] = sum_{ky,kx,o} dy[y+ph-ky, x0+p+pw-kx, o] w[ky,kx,c,o]
 template <int KH, int KW, int CIN, int COUT, int PX>
 __global__ __launch_bounds__(256) void conv_dgrad_px(const float* __restrict__ dy, const float* __restrict__ w,
-                                                     float* __restrict__ dx, FastDims d) {
+                                                     float* __restrict__ dx, FastDims d,
+                                                     const float* __restrict__ mask_y, int mask_act, float mask_alpha) {
     constexpr int NG = PX + KW - 1;
     const int ix0 = (blockIdx.x * 64 + threadIdx.x) * PX;
     const int iy = blockIdx.y * 4 + threadIdx.y;
@@ -344,7 +359,9 @@ __global__ __launch_bounds__(256) void conv_dgrad_px(const float* __restrict__ d
 #pragma unroll
     for (int p = 0; p < PX; ++p) {
         if (ix0 + p >= d.w) break;
-        store_vec<CIN>(dx + (((size_t)b * d.h + iy) * d.w + ix0 + p) * CIN, acc[p]);
+        const size_t off = (((size_t)b * d.h + iy) * d.w + ix0 + p) * CIN;
+        apply_mask<CIN>(acc[p], mask_y, off, mask_act, mask_alpha);
+        store_vec<CIN>(dx + off, acc[p]);
     }
 }
 
@@ -364,7 +381,8 @@ template <int KH, int KW, int PY, bool FLIP>
 __global__ __launch_bounds__(256) void conv_c16_reduce(const float* __restrict__ src, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ dst,
                                                        int n, int h, int wd, int ph, int pw, float pad, int use_bias,
-                                                       int act, float alpha) {
+                                                       int act, float alpha, const float* __restrict__ mask_y,
+                                                       int mask_act, float mask_alpha) {
     constexpr int C = 16, ROWS = PY + KH - 1;
     const int q = threadIdx.x & 3;
     const int ox = blockIdx.x * 16 + (threadIdx.x >> 2);
@@ -415,7 +433,10 @@ __global__ __launch_bounds__(256) void conv_c16_reduce(const float* __restrict__
         v += __shfl_xor(v, 2, 64);
         if (q == 0 && ox < wd && oy0 + p < h) {
             if (use_bias) v += bias[0];
-            dst[((size_t)b * h + oy0 + p) * wd + ox] = act_apply(v, act, alpha);
+            const size_t off = ((size_t)b * h + oy0 + p) * wd + ox;
+            v = act_apply(v, act, alpha);
+            if (mask_act != UOCR_ACT_NONE) v *= act_grad_from_output<float>(mask_y[off], mask_act, mask_alpha);
+            dst[off] = v;
         }
     }
 }
@@ -706,17 +727,19 @@ struct FastConv {
         return UOCR_OK;
     }
 
-    static int dgrad(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d) {
+    static int dgrad(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d, const ActMask& mask) {
         if constexpr (DPX > 0) {
             static_assert(DPX == 0 || (SH == 1 && SW == 1), "conv_dgrad_px is stride 1 only");
             const int groups = (d.w + DPX - 1) / DPX;
             const dim3 grid((groups + 63) / 64, (d.h + 3) / 4, d.n), block(64, 4);
             hipLaunchKernelGGL((conv_dgrad_px<KH, KW, CIN, COUT, DPX>), grid, block, 0, ctx->stream,
-                               (const float*)dy, (const float*)w, (float*)dx, dims(d));
+                               (const float*)dy, (const float*)w, (float*)dx, dims(d), (const float*)mask.y, mask.act,
+                               (float)mask.alpha);
         } else {
             const dim3 grid((d.w + 63) / 64, (d.h + 4 * DPY - 1) / (4 * DPY), d.n), block(64, 4);
             hipLaunchKernelGGL((conv_dgrad_fast<KH, KW, CIN, COUT, SH, SW, DPY>), grid, block, 0, ctx->stream,
-                               (const float*)dy, (const float*)w, (float*)dx, dims(d));
+                               (const float*)dy, (const float*)w, (float*)dx, dims(d), (const float*)mask.y, mask.act,
+                               (float)mask.alpha);
         }
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
@@ -788,7 +811,7 @@ int uocr_conv_fwd_fast(uocr_ctx* ctx, const void* x, const void* w, const void* 
         const dim3 grid((d.w + 15) / 16, (d.h + 4 * PY - 1) / (4 * PY), d.n), block(64, 4);
         hipLaunchKernelGGL((conv_c16_reduce<3, 3, PY, false>), grid, block, 0, ctx->stream, (const float*)x,
                            (const float*)w, (const float*)b, (float*)y, d.n, d.h, d.w, d.ph, d.pw, (float)pad_value,
-                           use_bias, act, (float)act_alpha);
+                           use_bias, act, (float)act_alpha, (const float*)nullptr, (int)UOCR_ACT_NONE, 0.f);
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
@@ -801,19 +824,20 @@ int uocr_conv_fwd_fast(uocr_ctx* ctx, const void* x, const void* w, const void* 
     UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "no fast conv kernel for this shape");
 }
 
-int uocr_conv_dgrad_fast(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d) {
+int uocr_conv_dgrad_fast(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d,
+                         const ActMask& mask) {
     if (is_c16_same(d, 1, 16)) {
         constexpr int PY = 4;
         const dim3 grid((d.w + 15) / 16, (d.h + 4 * PY - 1) / (4 * PY), d.n), block(64, 4);
         hipLaunchKernelGGL((conv_c16_reduce<3, 3, PY, true>), grid, block, 0, ctx->stream, (const float*)dy,
                            (const float*)w, (const float*)nullptr, (float*)dx, d.n, d.h, d.w, d.ph, d.pw, 0.f, 0,
-                           (int)UOCR_ACT_NONE, 0.f);
+                           (int)UOCR_ACT_NONE, 0.f, (const float*)mask.y, mask.act, (float)mask.alpha);
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
 #define X(KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX)                   \
     if (FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::match(d)) \
-        return FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::dgrad(ctx, dy, w, dx, d);
+        return FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::dgrad(ctx, dy, w, dx, d, mask);
     UOCR_FAST_CONVS(X)
 #undef X
     UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "no fast conv kernel for this shape");

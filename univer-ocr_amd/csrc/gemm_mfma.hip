@@ -47,6 +47,10 @@ struct Epilogue {
     // conv dw/db: rows >= split_row go to c2[j] instead (the bias row of [x~,1]^T.dy)
     int split_row;       // -1 = disabled
     float* c2;
+    // conv dx: value *= act'(mask_y[i*ldc + j]) (backward of the activation that produced this conv's input)
+    const float* mask_y;
+    int mask_act;
+    float mask_alpha;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act, float alpha) {
@@ -61,6 +65,7 @@ __device__ __forceinline__ float act_apply(float v, int act, float alpha) {
 __device__ __forceinline__ void epilogue_store(const Epilogue& e, int i, int j, float v) {
     if (e.bias) v += e.bias[j];
     v = act_apply(v, e.act, e.alpha);
+    if (e.mask_act != UOCR_ACT_NONE) v *= act_grad_from_output<float>(e.mask_y[(long)i * e.ldc + j], e.mask_act, e.mask_alpha);
     float* dst = (e.split_row >= 0 && i >= e.split_row) ? e.c2 + j : e.c + (long)i * e.ldc + j;
     *dst = e.accumulate ? *dst + v : v;
 }
@@ -443,7 +448,7 @@ int launch_mfma(uocr_ctx* ctx, const ALoader& A, const BRowMajor& B, const Epilo
 }
 
 inline Epilogue plain_epilogue(float* c, long ldc, int accumulate) {
-    return Epilogue{c, ldc, nullptr, UOCR_ACT_NONE, 0.f, accumulate, -1, nullptr};
+    return Epilogue{c, ldc, nullptr, UOCR_ACT_NONE, 0.f, accumulate, -1, nullptr, nullptr, UOCR_ACT_NONE, 0.f};
 }
 
 }  // namespace
@@ -501,11 +506,13 @@ int uocr_conv_fwd_mfma(uocr_ctx* ctx, const void* x, const void* w, const void* 
     const int M = d.n * d.oh * d.ow, K = d.kh * d.kw * d.cin;
     AConvFwd A{(const float*)x, d, (float)pad_value, M};
     BRowMajor B{(const float*)w, d.cout, K, d.cout, aligned16(w) ? 1 : 0};
-    Epilogue ep{(float*)y, d.cout, use_bias ? (const float*)b : nullptr, act, (float)act_alpha, 0, -1, nullptr};
+    Epilogue ep{(float*)y, d.cout, use_bias ? (const float*)b : nullptr, act, (float)act_alpha, 0, -1, nullptr,
+                nullptr,    UOCR_ACT_NONE, 0.f};
     return launch_mfma(ctx, A, B, ep, M, d.cout, K, false);
 }
 
-int uocr_conv_dgrad_mfma(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d) {
+int uocr_conv_dgrad_mfma(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d,
+                         const ActMask& mask) {
     const int M = d.n * d.h * d.w, D = d.kh * d.kw * d.cout;
     float* wt = ws_aux(ctx);
     hipLaunchKernelGGL(conv_weight_transpose_kernel, dim3(uocr_blocks_for((size_t)D * d.cin, 256, 1024)), dim3(256),
@@ -513,7 +520,10 @@ int uocr_conv_dgrad_mfma(uocr_ctx* ctx, const void* dy, const void* w, void* dx,
     UOCR_LAUNCH_CHECK(ctx);
     AConvDgrad A{(const float*)dy, d, M};
     BRowMajor B{wt, d.cin, D, d.cin, 1};
-    const Epilogue ep = plain_epilogue((float*)dx, d.cin, 0);
+    Epilogue ep = plain_epilogue((float*)dx, d.cin, 0);
+    ep.mask_y = (const float*)mask.y;
+    ep.mask_act = mask.act;
+    ep.mask_alpha = (float)mask.alpha;
     return launch_mfma(ctx, A, B, ep, M, d.cin, D, false);
 }
 
@@ -523,7 +533,8 @@ int uocr_conv_wgrad_mfma(uocr_ctx* ctx, const void* x, const void* dy, void* dw,
     const int M = K + (use_bias ? 1 : 0);
     AConvWgrad A{(const float*)x, d, (float)pad_value, K, use_bias, P};
     BRowMajor B{(const float*)dy, d.cout, P, d.cout, aligned16(dy) ? 1 : 0};
-    Epilogue ep{(float*)dw, d.cout, nullptr, UOCR_ACT_NONE, 0.f, accumulate, use_bias ? K : -1, (float*)db};
+    Epilogue ep{(float*)dw, d.cout, nullptr, UOCR_ACT_NONE, 0.f, accumulate, use_bias ? K : -1, (float*)db,
+                nullptr,    UOCR_ACT_NONE, 0.f};
     int rc = launch_mfma(ctx, A, B, ep, M, d.cout, P, true);
     if (rc) return rc;
     if (!use_bias && !accumulate) UOCR_HIP(ctx, hipMemsetAsync(db, 0, (size_t)d.cout * sizeof(float), ctx->stream));

@@ -107,5 +107,13 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* smem /* >= 
     return v;
 }
 
+// d act(x) / dx expressed through the activation OUTPUT y (leaky: alpha > 0 so sign(y) == sign(x))
+template <typename T>
+__device__ __forceinline__ T act_grad_from_output(T y, int act, T alpha) {
+    if (act == UOCR_ACT_LEAKY) return y >= T(0) ? T(1) : alpha;
+    if (act == UOCR_ACT_SIGMOID) return y * (T(1) - y);
+    return T(1);
+}
+
 // out = (accumulate ? out : 0) + scale * sum(partial[0..count)), one block, deterministic order
 int uocr_finish_sum(uocr_ctx* ctx, const double* partial, int count, double scale, double* out, int accumulate);

@@ -55,7 +55,7 @@ _PROTOS = {
     'uocr_event_elapsed_ms_sync': [_vp, _vp, C.POINTER(C.c_float)],
     'uocr_device_info': [_ctx, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_sz)],
     'uocr_conv2d_fwd': [_ctx, _i, _vp, _vp, _vp, _vp] + [_i] * 13 + [_d, _i, _i, _d],
-    'uocr_conv2d_bwd_data': [_ctx, _i, _vp, _vp, _vp] + [_i] * 13,
+    'uocr_conv2d_bwd_data': [_ctx, _i, _vp, _vp, _vp] + [_i] * 13 + [_vp, _i, _d],
     'uocr_conv2d_bwd_weight': [_ctx, _i, _vp, _vp, _vp, _vp] + [_i] * 13 + [_d, _i, _i],
     'uocr_maxpool2d_fwd': [_ctx, _i, _vp, _vp, _vp] + [_i] * 12,
     'uocr_maxpool2d_bwd': [_ctx, _i, _vp, _vp, _vp] + [_i] * 12,

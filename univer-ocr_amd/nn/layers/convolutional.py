@@ -75,13 +75,26 @@ class Convolutional2D(BaseLayerGPU):
         return [y]
 
     @track_method('backward')
-    def backward_fused(self, grads, activation):
+    def backward_fused(self, grads, activation=None, act_grad_applied=False, input_activation=None):
+        """Backward of the fused graph.  `activation`: the layer fused into this conv's forward (its
+        gradient is taken from the stored output unless the consumer already applied it:
+        `act_grad_applied`).  `input_activation`: this conv's input is the output of a fused
+        activation whose only consumer is this conv -- dx is stored already multiplied by that
+        activation's derivative (one pass less over the tensor)."""
         grad = ops.as_device(make_list_if_not(grads)[0])
-        grad = ops.act_bwd_from_output(activation.kind, self._fused_out, grad, activation.alpha)
-        result = [self._backward(grad, 0)]
+        if activation is not None and not act_grad_applied:
+            grad = ops.act_bwd_from_output(activation.kind, self._fused_out, grad, activation.alpha)
+        X = self._mem[0]
+        ops.conv2d_bwd_weight(X, grad, self.w.grad, self.b.grad, self.stride, self.padding, self.padding_value,
+                              self.bias, accumulate=True)
+        if input_activation is None:
+            dx = ops.conv2d_bwd_data(grad, self.w.value, X.shape, self.stride, self.padding)
+        else:
+            dx = ops.conv2d_bwd_data(grad, self.w.value, X.shape, self.stride, self.padding, x_act=X,
+                                     act=input_activation.kind, alpha=input_activation.alpha)
         self._fused_out = None
         self.clear_memory()
-        return result
+        return [dx]
 
     def get_output_shapes(self, input_shapes):
         batch, height, width, _ = make_list_if_not(input_shapes)[0]

@@ -227,11 +227,15 @@ class Model(BaseModel):
         for node in reversed(self._plan):
             if node not in self.relations_backward:
                 continue
-            if node in fused_act:                     # its gradient is applied inside the conv's backward
+            if node in fused_act:                     # its gradient is applied inside a conv's backward
                 grads_mem[node] = [incoming(node)]
-            elif node in fused_conv:
-                grads_mem[node] = make_list_if_not(
-                    self.layers[node].backward_fused(incoming(node), self.layers[fused_conv[node]]))
+            elif node in fused_conv or node in self._fusion[2]:
+                act = self.layers[fused_conv[node]] if node in fused_conv else None
+                folded = node in fused_conv and fused_conv[node] in self._fusion[3]
+                in_act = self._fusion[2].get(node)
+                grads_mem[node] = make_list_if_not(self.layers[node].backward_fused(
+                    incoming(node), act, act_grad_applied=folded,
+                    input_activation=None if in_act is None else self.layers[in_act]))
             else:
                 grads_mem[node] = make_list_if_not(self.layers[node].backward(incoming(node)))
         self.input_grads = {key: incoming(key) for key in range(self.inputs_count)
@@ -250,6 +254,7 @@ class Model(BaseModel):
 
     def _fusion_maps(self):
         if not getattr(self, 'fuse_activations', False):
+            self._fusion = ({}, {}, {}, set())
             return {}, {}
         if self._fusion is None:
             from .layers import Convolutional2D, LeakyRelu, Sigmoid
@@ -267,8 +272,21 @@ class Model(BaseModel):
                 if ok and type(act) in (Sigmoid, LeakyRelu):
                     fused_conv[node] = dst
                     fused_act[dst] = node
-            self._fusion = (fused_conv, fused_act)
-        return self._fusion
+            # a fused activation whose ONLY consumer is a conv: that conv's dx kernel multiplies by the
+            # activation's derivative in its epilogue (input_of[conv] = act), and the producing conv
+            # skips its own activation-gradient pass (folded)
+            input_of, folded = {}, set()
+            for act_node in fused_act:
+                consumers = self.relations_backward.get(act_node, {})
+                if len(consumers) != 1:
+                    continue
+                (dst, _), = consumers.items()
+                if not isinstance(dst, int) and isinstance(self.layers[dst], Convolutional2D) and \
+                        self.relations[dst] == [act_node]:
+                    input_of[dst] = act_node
+                    folded.add(act_node)
+            self._fusion = (fused_conv, fused_act, input_of, folded)
+        return self._fusion[0], self._fusion[1]
 
     def _loss_func(self, key):
         return self.loss[key] if isinstance(self.loss, list) else self.loss

@@ -63,13 +63,18 @@ def conv2d_fwd(x, w, b, stride, padding, pad_value=0.0, bias=True, act=None, alp
     return y
 
 
-def conv2d_bwd_data(dy, w, x_shape, stride, padding):
+def conv2d_bwd_data(dy, w, x_shape, stride, padding, x_act=None, act=None, alpha=0.0):
+    """dx of the conv; with `x_act` (the conv's input = output of a fused LeakyReLU / Sigmoid) the
+    kernel stores dx * act'(x_act), i.e. the gradient w.r.t. that activation's INPUT."""
     dims = _conv_dims(x_shape, w.shape, stride, padding)
-    code = _same_dtype(dy, w)
+    code = _same_dtype(dy, w) if x_act is None else _same_dtype(dy, w, x_act)
     if dy.shape != (dims[0], dims[11], dims[12], dims[4]):
         raise AssertionError(f'grad shape {dy.shape} does not match the layer output')
+    if x_act is not None and x_act.shape != tuple(x_shape):
+        raise AssertionError(f'activation tensor {x_act.shape} != conv input {tuple(x_shape)}')
     dx = CP.empty(x_shape, dy.dtype)
-    _rt().call('uocr_conv2d_bwd_data', code, dy.ptr, w.ptr, dx.ptr, *dims)
+    _rt().call('uocr_conv2d_bwd_data', code, dy.ptr, w.ptr, dx.ptr, *dims,
+               None if x_act is None else x_act.ptr, ACT_CODES[act if x_act is not None else None], float(alpha))
     return dx
 
 
