@@ -1,0 +1,76 @@
+"""Data-parallel path on CPU: world_size 2, gloo backend (the GPU path uses the same code with the
+"nccl" = RCCL backend).  Without a GPU the DeviceArrays are storage-only host tensors, so this
+covers what is host logic: weight broadcast at construction, the flat-gradient all-reduce, SUM vs
+MEAN semantics per loss type, deferred (overlapped) completion and the replica-consistency check."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, results):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from univer_ocr_amd.my_model.model import make_char, make_monochrome
+        from univer_ocr_amd.nn.optimizers import Momentum
+        from univer_ocr_amd.parallel import DataParallel, mean_type_loss
+
+        np.random.seed(100 + rank)                    # different initial weights on every rank
+        mono = make_monochrome((2, 8, 8, 1), Momentum(lr=0.1))
+        char = make_char((1, 32, 8, 1), Momentum(lr=0.1))
+        before = mono.pack.value.t.clone()
+        dp = DataParallel({'Monochrome': mono, 'Char': char}, overlap=True)
+        out = {'rank': rank}
+        # 1. replicas start identical (rank 0's weights), and they were different before
+        out['sync0'] = dp.replicas_in_sync(mono) and dp.replicas_in_sync(char)
+        out['changed'] = bool((before != mono.pack.value.t).any().item()) if rank != 0 else True
+        assert not mean_type_loss(mono) and mean_type_loss(char)
+        # 2. Dice nets SUM the gradients, immediate completion
+        mono.pack.grad.t.fill_(float(rank + 1))
+        mono.defer_grad_sync = False
+        mono.grad_sync(mono)
+        out['mono_grad'] = float(mono.pack.grad.t[0].item())              # 1 + 2 = 3
+        # 3. SoftmaxCE nets average; deferred completion (overlap): finished only by wait()
+        char.pack.grad.t.fill_(float(10 * (rank + 1)))
+        char.defer_grad_sync = True
+        char.grad_sync(char)
+        out['pending'] = id(char) in dp._pending
+        dp.wait(char)
+        out['char_grad'] = float(char.pack.grad.t[0].item())              # (10 + 20) / 2 = 15
+        out['drained'] = id(char) not in dp._pending
+        # 4. a diverged replica is detected
+        if rank == 1:
+            mono.pack.value.t[0] += 1.0
+        out['sync1'] = dp.replicas_in_sync(mono)
+        results[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_world2():
+    if torch.cuda.is_available():
+        pytest.skip('CPU (gloo) rehearsal of the data-parallel logic')
+    world, port = 2, _free_port()
+    with mp.Manager() as manager:
+        results = manager.dict()
+        mp.spawn(_worker, args=(world, port, results), nprocs=world, join=True)
+        results = dict(results)
+    assert set(results) == {0, 1}
+    for rank, out in results.items():
+        assert out['sync0'] and out['changed']
+        assert out['mono_grad'] == 3.0
+        assert out['pending'] and out['drained']
+        assert out['char_grad'] == 15.0
+        assert out['sync1'] is False

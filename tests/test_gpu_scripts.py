@@ -1,0 +1,37 @@
+"""The reference's own test entry points, driven through the HIP backend on the GPU:
+`test_nn.py test_gradients` (numeric gradient checks, float64) and `test_nn.py test_identity`
+(float32 production kernels vs float64 generic kernels on 5x240x320x6), plus one tiny `train_model`
+curriculum that writes and re-reads model_weights.json."""
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_test_gradients_script():
+    from univer_ocr_amd.nn.test import test_gradients
+    correct, total = test_gradients.main(True)
+    assert total >= 35 and correct == total          # reference probe: 35/35 on its NumPy path
+
+
+def test_test_identity_script():
+    from univer_ocr_amd.nn.test import test_identity
+    correct, total = test_identity.main(True)
+    assert (correct, total) == (10, 10)
+
+
+def test_train_model_curriculum(tmp_path, monkeypatch):
+    from univer_ocr_amd.my_model import train as train_mod
+    from univer_ocr_amd.nn import CP
+    CP.set_dtype('float32')
+    path = tmp_path / 'model_weights.json'
+    monkeypatch.setattr(train_mod, 'MODEL_WEIGHTS_FILE_PATH', path)
+    results = train_mod.train_model(True, epochs_scale=0.011, batch=1, height=32, width=64)
+    assert set(results) == {'TRAIN_MONOCHROME', 'TRAIN_PARAGRAPH', 'TRAIN_PAGE'}
+    weights = json.loads(path.read_text())
+    assert 'Monochrome/conv_1' in weights and 'Char/dense_block/dense_3' in weights
+    assert np.array(weights['Monochrome/conv_1']['w']).shape == (3, 3, 1, 16)
+    assert np.array(weights['Char/dense_block/dense_1']['w']).shape == (513, 1024)
+    assert all(np.isfinite(np.array(v)).all() for layer in weights.values() for v in layer.values())

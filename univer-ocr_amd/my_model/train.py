@@ -1,0 +1,72 @@
+"""`train_model` -- the curriculum driver behind `python train.py` (reference: my_model/train.py:67-289).
+
+Stages (mode, lr, lr_step, epochs) train one net at a time and then all of them, each stage resuming
+from and saving to `model_weights.json` (flat {"<layer name>": {"<param>": nested list}} written with
+compact separators, train.py:132-141).  The reference's stages that chain nets through the host
+crop/rotate code (TRAIN_LINE / TRAIN_CHAR / TRAIN_ALL) are replaced by TRAIN_PAGE, which trains all
+four nets on device-resident page and line-strip batches.  Data: seeded synthetic pages
+(my_model/synthetic.py); the reference's generate_data needs Windows fonts and stays outside."""
+import json
+import os
+from pathlib import Path
+
+from ..nn.gpu import CP
+from ..nn.optimizers import Adam
+from ..nn.progress_tracker import ProgressTracker
+from .model import Modes, make_context_maker, make_model_system
+from .synthetic import SyntheticPages
+from .trainer import Trainer
+
+MODEL_WEIGHTS_FILE_PATH = Path(os.environ.get(
+    'UOCR_WEIGHTS', Path(__file__).resolve().parent / 'model_weights.json'))
+
+
+def message(*args):
+    print(*args, flush=True)
+
+
+def load_weights(path=MODEL_WEIGHTS_FILE_PATH):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except OSError:
+        print('No model_weights.json file found')
+        return {}
+
+
+def train_model(use_gpu=True, show_progress_bar=False, save_train_progress=False, epochs_scale=None,
+                batch=1, height=256, width=512):
+    if not use_gpu:
+        CP.use_cpu()          # raises: the NumPy path is the reference itself
+    CP.use_gpu()
+    info = CP.runtime().device_info()
+    message(f'Using GPU\nname = {info["name"]}\nmultiProcessorCount = {info["cu_count"]}\n'
+            f'totalGlobalMem = {info["hbm_bytes"]}\nwarpSize = 64\n')
+    tracker = ProgressTracker(lambda *a: None)
+    scale = float(os.environ.get('UOCR_EPOCHS_SCALE', '0.02')) if epochs_scale is None else epochs_scale
+    stages = [(Modes.TRAIN_MONOCHROME, 0.0015, 0.995, 100), (Modes.TRAIN_PARAGRAPH, 0.0015, 0.995, 100),
+              (Modes.TRAIN_PAGE, 0.001, 0.9, 10)]
+    train_set = SyntheticPages(batch, height, width, seed=1234, length=4)
+    val_set = SyntheticPages(batch, height, width, seed=9999, length=2)
+    results = {}
+    for mode, lr, lr_step, epochs in stages:
+        epochs = max(1, int(round(epochs * scale)))
+        message(f'Training mode: {mode.name}')
+        weights = load_weights()
+        optimizer = Adam(lr=lr)
+        input_shape = (batch, height, width, 1)
+        model_system, models, names = make_model_system(input_shape, optimizer, tracker, weights, mode=mode,
+                                                        char_input_shape=(batch, 32, 64, 1))
+        message(f'Input shape: {input_shape}; parameters: {sum(m.count_parameters() for m in models.values())}')
+
+        def save_weights(better, models=models):
+            merged = load_weights()
+            for name, model in models.items():
+                if name in better:
+                    merged.update(model.get_weights())
+            with open(MODEL_WEIGHTS_FILE_PATH, 'w') as f:
+                json.dump(merged, f, separators=(',', ':'))
+        trainer = Trainer(model_system, make_context_maker(mode), models, train_set, val_set, tracker,
+                          show_progress_bar, optimizer, lr_step, save_weights)
+        results[mode.name] = trainer.train(epochs)
+    return results

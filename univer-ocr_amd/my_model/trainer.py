@@ -99,3 +99,143 @@ class PageTrainer:
 
     def forward(self, context):
         self.model_system.predict({**context})
+
+
+class Losses:
+    """Per-model running losses of one epoch (reference: my_model/trainer.py:10-125)."""
+
+    def __init__(self, model_names, outputs_cnts):
+        self.model_names, self.outputs_cnts = model_names, outputs_cnts
+        inf = float('inf')
+        self.train_prev_losses = self._new(inf)
+        self.val_best_losses = self._new(inf)
+        self.val_prev_losses = self._new(inf)
+        self.train_losses = self.val_losses = None
+        self.best_loss_epoch = {name: 0 for name in model_names}
+
+    def _new(self, value):
+        return {name: [value] * self.outputs_cnts[name] for name in self.model_names}
+
+    def reset(self):
+        self.train_losses, self.val_losses = self._new(0.0), self._new(0.0)
+
+    def _add(self, table, update):
+        for name in self.model_names:
+            for i in range(self.outputs_cnts[name]):
+                table[name][i] += float(update[name]['output_losses'][i])
+
+    def train(self, update):
+        self._add(self.train_losses, update)
+
+    def validation(self, update):
+        self._add(self.val_losses, update)
+
+    def normalize(self, n_train, n_val):
+        for name in self.model_names:
+            self.train_losses[name] = [v / n_train for v in self.train_losses[name]]
+            self.val_losses[name] = [v / n_val for v in self.val_losses[name]]
+
+    def get_better_weights(self, epoch):
+        better = []
+        for name in self.model_names:
+            new, best = np.mean(self.val_losses[name]), np.mean(self.val_best_losses[name])
+            if new < best or (not np.isnan(new) and np.isnan(best)):
+                better.append(name)
+                self.val_best_losses[name] = self.val_losses[name]
+                self.best_loss_epoch[name] = epoch
+        return better
+
+    def next(self):
+        self.train_prev_losses, self.val_prev_losses = self.train_losses, self.val_losses
+
+    def print(self, left_margin=0):
+        pad = ' ' * left_margin
+        for title, now, prev in (('Train loss', self.train_losses, self.train_prev_losses),
+                                 ('Validation loss', self.val_losses, self.val_prev_losses)):
+            cells = []
+            for name in self.model_names:
+                vals = ' '.join(f'{v: .6f}' for v in now[name])
+                diffs = ' '.join(f'{a - b:+.6f}' for a, b in zip(now[name], prev[name]))
+                cells.append(f'{name}: {vals} ({diffs})')
+            print(pad + f'{title + ":":18s}' + ' | '.join(cells))
+
+
+class Trainer:
+    """Epoch loop of the reference (my_model/trainer.py:128-296): a validation pre-pass, then per epoch a
+    train pass and a validation pass, learning-rate decay, NaN rollback (reload the last weights up to
+    10 times with a shrinking lr, then the best ones) and a callback with the models whose
+    validation loss improved.  `make_context_func(dataset.get, (index,))` builds the device context."""
+
+    def __init__(self, model_system, make_context_func, models, train_dataset, validation_dataset,
+                 progress_tracker=None, show_progress_bar=False, optimizer=None, learning_rate_step=0.995,
+                 save_weights_func=None, save_pictures_func=None):
+        from ..nn.progress_tracker import BaseProgressTracker
+        self.model_system, self.make_context_func, self.models = model_system, make_context_func, models
+        self.train_dataset, self.validation_dataset = train_dataset, validation_dataset
+        self.progress_tracker = progress_tracker or BaseProgressTracker()
+        self.show_progress_bar = show_progress_bar
+        self.optimizer, self.learning_rate_step = optimizer, learning_rate_step
+        self.save_weights_func, self.save_pictures_func = save_weights_func, save_pictures_func
+
+    def _weights(self):
+        return {name: w for model in self.models.values() for name, w in model.get_weights().items()}
+
+    def _pass(self, dataset, order, losses_sink, train, epoch, stage):
+        for i, idx in enumerate(order):
+            self.progress_tracker.reset()
+            context = self.make_context_func(dataset.get, (idx,))
+            (self.model_system.train if train else self.model_system.test)(context)
+            losses_sink(context['losses'])
+            if self.save_pictures_func is not None:
+                self.save_pictures_func(epoch, stage, i, context)
+            self.progress_tracker.message(f'{stage}_iteration', {'current': i + 1, 'total': len(order)})
+
+    def train(self, num_epochs):
+        from random import shuffle
+        names = list(self.models)
+        losses = Losses(names, {n: m.get_outputs_count() for n, m in self.models.items()})
+        n_train, n_val = len(self.train_dataset), len(self.validation_dataset)
+        assert n_val > 0, 'Validation dataset must have at least 1 element'
+        print('Precomputing losses')
+        losses.reset()
+        self._pass(self.validation_dataset, list(range(n_val)), losses.validation, False, 0, 'precomputing')
+        losses.next()
+        best_weights = last_weights = self._weights()
+        reload_attempts, epoch = 0, 1
+        train_order, val_order = list(range(n_train)), list(range(n_val))
+        while epoch <= num_epochs:
+            print(f'Epoch {epoch}/{num_epochs}:' + (f'  lr = {self.optimizer.lr}' if self.optimizer else ''))
+            self.progress_tracker.message('epoch', {'current': epoch, 'total': num_epochs})
+            losses.reset()
+            shuffle(train_order)
+            self._pass(self.train_dataset, train_order, losses.train, True, epoch, 'train')
+            shuffle(val_order)
+            self._pass(self.validation_dataset, val_order, losses.validation, False, epoch, 'validation')
+            losses.normalize(n_train, n_val)
+            has_nan = any(model.nan_weights() for model in self.models.values())
+            if self.optimizer is not None:
+                reload_attempts += 1
+                self.optimizer.lr *= self.learning_rate_step ** reload_attempts
+                if has_nan:
+                    source = last_weights if reload_attempts < 10 else best_weights
+                    print('NaN value found in weights, loading ' +
+                          ('last weights' if reload_attempts < 10 else 'last best weights'))
+                    for model in self.models.values():
+                        model.set_weights(source)
+                    if reload_attempts >= 10:
+                        reload_attempts = 0
+                    continue
+            elif has_nan:
+                raise ValueError('NaN value found in weights, but no optimizer provided. Provide optimizer and '
+                                 'learning_rate_step, so learning rate could be decreased to try avoiding NaN values')
+            losses.print(left_margin=2)
+            better = losses.get_better_weights(epoch)
+            if better and self.save_weights_func:
+                print('  Saving weights for ' + ', '.join(better))
+                self.save_weights_func(better)
+                best_weights = self._weights()
+            last_weights = self._weights()
+            epoch += 1
+            reload_attempts = 0
+            losses.next()
+        return losses.val_best_losses, losses.best_loss_epoch
