@@ -149,13 +149,20 @@ def main():
     layers = make_page_batch(args.batch, args.height, args.width, args.char_width, seed=1234 + rank)
     context = trainer.make_context(layers)       # inputs resident in HBM before the timed region
 
-    # dominant kernel (profiles/): dw/db of Monochrome conv_2 (3x3, 16->1) -- reads the 16-channel
-    # activation (B*H*W*16*4 B) and dy (B*H*W*4 B) once: algorithmic bytes = 4*B*H*W*(16+1) + 4*(144+1)
+    # dominant kernel = the single longest launch of the step in the rocprofv3 trace (profiles/):
+    # dx of Monochrome conv_2 (3x3, 16->1) with the LeakyReLU' epilogue of conv_1 folded in.  One launch
+    # reads dy (1 ch) and the activation output (16 ch, the mask) and writes dx (16 ch):
+    # algorithmic bytes = 4 * B*H*W * (1 + 16 + 16) + 4 * 144 (weights)
     npix = args.batch * args.height * args.width
-    probe = KernelProbe(rt, 'uocr_conv2d_bwd_weight',
-                        lambda a: a[8] == 16 and a[9] == 1 and a[10] == 3 and a[11] == 3)
-    dominant = {'kernel': 'conv2d_bwd_weight 3x3 16->1 (Monochrome/conv_2 dw,db)',
-                'bytes': 4.0 * npix * 17 + 4 * 145}
+    probe = KernelProbe(rt, 'uocr_conv2d_bwd_data',
+                        lambda a: a[7] == 16 and a[8] == 1 and a[9] == 3 and a[10] == 3)
+    dominant = {'kernel': "conv2d_bwd_data 3x3 16->1 + LeakyReLU' epilogue (Monochrome/conv_2 dx; conv_c16_expand<3,3,2,true>)",
+                'bytes': 4.0 * npix * 33 + 4 * 144}
+    traffic = None            # HBM bytes per launch from rocprofv3 PMC passes, when a profile is committed
+    tpath = os.path.join(ROOT, 'profiles', 'dominant_kernel_traffic.json')
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get('hbm_bytes_per_launch')
 
     def barrier():
         torch.cuda.synchronize()
@@ -203,7 +210,7 @@ def main():
             },
             'roofline': {'bound': 'hbm', 'kernel': dominant['kernel'], 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                         'traffic': None, 'avg_launch_us': round(kernel_ms * 1e3, 2), 'launches_timed': launches,
+                         'traffic': traffic, 'avg_launch_us': round(kernel_ms * 1e3, 2), 'launches_timed': launches,
                          'algorithmic_bytes_per_launch': dominant['bytes']},
         }
         if world == 1 and not args.no_cpu_baseline:

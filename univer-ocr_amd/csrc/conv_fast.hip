@@ -441,6 +441,80 @@ __global__ __launch_bounds__(256) void conv_c16_reduce(const float* __restrict__
     }
 }
 
+// The opposite direction, 1 channel -> 16 channels through a KHxKW window (Monochrome conv_1 forward,
+// conv_2 dx): lane (pixel, quad) produces 4 of the 16 channels, so every store instruction of a wave
+// is 64 x 16 B contiguous.  With one lane per pixel(s) the 64 B per pixel were written as four 16 B
+// pieces at a 64-128 B lane stride and rocprofv3 WRITE_SIZE showed 1.37x the algorithmic bytes.
+//   FLIP = false: y[p,o]  = sum_k x[p + k - pad] * w[k,o] (+ b[o], activation)
+//   FLIP = true : dx[p,c] = sum_k dy[p - k + pad] * w[k,c]  (* act'(mask_y[p,c]))
+template <int KH, int KW, int PY, bool FLIP>
+__global__ __launch_bounds__(256) void conv_c16_expand(const float* __restrict__ src, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ dst,
+                                                       int n, int h, int wd, int ph, int pw, float pad, int use_bias,
+                                                       int act, float alpha, const float* __restrict__ mask_y,
+                                                       int mask_act, float mask_alpha) {
+    constexpr int C = 16, ROWS = PY + KH - 1;
+    const int q = threadIdx.x & 3;
+    const int ox = blockIdx.x * 16 + (threadIdx.x >> 2);
+    const int oy0 = (blockIdx.y * 4 + threadIdx.y) * PY;
+    const int b = blockIdx.z;
+    float wreg[KH][KW][4];
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const int sky = FLIP ? KH - 1 - ky : ky, skx = FLIP ? KW - 1 - kx : kx;
+            const float4 t = *reinterpret_cast<const float4*>(w + (sky * KW + skx) * C + q * 4);
+            wreg[ky][kx][0] = t.x;
+            wreg[ky][kx][1] = t.y;
+            wreg[ky][kx][2] = t.z;
+            wreg[ky][kx][3] = t.w;
+        }
+    const int PH = FLIP ? KH - 1 - ph : ph, PW = FLIP ? KW - 1 - pw : pw;
+    float acc[PY][4];
+#pragma unroll
+    for (int p = 0; p < PY; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = 0.f;
+    const float* sb = src + (size_t)b * h * wd;
+    const int oxc = min(ox, wd - 1);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int iy = oy0 - PH + r;
+        const bool row_ok = iy >= 0 && iy < h;
+        const float* sr = sb + (size_t)min(max(iy, 0), h - 1) * wd;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const int ix = oxc - PW + kx;
+            float v = sr[min(max(ix, 0), wd - 1)];
+            if (!(row_ok && ix >= 0 && ix < wd)) v = pad;
+#pragma unroll
+            for (int p = 0; p < PY; ++p) {
+                const int ky = r - p;      // compile-time after unrolling
+                if (ky >= 0 && ky < KH) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[p][j] += v * wreg[ky][kx][j];
+                }
+            }
+        }
+    }
+    if (ox >= wd) return;
+#pragma unroll
+    for (int p = 0; p < PY; ++p) {
+        if (oy0 + p >= h) break;
+        const size_t off = (((size_t)b * h + oy0 + p) * wd + ox) * C + q * 4;
+        float out[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[p][j];
+            if (use_bias) v += bias[q * 4 + j];
+            out[j] = act_apply(v, act, alpha);
+        }
+        apply_mask<4>(out, mask_y, off, mask_act, mask_alpha);
+        store_vec<4>(dst + off, out);
+    }
+}
+
 // dw[ky,kx,c] (+ db) of the 16 -> 1 conv, x-stationary: dw[ky,kx,c] = sum_q x[q,c] * dy[q - (ky,kx) + pad].
 // A lane (input pixel q, channel quad) loads its 16 B of x exactly ONCE (64 lanes = 1 KiB contiguous)
 // and the 1-channel dy at the KH*KW shifted positions (4 B each, L1 hits), so the 268 MB tensor
@@ -806,6 +880,15 @@ inline bool is_c16_same(const ConvDims& d, int cin, int cout) {
 
 int uocr_conv_fwd_fast(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
                        double pad_value, int use_bias, int act, double act_alpha) {
+    if (is_c16_same(d, 1, 16)) {
+        constexpr int PY = 2;
+        const dim3 grid((d.w + 15) / 16, (d.h + 4 * PY - 1) / (4 * PY), d.n), block(64, 4);
+        hipLaunchKernelGGL((conv_c16_expand<3, 3, PY, false>), grid, block, 0, ctx->stream, (const float*)x,
+                           (const float*)w, (const float*)b, (float*)y, d.n, d.h, d.w, d.ph, d.pw, (float)pad_value,
+                           use_bias, act, (float)act_alpha, (const float*)nullptr, (int)UOCR_ACT_NONE, 0.f);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
     if (is_c16_same(d, 16, 1)) {
         constexpr int PY = 4;
         const dim3 grid((d.w + 15) / 16, (d.h + 4 * PY - 1) / (4 * PY), d.n), block(64, 4);
@@ -826,6 +909,15 @@ int uocr_conv_fwd_fast(uocr_ctx* ctx, const void* x, const void* w, const void* 
 
 int uocr_conv_dgrad_fast(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d,
                          const ActMask& mask) {
+    if (is_c16_same(d, 16, 1)) {
+        constexpr int PY = 2;
+        const dim3 grid((d.w + 15) / 16, (d.h + 4 * PY - 1) / (4 * PY), d.n), block(64, 4);
+        hipLaunchKernelGGL((conv_c16_expand<3, 3, PY, true>), grid, block, 0, ctx->stream, (const float*)dy,
+                           (const float*)w, (const float*)nullptr, (float*)dx, d.n, d.h, d.w, d.ph, d.pw, 0.f, 0,
+                           (int)UOCR_ACT_NONE, 0.f, (const float*)mask.y, mask.act, (float)mask.alpha);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
     if (is_c16_same(d, 1, 16)) {
         constexpr int PY = 4;
         const dim3 grid((d.w + 15) / 16, (d.h + 4 * PY - 1) / (4 * PY), d.n), block(64, 4);
