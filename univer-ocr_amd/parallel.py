@@ -39,19 +39,35 @@ class DataParallel:
         for model in self.models:
             if model.pack is None:
                 raise RuntimeError('data parallel needs initialised models with a ParamPack')
-            dist.broadcast(model.pack.value.t, src=0, group=process_group)   # identical replicas
+            value = model.pack.value.t
+            if value.is_cuda and dist.get_backend(process_group) == 'gloo':
+                host = value.cpu()
+                dist.broadcast(host, src=0, group=process_group)
+                value.copy_(host)
+            else:
+                dist.broadcast(value, src=0, group=process_group)       # identical replicas
             model.grad_sync = self._sync
 
     def _sync(self, model):
         """Called by Model.compute_loss_and_gradients right after backward."""
-        work = dist.all_reduce(model.pack.grad.t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        grad = model.pack.grad.t
+        if grad.is_cuda and dist.get_backend(self.group) == 'gloo':
+            # rehearsal of the N > 1 path on ONE card (several ranks share cuda:0, which RCCL refuses):
+            # stage through the host.  Never used with the nccl backend.
+            host = grad.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            grad.copy_(host)
+            self._finish(model, None)
+            return
+        work = dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if self.overlap and model.defer_grad_sync:
             self._pending[id(model)] = work        # finished later by wait(model)
         else:
             self._finish(model, work)
 
     def _finish(self, model, work):
-        work.wait()                                # orders the compute stream after the collective
+        if work is not None:
+            work.wait()                            # orders the compute stream after the collective
         if mean_type_loss(model):
             grad = model.pack.grad
             if grad.t.is_cuda:
@@ -66,7 +82,7 @@ class DataParallel:
 
     def replicas_in_sync(self, model, tol=0.0):
         """Debug check: every rank holds the same weights."""
-        mine = model.pack.value.t.detach().clone()
+        mine = model.pack.value.t.detach().cpu().clone()
         ref = mine.clone()
         dist.broadcast(ref, src=0, group=self.group)
         diff = (mine - ref).abs().max()
