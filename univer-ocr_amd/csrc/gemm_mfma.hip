@@ -420,9 +420,11 @@ int launch_mfma(uocr_ctx* ctx, const ALoader& A, const BRowMajor& B, const Epilo
     const int bm = ((long)((M + 127) / 128) * ((N + BN - 1) / BN) >= 512) ? 128 : 64;
     const int gm = (M + bm - 1) / bm, gn = (N + BN - 1) / BN;
     int nsplit = 1;
-    if (allow_split && gm * gn < 256 && ntiles >= 8) {
-        nsplit = (512 + gm * gn - 1) / (gm * gn);
-        if (nsplit > ntiles / 4) nsplit = ntiles / 4;
+    // Small GEMMs are latency-bound per block (a depth tile is ~1k MFMA cycles against a 1-2 us global
+    // load round trip), so aim for ~4 resident blocks per CU: split the depth until there are ~1024 blocks
+    if (allow_split && gm * gn < 1024 && ntiles >= 4) {
+        nsplit = (1024 + gm * gn - 1) / (gm * gn);
+        if (nsplit > ntiles / 2) nsplit = ntiles / 2;
         if (nsplit > 32) nsplit = 32;
         const size_t per = (size_t)M * N * sizeof(float);
         if ((size_t)nsplit * per > ws_half(ctx)) nsplit = (int)(ws_half(ctx) / per);
@@ -508,7 +510,7 @@ int uocr_conv_fwd_mfma(uocr_ctx* ctx, const void* x, const void* w, const void* 
     BRowMajor B{(const float*)w, d.cout, K, d.cout, aligned16(w) ? 1 : 0};
     Epilogue ep{(float*)y, d.cout, use_bias ? (const float*)b : nullptr, act, (float)act_alpha, 0, -1, nullptr,
                 nullptr,    UOCR_ACT_NONE, 0.f};
-    return launch_mfma(ctx, A, B, ep, M, d.cout, K, false);
+    return launch_mfma(ctx, A, B, ep, M, d.cout, K, (size_t)M * d.cout * 4 * 8 <= ws_half(ctx));
 }
 
 int uocr_conv_dgrad_mfma(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d,
@@ -524,7 +526,7 @@ int uocr_conv_dgrad_mfma(uocr_ctx* ctx, const void* dy, const void* w, void* dx,
     ep.mask_y = (const float*)mask.y;
     ep.mask_act = mask.act;
     ep.mask_alpha = (float)mask.alpha;
-    return launch_mfma(ctx, A, B, ep, M, d.cin, D, false);
+    return launch_mfma(ctx, A, B, ep, M, d.cin, D, (size_t)M * d.cin * 4 * 8 <= ws_half(ctx));
 }
 
 int uocr_conv_wgrad_mfma(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
