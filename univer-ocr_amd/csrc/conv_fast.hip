@@ -244,6 +244,29 @@ __global__ __launch_bounds__(256) void conv_dgrad_fast(const float* __restrict__
     }
 }
 
+// One-channel row segment seg[j] = row[first + j], j < N, as aligned float4 loads: `first` = 4*a - OFFS
+// with OFFS compile-time, the row start 16-byte aligned and width % 4 == 0, so every float4 is either
+// fully inside or fully outside the row (outside -> fill).  8-11 dword loads at a 16 B lane stride
+// (25 % of each 128-B line per instruction, TA-bound) become 3-4 fully contiguous 16-B loads.
+template <int N, int OFFS>
+__device__ __forceinline__ void load_row_c1(const float* __restrict__ row, int a4, int width, bool row_ok,
+                                            float fill, float (&seg)[N][1]) {
+    constexpr int NV4 = (OFFS + N + 3) / 4;
+    float buf[NV4 * 4];
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+        const int col = a4 + 4 * k;
+        float4 v = *reinterpret_cast<const float4*>(row + min(max(col, 0), width - 4));
+        if (!(row_ok && col >= 0 && col < width)) v = make_float4(fill, fill, fill, fill);
+        buf[4 * k] = v.x;
+        buf[4 * k + 1] = v.y;
+        buf[4 * k + 2] = v.z;
+        buf[4 * k + 3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) seg[j][0] = buf[OFFS + j];
+}
+
 // ---------------------------------------------------------------------------------------------
 // Row-loop kernels for the few-channel (COUT <= 4 / CIN <= 16) convs.  Structure chosen from the ISA:
 //   * the tap-ROW loop (ky) is a real loop (not unrolled), so only one row of weights
@@ -278,13 +301,23 @@ __global__ __launch_bounds__(256) void conv_fwd_px(const float* __restrict__ x, 
         const float* xr = xb + (size_t)min(max(iy, 0), d.h - 1) * d.w * CIN;
         const float* wr = w + ky * (KW * CIN * COUT);
         float xv[NXV][CIN];
+        bool vec_done = false;
+        if constexpr (CIN == 1 && PX == 4) {
+            constexpr int PWC = KW / 2, OFFS = (4 - PWC % 4) % 4;      // "same" padding: ix0 = 4a*SW - PWC
+            if (d.pw == PWC && d.w % 4 == 0) {
+                load_row_c1<NXV, OFFS>(xr, ix0 - OFFS, d.w, row_ok, pad, xv);
+                vec_done = true;
+            }
+        }
+        if (!vec_done) {
 #pragma unroll
-        for (int j = 0; j < NXV; ++j) {
-            const int ix = ix0 + j;
-            load_vec<CIN>(xr + (size_t)min(max(ix, 0), d.w - 1) * CIN, xv[j]);
-            if (!(row_ok && ix >= 0 && ix < d.w)) {
+            for (int j = 0; j < NXV; ++j) {
+                const int ix = ix0 + j;
+                load_vec<CIN>(xr + (size_t)min(max(ix, 0), d.w - 1) * CIN, xv[j]);
+                if (!(row_ok && ix >= 0 && ix < d.w)) {
 #pragma unroll
-                for (int c = 0; c < CIN; ++c) xv[j][c] = pad;
+                    for (int c = 0; c < CIN; ++c) xv[j][c] = pad;
+                }
             }
         }
 #pragma unroll
@@ -297,6 +330,15 @@ __global__ __launch_bounds__(256) void conv_fwd_px(const float* __restrict__ x, 
 #pragma unroll
                     for (int p = 0; p < PX; ++p) acc[p][o] += xv[p * SW + kx][c] * wv;
                 }
+    }
+    if constexpr (COUT == 1 && PX == 4) {
+        if (d.ow % 4 == 0) {          // the 4 pixels of the thread are one aligned float4
+            float out[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) out[p] = act_apply(acc[p][0] + (use_bias ? bias[0] : 0.f), act, alpha);
+            store_vec<4>(y + ((size_t)b * d.oh + oy) * d.ow + ox0, out);
+            return;
+        }
     }
 #pragma unroll
     for (int p = 0; p < PX; ++p) {
@@ -336,13 +378,23 @@ __global__ __launch_bounds__(256) void conv_dgrad_px(const float* __restrict__ d
         const float* gr = gb + (size_t)min(max(gy, 0), d.oh - 1) * d.ow * COUT;
         const float* wr = w + ky * (KW * CIN * COUT);
         float g[NG][COUT];
+        bool vec_done = false;
+        if constexpr (COUT == 1 && PX == 4) {
+            constexpr int PWC = KW / 2, OFFS = (((KW - 1 - PWC) % 4) + 4) % 4;   // gx0 = 4a - (KW-1-PWC)
+            if (d.pw == PWC && d.ow % 4 == 0) {
+                load_row_c1<NG, OFFS>(gr, gx0 - OFFS, d.ow, row_ok, 0.f, g);
+                vec_done = true;
+            }
+        }
+        if (!vec_done) {
 #pragma unroll
-        for (int j = 0; j < NG; ++j) {
-            const int gx = gx0 + j;
-            load_vec<COUT>(gr + (size_t)min(max(gx, 0), d.ow - 1) * COUT, g[j]);
-            if (!(row_ok && gx >= 0 && gx < d.ow)) {
+            for (int j = 0; j < NG; ++j) {
+                const int gx = gx0 + j;
+                load_vec<COUT>(gr + (size_t)min(max(gx, 0), d.ow - 1) * COUT, g[j]);
+                if (!(row_ok && gx >= 0 && gx < d.ow)) {
 #pragma unroll
-                for (int o = 0; o < COUT; ++o) g[j][o] = 0.f;
+                    for (int o = 0; o < COUT; ++o) g[j][o] = 0.f;
+                }
             }
         }
 #pragma unroll
@@ -355,6 +407,15 @@ __global__ __launch_bounds__(256) void conv_dgrad_px(const float* __restrict__ d
 #pragma unroll
                     for (int p = 0; p < PX; ++p) acc[p][c] += g[p + (KW - 1) - kx][o] * wv;
                 }
+    }
+    if constexpr (CIN == 1 && PX == 4) {
+        if (d.w % 4 == 0) {
+            float out[4] = {acc[0][0], acc[1][0], acc[2][0], acc[3][0]};
+            const size_t off = ((size_t)b * d.h + iy) * d.w + ix0;
+            apply_mask<4>(out, mask_y, off, mask_act, mask_alpha);
+            store_vec<4>(dx + off, out);
+            return;
+        }
     }
 #pragma unroll
     for (int p = 0; p < PX; ++p) {
@@ -656,12 +717,14 @@ struct WgradCfg {
     static constexpr int OCG = COUT / COB;              // output-channel groups
 };
 
-template <int KH, int KW, int CIN, int COUT, int SH, int SW, int KYR, int COB, int PY, bool CLAMP>
+template <int KH, int KW, int CIN, int COUT, int SH, int SW, int KYR, int COB, int PX, bool CLAMP>
 __global__ __launch_bounds__(256) void conv_wgrad_fast(const float* __restrict__ x, const float* __restrict__ dy,
                                                        float* __restrict__ partial, FastDims d, float pad,
                                                        int rows_per_block, int nbands) {
+    // a thread visits PX horizontally adjacent output pixels per step: the (PX-1)*SW + KW input vectors
+    // of a tap row are loaded once for all PX*KW (pixel, tap) pairs
     using C = WgradCfg<KH, KW, CIN, COUT, SH, SW, KYR, COB>;
-    constexpr int ROWS = (PY - 1) * SH + KYR;      // input rows feeding PY vertically adjacent outputs
+    constexpr int NXV = (PX - 1) * SW + KW;
     __shared__ float red[4][C::NP];
     const int lane = threadIdx.x, wv = threadIdx.y;
     const int band = blockIdx.x % nbands, b = blockIdx.x / nbands;
@@ -674,13 +737,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast(const float* __restrict__
     for (int a = 0; a < C::NP; ++a) acc[a] = 0.f;
     const float* xb = x + (size_t)b * d.h * d.w * CIN;
     const float* gb = dy + (size_t)b * d.oh * d.ow * COUT + oc0;
-    for (int oy = row0 + wv * PY; oy < row1; oy += 4 * PY) {
-        for (int ox = lane; ox < d.ow; ox += 64) {
-            float g[PY][COB];
+    for (int oy = row0 + wv; oy < row1; oy += 4) {
+        for (int ox0 = lane * PX; ox0 < d.ow; ox0 += 64 * PX) {
+            float g[PX][COB];
 #pragma unroll
-            for (int p = 0; p < PY; ++p) {
-                if (oy + p < row1) {
-                    load_vec<COB>(gb + ((size_t)(oy + p) * d.ow + ox) * COUT, g[p]);
+            for (int p = 0; p < PX; ++p) {
+                if (ox0 + p < d.ow) {
+                    load_vec<COB>(gb + ((size_t)oy * d.ow + ox0 + p) * COUT, g[p]);
                 } else {
 #pragma unroll
                     for (int o = 0; o < COB; ++o) g[p][o] = 0.f;
@@ -690,44 +753,52 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast(const float* __restrict__
                     for (int o = 0; o < COB; ++o) acc[C::NW + o] += g[p][o];
                 }
             }
-            const int iy0 = oy * SH - d.ph + ky0, ix0 = ox * SW - d.pw;
+            const int iy0 = oy * SH - d.ph + ky0, ix0 = ox0 * SW - d.pw;
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const int iy = iy0 + r;
+            for (int kyl = 0; kyl < KYR; ++kyl) {
+                const int iy = iy0 + kyl;
                 const bool row_ok = iy >= 0 && iy < d.h;
                 const int iyc = min(max(iy, 0), d.h - 1);
-#pragma unroll
-                for (int kx = 0; kx < KW; ++kx) {
-                    const int ix = ix0 + kx;
-                    // measured per shape: the clamped unconditional load is 1.3-2x faster for the
-                    // CIN = 4 kernels and 3.5x SLOWER for the CIN = 1 5x5 kernel than the branch
-                    float xv[CIN];
-                    if constexpr (CLAMP) {
-                        load_vec<CIN>(xb + ((size_t)iyc * d.w + min(max(ix, 0), d.w - 1)) * CIN, xv);
-                        if (!(row_ok && ix >= 0 && ix < d.w)) {
-#pragma unroll
-                            for (int c = 0; c < CIN; ++c) xv[c] = pad;
-                        }
-                    } else {
-                        if (row_ok && ix >= 0 && ix < d.w) {
-                            load_vec<CIN>(xb + ((size_t)iy * d.w + ix) * CIN, xv);
-                        } else {
-#pragma unroll
-                            for (int c = 0; c < CIN; ++c) xv[c] = pad;
-                        }
+                float xv[NXV][CIN];
+                bool vec_done = false;
+                if constexpr (CIN == 1 && PX == 4) {
+                    constexpr int PWC = KW / 2, OFFS = (4 - PWC % 4) % 4;
+                    if (d.pw == PWC && d.w % 4 == 0) {
+                        load_row_c1<NXV, OFFS>(xb + (size_t)iyc * d.w, ix0 - OFFS, d.w, row_ok, pad, xv);
+                        vec_done = true;
                     }
+                }
+                if (!vec_done) {
 #pragma unroll
-                    for (int p = 0; p < PY; ++p) {
-                        const int kyl = r - p * SH;      // compile-time after unrolling
-                        if (kyl >= 0 && kyl < KYR) {
+                    for (int j = 0; j < NXV; ++j) {
+                        const int ix = ix0 + j;
+                        // measured per shape: the clamped unconditional load is 1.3-2x faster for the
+                        // CIN = 4 kernels and 3.5x SLOWER for the CIN = 1 5x5 kernel than the branch
+                        if constexpr (CLAMP) {
+                            load_vec<CIN>(xb + ((size_t)iyc * d.w + min(max(ix, 0), d.w - 1)) * CIN, xv[j]);
+                            if (!(row_ok && ix >= 0 && ix < d.w)) {
 #pragma unroll
-                            for (int c = 0; c < CIN; ++c)
+                                for (int c = 0; c < CIN; ++c) xv[j][c] = pad;
+                            }
+                        } else {
+                            if (row_ok && ix >= 0 && ix < d.w) {
+                                load_vec<CIN>(xb + ((size_t)iy * d.w + ix) * CIN, xv[j]);
+                            } else {
 #pragma unroll
-                                for (int o = 0; o < COB; ++o)
-                                    acc[((kyl * KW + kx) * CIN + c) * COB + o] += xv[c] * g[p][o];
+                                for (int c = 0; c < CIN; ++c) xv[j][c] = pad;
+                            }
                         }
                     }
                 }
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+                    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                        for (int o = 0; o < COB; ++o)
+#pragma unroll
+                            for (int p = 0; p < PX; ++p)
+                                acc[((kyl * KW + kx) * CIN + c) * COB + o] += xv[p * SW + kx][c] * g[p][o];
             }
         }
     }
@@ -823,7 +894,7 @@ struct FastConv {
                      double pad, int use_bias, int accumulate) {
         using C = WgradCfg<KH, KW, CIN, COUT, SH, SW, KYR, WCOB>;
         // bands of output rows: ~512 blocks per (tap group, channel group), at least 4 rows each
-        constexpr int RQ = 4 * WPY;       // rows consumed per block iteration
+        constexpr int RQ = 4;             // rows consumed per block iteration (one per wave)
         int rows = (d.n * d.oh + 511) / 512;
         rows = ((rows + RQ - 1) / RQ) * RQ;
         if (rows > d.oh) rows = ((d.oh + RQ - 1) / RQ) * RQ;
@@ -845,17 +916,17 @@ struct FastConv {
     }
 };
 
-// the my_model shapes:  KH KW CIN COUT SH SW | legacy fwd: COB PY | legacy dgrad: PY | wgrad: KYR COB PY |
+// the my_model shapes:  KH KW CIN COUT SH SW | legacy fwd: COB PY | legacy dgrad: PY | wgrad: KYR COB PX |
 //                        row-loop kernels: fwd PX, dgrad PX (0 = use the legacy kernel)
 #define UOCR_FAST_CONVS(X)                                                                         \
     X(3, 3, 1, 16, 1, 1, 4, 2, 4, 3, 16, 1, 0, 4) /* Monochrome conv_1: dgrad re-reads 16-ch dy */ \
     X(3, 3, 16, 1, 1, 1, 1, 4, 1, 1, 1, 1, 4, 2)  /* Monochrome conv_2: fwd/wgrad re-read 16-ch x */ \
-    X(5, 5, 1, 1, 2, 2, 1, 1, 1, 5, 1, 1, 4, 0)   /* Paragraph down_1/2 */                         \
-    X(5, 5, 1, 1, 1, 1, 1, 4, 4, 5, 1, 1, 4, 4)   /* Paragraph up_2, up_1, end */                  \
+    X(5, 5, 1, 1, 2, 2, 1, 1, 1, 5, 1, 4, 4, 0)   /* Paragraph down_1/2 */                         \
+    X(5, 5, 1, 1, 1, 1, 1, 4, 4, 5, 1, 4, 4, 4)   /* Paragraph up_2, up_1, end */                  \
     X(5, 5, 1, 4, 2, 2, 4, 1, 1, 5, 4, 1, 4, 0)   /* Line down_1 */                                \
-    X(5, 5, 4, 4, 2, 2, 4, 2, 1, 1, 4, 1, 4, 0)   /* Line down_2 */                                \
-    X(5, 5, 4, 4, 1, 1, 4, 4, 4, 1, 4, 1, 4, 4)   /* Line up_2, up_1 */                            \
-    X(5, 5, 4, 2, 1, 1, 2, 4, 4, 1, 2, 1, 4, 4)   /* Line end */                                   \
+    X(5, 5, 4, 4, 2, 2, 4, 2, 1, 1, 4, 2, 4, 0)   /* Line down_2 */                                \
+    X(5, 5, 4, 4, 1, 1, 4, 4, 4, 1, 4, 4, 4, 4)   /* Line up_2, up_1 */                            \
+    X(5, 5, 4, 2, 1, 1, 2, 4, 4, 1, 2, 4, 4, 4)   /* Line end */                                   \
     X(5, 3, 1, 64, 2, 1, 4, 1, 1, 5, 8, 1, 0, 0)  /* Char conv_1 */
 
 }  // namespace
