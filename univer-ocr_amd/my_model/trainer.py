@@ -27,7 +27,7 @@ def make_optimizer(name, lr):
 class PageTrainer:
     def __init__(self, batch, height=256, width=512, char_width=64, optimizer='sgd', lr=0.0015, seed=0,
                  nets=('Monochrome', 'Paragraph', 'Line', 'Char'), data_parallel=None, overlap=True,
-                 init='kaiming_normal', fuse=True):
+                 init='kaiming_normal', fuse=True, lanes=True):
         np.random.seed(seed)                        # kaiming_uniform draws from the NumPy global RNG
         self.batch = batch
         self.optimizer = make_optimizer(optimizer, lr)
@@ -41,6 +41,11 @@ class PageTrainer:
         self.models = {n: m for n, m in self.models.items() if n in nets}
         for model in self.models.values():
             model.enable_fusion(fuse)            # conv + LeakyReLU / Sigmoid as one forward kernel
+        # one stream (lane) per net: the nets are independent until the optimizer step
+        self.lanes = None
+        if lanes and CP.has_device() and len(self.models) > 1:
+            rt = CP.runtime()
+            self.lanes = {name: rt.add_lane() for name in self.models}
         self.dp = None
         if data_parallel is None:
             data_parallel = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -84,6 +89,8 @@ class PageTrainer:
     def step(self, context):
         """Train every net once.  Returns {net: {'output_losses': [...], 'regularization_loss': r}}."""
         comps = self.model_system.components
+        if self.lanes is not None:
+            return self._step_lanes(context)
         if self.dp is None or not self.dp.overlap:
             self.model_system.train(context)
             return context['losses']
@@ -95,6 +102,32 @@ class PageTrainer:
             comp._publish()
         for comp in comps:                          # then finish: wait, L2, optimizer
             context['losses'][comp.name] = comp.model.train_finish()
+        return context['losses']
+
+    def _step_lanes(self, context):
+        """Every net on its own stream.  The lanes start after everything already queued on the main
+        stream (the inputs) and the main stream ends the step by waiting for all of them.  With data
+        parallelism each net's all-reduce is issued from its lane right after its backward."""
+        import torch
+        rt = CP.runtime()
+        main = torch.cuda.current_stream()
+        start = torch.cuda.Event()
+        start.record(main)
+        context['losses'] = {}
+        comps = self.model_system.components
+        for comp in comps:
+            with rt.lane(self.lanes[comp.name]) as stream:
+                stream.wait_event(start)
+                comp.selector(context)
+                X, y = next(comp.selector.get())
+                comp.model.train_begin(X, y)
+                comp._publish()
+        for comp in comps:
+            with rt.lane(self.lanes[comp.name]) as stream:
+                context['losses'][comp.name] = comp.model.train_finish()
+                done = torch.cuda.Event()
+                done.record(stream)
+            main.wait_event(done)
         return context['losses']
 
     def forward(self, context):

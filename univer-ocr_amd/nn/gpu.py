@@ -51,6 +51,31 @@ class Runtime:
         self._fn = {}
         self.launches = 0
         self.call('uocr_ctx_set_stream', C.c_void_p(self.stream.cuda_stream))
+        self._lanes = [(self.ctx, self.stream)]      # lane 0 = the main stream
+
+    # -- lanes: extra (context, stream) pairs so independent models run concurrently ---------------
+    def add_lane(self, workspace_mb=64):
+        """A further HIP context of the library with its own stream and workspace.  The four my_model
+        nets are independent, so each trains on its own lane: the latency-bound kernels of the small
+        nets run under the bandwidth-bound kernels of the large ones."""
+        import ctypes as C
+        handle = C.c_void_p()
+        rc = self.lib.uocr_ctx_create(self.device_index, int(workspace_mb) << 20, C.byref(handle))
+        if rc != 0:
+            raise HipError(f'uocr_ctx_create (lane) failed with code {rc}')
+        stream = torch.cuda.Stream(device=self.device)
+        main = self.ctx
+        self.ctx = handle
+        self.call('uocr_ctx_set_stream', C.c_void_p(stream.cuda_stream))
+        self.ctx = main
+        self._lanes.append((handle, stream))
+        return len(self._lanes) - 1
+
+    def lane(self, index):
+        return _Lane(self, index)
+
+    def lane_stream(self, index):
+        return self._lanes[index][1]
 
     def call(self, name, *args):
         fn = self._fn.get(name)
@@ -69,8 +94,12 @@ class Runtime:
 
     def set_option(self, key, value):
         """Kernel selection knobs of the C ABI: 'mfma' (0 never / 1 auto / 2 whenever eligible),
-        'fast_paths' (0 generic kernels only / 1 shape-specialised)."""
-        self.call('uocr_ctx_set_option', key.encode(), int(value))
+        'fast_paths' (0 generic kernels only / 1 shape-specialised).  Applied to every lane."""
+        current = self.ctx
+        for handle, _ in self._lanes:
+            self.ctx = handle
+            self.call('uocr_ctx_set_option', key.encode(), int(value))
+        self.ctx = current
 
     def synchronize(self):
         self.call('uocr_stream_sync')
@@ -81,6 +110,24 @@ class Runtime:
         cus, hbm = C.c_int(), C.c_size_t()
         self.call('uocr_device_info', name, 256, C.byref(cus), C.byref(hbm))
         return {'name': name.value.decode(), 'cu_count': cus.value, 'hbm_bytes': hbm.value}
+
+
+class _Lane:
+    """`with runtime.lane(i):` -- kernels, allocations and copies inside go to lane i's stream."""
+
+    def __init__(self, rt, index):
+        self.rt, self.index = rt, index
+
+    def __enter__(self):
+        self.prev_ctx, self.prev_stream = self.rt.ctx, torch.cuda.current_stream()
+        self.rt.ctx, stream = self.rt._lanes[self.index]
+        torch.cuda.set_stream(stream)
+        return stream
+
+    def __exit__(self, *exc):
+        self.rt.ctx = self.prev_ctx
+        torch.cuda.set_stream(self.prev_stream)
+        return False
 
 
 class DeviceArray:
