@@ -57,7 +57,8 @@ int uocr_ctx_destroy(uocr_ctx* ctx);
 int uocr_ctx_set_stream(uocr_ctx* ctx, void* hip_stream);
 void* uocr_ctx_get_stream(uocr_ctx* ctx);
 /* kernel selection knobs (for parity tests and A/B timing): "mfma" = 0 never / 1 auto / 2 whenever
- * eligible; "fast_paths" = 0 generic kernels only / 1 shape-specialised kernels (default) */
+ * eligible; "fast_paths" = 0 generic kernels only / 1 shape-specialised kernels (default);
+ * "tiled" = 0 / 1 (default) LDS-tiled conv kernels where instantiated */
 int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value);
 int uocr_ctx_reserve_workspace(uocr_ctx* ctx, size_t bytes);   /* synchronises; not capturable */
 const char* uocr_last_error(uocr_ctx* ctx);

@@ -4,6 +4,8 @@
 
 namespace {
 
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 int check_dims(uocr_ctx* ctx, const ConvDims& d) {
     UOCR_REQUIRE(ctx, d.n > 0 && d.h > 0 && d.w > 0 && d.cin > 0 && d.cout > 0);
     UOCR_REQUIRE(ctx, d.kh > 0 && d.kw > 0 && d.sh > 0 && d.sw > 0 && d.ph >= 0 && d.pw >= 0);
@@ -27,6 +29,8 @@ int uocr_conv2d_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, cons
     if (rc) return rc;
     UOCR_REQUIRE(ctx, x && w && y && (b || !use_bias));
     UOCR_REQUIRE(ctx, act >= UOCR_ACT_NONE && act <= UOCR_ACT_SIGMOID);
+    if (uocr_conv_tiled_eligible(ctx, dtype, d) && aligned16(x) && aligned16(y))
+        return uocr_conv_fwd_tiled(ctx, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
     if (uocr_conv_fast_eligible(ctx, dtype, d, x, y, w))
         return uocr_conv_fwd_fast(ctx, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
     if (uocr_conv_mfma_eligible(ctx, dtype, d, 0))

@@ -1,0 +1,132 @@
+// LDS-tiled direct convolution (float32) for the 4-channel, many-tap, stride-1 convs of the Line net
+// (5x5, 4 -> 4 and 4 -> 2 at 128x256 and 256x512; reference shapes my_model/model.py:194-247).
+//
+// One pixel per thread with 25 taps re-reads every input vector 25 times through L1
+// (64 B/clk/CU): the register-tiled kernels of conv_fast.hip were bound by that, at 1-2 TB/s of
+// algorithmic bandwidth.  Here a block of 8 x 32 output pixels stages its (8+KH-1) x (32+KW-1)
+// input window ONCE into LDS as float4 pixels (coalesced 16-B loads, 1.7x halo overhead) and every
+// tap is a ds_read_b128 with consecutive lanes on consecutive 16-B slots (conflict-free,
+// 256 B/clk/CU).  Weights: one tap ROW at a time in SGPRs (the tap-row loop is not unrolled, see
+// conv_fast.hip).  Measured (line.up_1, 32x256x512x4): forward 72 -> 62 us.  The same structure was
+// tried for dx (69 -> 77 us) and dw (117 -> 226 us: a barrier per tile and 5 tap-row blocks re-staging
+// the same rows) and lost to the register-tiled kernels, so only the forward uses it.
+#include "conv_dims.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 32;     // output tile = 256 threads, one pixel each
+
+struct TileDims {
+    int n, h, w, ph, pw;           // same-size stride-1 conv: output (h, w) == input (h, w)
+};
+
+__device__ __forceinline__ float act_apply(float v, int act, float alpha) {
+    switch (act) {
+        case UOCR_ACT_RELU: return v * (v >= 0.f ? 1.f : 0.f);
+        case UOCR_ACT_LEAKY: return v * ((v >= 0.f ? 1.f : 0.f) + alpha * (v < 0.f ? 1.f : 0.f));
+        case UOCR_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void store_c(float* p, const float (&v)[C]) {
+    if constexpr (C == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else if constexpr (C == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+    else p[0] = v[0];
+}
+
+// stage rows [y0, y0+ROWS) x cols [x0, x0+COLS) of a C-channel image (C = 2 or 4) into LDS as float4
+// pixels (C = 2: .z/.w unused); outside the image -> fill
+template <int C, int ROWS, int COLS>
+__device__ __forceinline__ void stage_tile(float4* __restrict__ tile, const float* __restrict__ img, int h, int w,
+                                           int y0, int x0, float fill, int tid) {
+    for (int i = tid; i < ROWS * COLS; i += TH * TW) {
+        const int r = i / COLS, c = i - r * COLS;
+        const int y = y0 + r, x = x0 + c;
+        float4 v = make_float4(fill, fill, fill, fill);
+        if (y >= 0 && y < h && x >= 0 && x < w) {
+            const float* p = img + ((size_t)y * w + x) * C;
+            if constexpr (C == 4) v = *reinterpret_cast<const float4*>(p);
+            else { const float2 t = *reinterpret_cast<const float2*>(p); v.x = t.x; v.y = t.y; }
+        }
+        tile[i] = v;
+    }
+}
+
+// y[p,o] = sum_{ky,kx,c} x[p + (ky,kx) - pad, c] w[ky,kx,c,o] (+ b, activation)
+template <int KH, int KW, int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_tiled_kernel(const float* __restrict__ src, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ dst,
+                                                         TileDims d, float pad, int use_bias, int act, float alpha) {
+    constexpr int SRC = CIN, DST = COUT;
+    constexpr int ROWS = TH + KH - 1, COLS = TW + KW - 1;
+    __shared__ float4 tile[ROWS * COLS];
+    const int tx = threadIdx.x & (TW - 1), ty = threadIdx.x / TW;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, b = blockIdx.z;
+    const int PH = d.ph, PW = d.pw;
+    stage_tile<SRC, ROWS, COLS>(tile, src + (size_t)b * d.h * d.w * SRC, d.h, d.w, y0 - PH, x0 - PW, pad, threadIdx.x);
+    __syncthreads();
+    float acc[DST];
+#pragma unroll
+    for (int i = 0; i < DST; ++i) acc[i] = 0.f;
+#pragma unroll 1
+    for (int r = 0; r < KH; ++r) {
+        const int ky = r;
+        const float* wr = w + ky * (KW * CIN * COUT);
+#pragma unroll
+        for (int q = 0; q < KW; ++q) {
+            const int kx = q;
+            const float4 v4 = tile[(ty + r) * COLS + tx + q];
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) {
+                    const float wv = wr[(kx * CIN + c) * COUT + o];
+                    acc[o] += v[c] * wv;
+                }
+        }
+    }
+    const int ox = x0 + tx, oy = y0 + ty;
+    if (ox >= d.w || oy >= d.h) return;
+    const size_t off = (((size_t)b * d.h + oy) * d.w + ox) * DST;
+    float out[DST];
+#pragma unroll
+    for (int i = 0; i < DST; ++i) {
+        float t = acc[i];
+        if (use_bias) t += bias[i];
+        out[i] = act_apply(t, act, alpha);
+    }
+    store_c<DST>(dst + off, out);
+}
+
+template <int COUT>
+bool shape_ok(const ConvDims& d) {
+    return d.kh == 5 && d.kw == 5 && d.cin == 4 && d.cout == COUT && d.sh == 1 && d.sw == 1 && d.oh == d.h &&
+           d.ow == d.w;
+}
+
+}  // namespace
+
+bool uocr_conv_tiled_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d) {
+    if (dtype != UOCR_F32 || !ctx->opt_fast || ctx->opt_tiled == 0) return false;
+    return shape_ok<4>(d) || shape_ok<2>(d);
+}
+
+int uocr_conv_fwd_tiled(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
+                        double pad_value, int use_bias, int act, double act_alpha) {
+    const TileDims td{d.n, d.h, d.w, d.ph, d.pw};
+    const dim3 grid((d.w + TW - 1) / TW, (d.h + TH - 1) / TH, d.n), block(256);
+    if (d.cout == 4)
+        hipLaunchKernelGGL((conv_tiled_kernel<5, 5, 4, 4>), grid, block, 0, ctx->stream, (const float*)x,
+                           (const float*)w, (const float*)b, (float*)y, td, (float)pad_value, use_bias, act,
+                           (float)act_alpha);
+    else
+        hipLaunchKernelGGL((conv_tiled_kernel<5, 5, 4, 2>), grid, block, 0, ctx->stream, (const float*)x,
+                           (const float*)w, (const float*)b, (float*)y, td, (float)pad_value, use_bias, act,
+                           (float)act_alpha);
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
+}
+

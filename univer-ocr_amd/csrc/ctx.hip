@@ -21,6 +21,7 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->owns_stream = true;
     ctx->opt_mfma = 1;
     ctx->opt_fast = 1;
+    ctx->opt_tiled = 1;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return UOCR_ERR_HIP;
@@ -66,6 +67,7 @@ int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value) {
     UOCR_REQUIRE(ctx, key != nullptr);
     if (!strcmp(key, "mfma")) ctx->opt_mfma = value;
     else if (!strcmp(key, "fast_paths")) ctx->opt_fast = value;
+    else if (!strcmp(key, "tiled")) ctx->opt_tiled = value;
     else UOCR_FAIL(ctx, UOCR_ERR_ARG, "unknown option '%s'", key);
     return UOCR_OK;
 }

@@ -16,6 +16,7 @@ struct uocr_ctx {
     int cu_count;
     int opt_mfma;        // 0 = never, 1 = auto (default), 2 = whenever eligible (tests)
     int opt_fast;        // 0 = generic kernels only, 1 = shape-specialised fast paths (default)
+    int opt_tiled;       // 0 = no LDS-tiled conv kernels, 1 = use them where instantiated (default)
     char err[512];
 };
 
