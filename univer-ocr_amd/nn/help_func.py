@@ -1,27 +1,35 @@
-"""Small argument helpers (reference: nn/help_func.py:4-31, same names and error types)."""
-from collections.abc import Iterable
+"""Argument normalisation shared by the layer constructors.
+
+API of the reference's nn/help_func.py (`make_list_if_not`, `tuplize`) including the exception types
+its callers rely on: ValueError for a negative size, TypeError for anything that is not an int or
+a sequence of exactly `length` ints."""
+import numbers
 
 
 def make_list_if_not(var):
-    return var if isinstance(var, list) else [var]
+    if isinstance(var, list):
+        return var
+    return [var]
+
+
+def _is_int(value):
+    return isinstance(value, numbers.Integral) and not isinstance(value, bool)
 
 
 def tuplize(name, var, length):
-    """int -> (int,)*length; iterable of `length` ints -> tuple.  ValueError for negatives,
-    TypeError for anything else (help_func.py:24-29)."""
-    if isinstance(var, bool):
-        candidate = None
-    elif isinstance(var, int):
-        candidate = (var,) * length
-    elif isinstance(var, Iterable):
-        items = tuple(var)
-        ok = len(items) == length and all(isinstance(v, int) and not isinstance(v, bool) for v in items)
-        candidate = items if ok else None
+    """`3` -> `(3, 3)`, `(5, 3)` -> `(5, 3)` for length 2."""
+    if _is_int(var):
+        values = (int(var),) * length
     else:
-        candidate = None
-    if candidate is not None and any(v < 0 for v in candidate):
+        try:
+            values = tuple(var)
+        except TypeError:
+            values = None
+        if isinstance(var, (str, bytes)) or values is None or len(values) != length or \
+                not all(_is_int(v) for v in values):
+            raise TypeError(f'{name} must be either int or iterable of ints of length {length}, '
+                            f'found {type(var).__name__}')
+        values = tuple(int(v) for v in values)
+    if min(values) < 0:
         raise ValueError(f'{name} cannot be negative, found: {var}')
-    if candidate is None:
-        raise TypeError(f'{name} must be either int or iterable of ints of length {length}, '
-                        f'found {type(var).__name__}')
-    return candidate
+    return values

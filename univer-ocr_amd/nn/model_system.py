@@ -1,52 +1,21 @@
-"""Model system: a list of components run in order over a shared `context` dict
-(reference: nn/model_system.py:1-167, same class names and context keys).
+"""Model system: an ordered list of components that read and write one shared `context` dict.
 
-train/test put per-component losses into context['losses'][name], predict puts the raw prediction
-into context['prediction'][name]; selectors say where a component reads X / y and writes its
-prediction.  The crop/rotate stages between the nets are host code in the reference and plug in
-here unchanged as RawFunctionComponent / WrappedFunctionComponent.
-"""
+Same public names and context conventions as the reference's nn/model_system.py.  A ModelComponent
+runs one model on the arrays its selector picks out of the context, files the losses under
+context['losses'][name] (predict: the raw prediction under context['prediction'][name]) and hands
+the model outputs back to the selector; function components are the reference's host stages (crop,
+rotate, label) and plug in unchanged."""
 
-
-class BaseComponent:
-    def train(self, context):
-        raise NotImplementedError()
-
-    def test(self, context):
-        raise NotImplementedError()
-
-    def predict(self, context):
-        raise NotImplementedError()
+_SLOT_OF_MODE = {'train': 'losses', 'test': 'losses', 'predict': 'prediction'}
 
 
-class RawFunctionComponent(BaseComponent):
-    def __init__(self, func):
-        self.func = func
-
-    def __call__(self, context):
-        self.func(context)
-
-    train = test = predict = __call__
-
-
-class WrappedFunctionComponent(RawFunctionComponent):
-    def __init__(self, name, func, *args_labels, **kwargs_labels):
-        super().__init__(func)
-        self.name, self.args_labels, self.kwargs_labels = name, args_labels, kwargs_labels
-
-    def __call__(self, context):
-        args = [context[label] for label in self.args_labels]
-        kwargs = {key: context[label] for key, label in self.kwargs_labels.items()}
-        context[self.name] = self.func(*args, **kwargs)
-
-    train = test = predict = __call__
-
-
+# ---- selectors: where a component finds X / y and where its prediction goes -----------------------
 class BaseSelector:
     def __init__(self):
         self.context = None
 
     def __call__(self, context):
+        """Bind to the context of the current step."""
         self.context = context
 
     def get(self):
@@ -60,12 +29,17 @@ class BaseSelector:
 
 
 class StringSelector(BaseSelector):
+    """One sample per step, addressed by three context keys."""
+
     def __init__(self, X_label, y_label, pred_label):
-        super().__init__()
-        self.X_label, self.y_label, self.pred_label = X_label, y_label, pred_label
+        BaseSelector.__init__(self)
+        self.X_label = X_label
+        self.y_label = y_label
+        self.pred_label = pred_label
 
     def get(self):
-        yield self.context[self.X_label], self.context[self.y_label]
+        ctx = self.context
+        yield ctx[self.X_label], ctx[self.y_label]
 
     def get_X(self):
         yield self.context[self.X_label]
@@ -75,43 +49,103 @@ class StringSelector(BaseSelector):
 
 
 class IterableSelector(StringSelector):
+    """The context keys hold lists of samples; predictions are collected in a list."""
+
     def get(self):
-        yield from zip(self.context[self.X_label], self.context[self.y_label])
+        ctx = self.context
+        for pair in zip(ctx[self.X_label], ctx[self.y_label]):
+            yield pair
 
     def get_X(self):
-        yield from self.context[self.X_label]
+        for X in self.context[self.X_label]:
+            yield X
 
     def put(self, pred):
-        self.context.setdefault(self.pred_label, []).append(pred)
+        collected = self.context.get(self.pred_label)
+        if collected is None:
+            collected = self.context[self.pred_label] = []
+        collected.append(pred)
+
+
+# ---- components ------------------------------------------------------------------------------------
+class BaseComponent:
+    def train(self, context):
+        raise NotImplementedError()
+
+    def test(self, context):
+        raise NotImplementedError()
+
+    def predict(self, context):
+        raise NotImplementedError()
+
+
+class RawFunctionComponent(BaseComponent):
+    """A host stage: the same `func(context)` in every mode."""
+
+    def __init__(self, func):
+        self.func = func
+
+    def __call__(self, context):
+        self.func(context)
+
+    def train(self, context):
+        self(context)
+
+    def test(self, context):
+        self(context)
+
+    def predict(self, context):
+        self(context)
+
+
+class WrappedFunctionComponent(RawFunctionComponent):
+    """A host stage given as a plain function of context entries; its result is stored under `name`."""
+
+    def __init__(self, name, func, *args_labels, **kwargs_labels):
+        RawFunctionComponent.__init__(self, func)
+        self.name = name
+        self.args_labels = args_labels
+        self.kwargs_labels = kwargs_labels
+
+    def __call__(self, context):
+        positional = [context[label] for label in self.args_labels]
+        named = {key: context[label] for key, label in self.kwargs_labels.items()}
+        context[self.name] = self.func(*positional, **named)
+
+
+def _file_losses(store, name, losses):
+    """First sample of a step creates the entry; further samples extend its lists / add its scalars."""
+    if name not in store:
+        store[name] = losses
+        return
+    entry = store[name]
+    for key in losses:
+        entry[key] += losses[key]
 
 
 class ModelComponent(BaseComponent):
     def __init__(self, name, model, selector, delist_result=False):
-        self.name, self.model, self.selector, self.delist_result = name, model, selector, delist_result
+        self.name = name
+        self.model = model
+        self.selector = selector
+        self.delist_result = delist_result
 
     def _publish(self):
-        result = [self.model.layers_outputs[k] for k in range(self.model.outputs_count)]
-        self.selector.put(result[0] if self.delist_result else result)
+        model = self.model
+        outputs = [model.layers_outputs[index] for index in range(model.outputs_count)]
+        self.selector.put(outputs[0] if self.delist_result else outputs)
 
-    def _accumulate(self, context, losses):
-        seen = context['losses'].get(self.name)
-        if seen is None:
-            context['losses'][self.name] = losses
-        else:
-            for key, value in losses.items():     # lists concatenate, scalars add (model_system.py:109-111)
-                seen[key] += value
+    def _supervised(self, context, step):
+        self.selector(context)
+        for X, y in self.selector.get():
+            _file_losses(context['losses'], self.name, step(X, y))
+            self._publish()
 
     def train(self, context):
-        self.selector(context)
-        for X, y in self.selector.get():
-            self._accumulate(context, self.model.train(X, y))
-            self._publish()
+        self._supervised(context, self.model.train)
 
     def test(self, context):
-        self.selector(context)
-        for X, y in self.selector.get():
-            self._accumulate(context, self.model.test(X, y))
-            self._publish()
+        self._supervised(context, self.model.test)
 
     def predict(self, context):
         self.selector(context)
@@ -126,17 +160,16 @@ class ModelSystem:
         assert all(isinstance(c, BaseComponent) for c in components)
         self.components = components
 
-    def train(self, context):
-        context['losses'] = {}
+    def _each(self, mode, context):
+        context[_SLOT_OF_MODE[mode]] = {}
         for component in self.components:
-            component.train(context)
+            getattr(component, mode)(context)
+
+    def train(self, context):
+        self._each('train', context)
 
     def test(self, context):
-        context['losses'] = {}
-        for component in self.components:
-            component.test(context)
+        self._each('test', context)
 
     def predict(self, context):
-        context['prediction'] = {}
-        for component in self.components:
-            component.predict(context)
+        self._each('predict', context)

@@ -1,82 +1,87 @@
-"""Per-layer timing hooks (reference: nn/progress_tracker.py:5-126, same public names).
+"""Per-layer timing hooks with the public names of the reference's nn/progress_tracker.py
+(`Event`, `BaseProgressTracker`, `ProgressTracker`, `track_method`, `track_function`).
 
-`track_method('forward'/'backward')` wraps every layer call; with the default BaseProgressTracker
-it costs two no-op calls.  Kernels are asynchronous, so wall time per layer is only meaningful with
-`ProgressTracker(sync=True)`, which synchronises the HIP stream at every stop (the reference
-synchronises after every custom kernel anyway: convolutional.py:192,278)."""
-from datetime import datetime
-from functools import wraps
+Every layer's forward/backward is wrapped by `track_method`; with the default (null) tracker that
+is two no-op calls.  Kernels are launched asynchronously, so the wall time of a layer call is only
+meaningful with `ProgressTracker(sync=True)`, which synchronises the HIP stream when an event stops
+(the reference synchronises after every custom kernel anyway: layers/convolutional.py:192,278).
+The summary handed to the handler keeps the reference's dictionary keys (name, done, started,
+stopped, time, counter) because the web UI renders them."""
+import functools
+from collections import defaultdict
+from datetime import datetime, timedelta
+
+_FIELDS = ('name', 'done', 'started', 'stopped', 'time', 'counter')
 
 
 class Event:
+    """Accumulated wall time and call count of one (layer, phase) pair."""
+
     def __init__(self, name):
         self.name = name
         self.reset()
 
     def reset(self):
-        self.done, self.started, self.stopped, self.time, self.counter = False, None, None, None, 0
+        self.done = False
+        self.started = self.stopped = self.time = None
+        self.counter = 0
 
     def start(self):
-        self.done, self.started = False, datetime.now()
+        self.done = False
+        self.started = datetime.now()
 
     def stop(self):
         self.stopped = datetime.now()
-        elapsed = self.stopped - self.started
-        self.time = elapsed if self.time is None else self.time + elapsed
-        self.done = True
+        self.time = (self.time or timedelta(0)) + (self.stopped - self.started)
         self.counter += 1
+        self.done = True
 
     def to_dict(self):
-        return {key: getattr(self, key) for key in ('name', 'done', 'started', 'stopped', 'time', 'counter')}
+        return {field: getattr(self, field) for field in _FIELDS}
 
 
 class BaseProgressTracker:
-    def __init__(self, *args, **kwargs):
-        pass
+    """Null object: accepts every call of the interface and records nothing."""
 
-    def register_layer(self, name):
+    def __init__(self, *args, **kwargs):
         pass
 
     def get_summary(self):
         return {}
 
-    def start_tracking(self, name, event):
-        pass
+    def _ignore(self, *args, **kwargs):
+        return None
 
-    def stop_tracking(self, name, event):
-        pass
-
-    def message(self, message, data=None):
-        pass
-
-    def reset(self):
-        pass
+    register_layer = start_tracking = stop_tracking = message = reset = _ignore
 
 
 class ProgressTracker(BaseProgressTracker):
     def __init__(self, handler=print, sync=False):
-        self.layers = {}
         self.handler = handler
         self.sync = sync
+        self.layers = defaultdict(dict)          # layer name -> {phase: Event}
 
     def register_layer(self, name):
         self.layers[name] = {}
 
     def get_summary(self):
-        return {name: [ev.to_dict() for ev in events.values()] for name, events in self.layers.items()}
+        return {layer: [ev.to_dict() for ev in phases.values()] for layer, phases in self.layers.items()}
+
+    def _event(self, layer, phase):
+        phases = self.layers[layer]
+        if phase not in phases:
+            phases[phase] = Event(phase)
+        return phases[phase]
 
     def start_tracking(self, name, event):
-        events = self.layers.setdefault(name, {})
-        if event not in events:
-            events[event] = Event(event)
-        events[event].start()
+        self._event(name, event).start()
         self.handler(event, self.get_summary())
 
     def stop_tracking(self, name, event):
         if self.sync:
             from .gpu import CP
             CP.runtime().synchronize()
-        self.layers[name][event].stop()
+        self._event(name, event).stop()
         self.handler(event, self.get_summary())
 
     def message(self, message, data=None):
@@ -84,35 +89,36 @@ class ProgressTracker(BaseProgressTracker):
 
     def reset(self):
         self.handler('reset')
-        for events in self.layers.values():
-            for ev in events.values():
+        for phases in self.layers.values():
+            for ev in phases.values():
                 ev.reset()
 
 
+def _tracked(func, tracker_of, name_of, phase):
+    @functools.wraps(func)
+    def wrapper(*args, **kwargs):
+        tracker, name = tracker_of(args), name_of(args)
+        tracker.start_tracking(name, phase)
+        try:
+            return func(*args, **kwargs)
+        finally:
+            tracker.stop_tracking(name, phase)
+    return wrapper
+
+
 def track_method(event):
+    """Decorator for layer methods: uses `self.progress_tracker` and `self.name`."""
     def decorator(func):
-        @wraps(func)
-        def wrapper(self, *args, **kwargs):
-            tracker = self.progress_tracker
-            tracker.start_tracking(self.name, event)
-            result = func(self, *args, **kwargs)
-            tracker.stop_tracking(self.name, event)
-            return result
-        return wrapper
+        return _tracked(func, lambda a: a[0].progress_tracker, lambda a: a[0].name, event)
     return decorator
 
 
 def track_function(name, event, progress_tracker):
+    """Decorator for free functions (the host stages of a model system)."""
     if progress_tracker is None:
         return lambda func: func
     progress_tracker.register_layer(name)
 
     def decorator(func):
-        @wraps(func)
-        def wrapper(*args, **kwargs):
-            progress_tracker.start_tracking(name, event)
-            result = func(*args, **kwargs)
-            progress_tracker.stop_tracking(name, event)
-            return result
-        return wrapper
+        return _tracked(func, lambda a: progress_tracker, lambda a: name, event)
     return decorator
