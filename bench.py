@@ -133,6 +133,9 @@ def main():
     ap.add_argument('--lr', type=float, default=0.0015)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-overlap', action='store_true')
+    ap.add_argument('--solo-replay', action='store_true',
+                    help='after the timed loop replay the dominant launch alone (roofline.solo_*); off by default so '
+                         'that a rocprofv3 trace of this command averages only the in-loop launches')
     ap.add_argument('--h2d', action='store_true',
                     help='also re-upload the batch from pinned host memory every step (PCIe-inclusive rate; '
                          'reported as config.h2d_inclusive, never as value)')
@@ -220,7 +223,7 @@ def main():
     if rank == 0:
         kernel_ms, launches = probe.mean_ms()
         achieved = dominant['bytes'] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        solo_ms = probe.solo_ms()
+        solo_ms = probe.solo_ms() if args.solo_replay else None
         images = args.batch * world * args.steps
         out = {
             'metric': 'document-images/sec (fwd+bwd) on 256x512 synthetic pages' +
