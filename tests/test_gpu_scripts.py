@@ -35,3 +35,23 @@ def test_train_model_curriculum(tmp_path, monkeypatch):
     assert np.array(weights['Monochrome/conv_1']['w']).shape == (3, 3, 1, 16)
     assert np.array(weights['Char/dense_block/dense_1']['w']).shape == (513, 1024)
     assert all(np.isfinite(np.array(v)).all() for layer in weights.values() for v in layer.values())
+
+
+def test_page_feeder_uint8_pipeline_matches_direct_copy():
+    """uint8 upload on the copy stream + device-side conversion == CP.copy of the float layers."""
+    from univer_ocr_amd.my_model.pipeline import PAGE_FEEDS, PageFeeder, to_uint8_layers
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    from univer_ocr_amd.nn import CP
+    CP.use_gpu(0)
+    CP.set_dtype('float32')
+    batches = [to_uint8_layers(make_page_batch(2, 32, 64, 16, seed=s)) for s in (1, 2, 3)]
+    feeder = PageFeeder(batches[0])
+    feeder.stage(batches[0])
+    for i, batch in enumerate(batches):
+        ctx = feeder.context()
+        if i + 1 < len(batches):
+            feeder.stage(batches[i + 1])
+        for label, (tag, scale) in PAGE_FEEDS.items():
+            expect = batch[tag].astype(np.float32) * np.float32(scale)
+            got = CP.asnumpy(ctx[label])
+            assert got.dtype == np.float32 and np.allclose(got, expect, rtol=1e-6, atol=0), label
