@@ -133,6 +133,12 @@ def main():
     ap.add_argument('--lr', type=float, default=0.0015)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-overlap', action='store_true')
+    ap.add_argument('--graphs', action='store_true',
+                    help='replay Paragraph, Line and Char as HIP graphs (PageTrainer(graphs=True)); Monochrome stays eager '
+                         'so that the HIP events around the dominant kernel keep working')
+    ap.add_argument('--skip-input-grads', action='store_true',
+                    help='DIAGNOSTIC: do not compute the gradient w.r.t. the page inputs (unused by training; the '
+                         'reference computes it, and so does the default run)')
     ap.add_argument('--solo-replay', action='store_true',
                     help='after the timed loop replay the dominant launch alone (roofline.solo_*); off by default so '
                          'that a rocprofv3 trace of this command averages only the in-loop launches')
@@ -167,7 +173,8 @@ def main():
     rt = CP.runtime()
 
     trainer = PageTrainer(args.batch, args.height, args.width, args.char_width, args.optimizer, args.lr,
-                          seed=0, overlap=not args.no_overlap)
+                          seed=0, overlap=not args.no_overlap, input_grads=not args.skip_input_grads,
+                          graphs=args.graphs, eager_nets=('Monochrome',))   # probed kernel stays eager
     layers = make_page_batch(args.batch, args.height, args.width, args.char_width, seed=1234 + rank)
     context = trainer.make_context(layers)       # inputs resident in HBM before the timed region
 
@@ -206,6 +213,8 @@ def main():
         feeder.stage(layers_u8)         # start the upload of batch i+1
         return trainer.step(ctx)
 
+    if args.graphs:
+        trainer.capture(context)
     for _ in range(args.warmup):
         losses = one_step()
     barrier()
@@ -230,7 +239,8 @@ def main():
         images = args.batch * world * args.steps
         out = {
             'metric': 'document-images/sec (fwd+bwd) on 256x512 synthetic pages' +
-                      (' [DIAGNOSTIC: PCIe upload of every batch inside the timed region]' if args.h2d else ''),
+                      (' [DIAGNOSTIC: PCIe upload of every batch inside the timed region]' if args.h2d else '') +
+                      (' [DIAGNOSTIC: page-input gradients not computed]' if args.skip_input_grads else ''),
             'value': round(images / elapsed, 2),
             'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -245,7 +255,7 @@ def main():
                 'page': [args.height, args.width], 'optimizer': args.optimizer,
                 'parallelism': f'dp{world}', 'grad_allreduce': 'rccl, 1 flat buffer per net' if world > 1 else None,
                 'final_losses': final,
-                'h2d_inclusive': bool(args.h2d),
+                'h2d_inclusive': bool(args.h2d), 'input_grads': not args.skip_input_grads, 'hip_graphs': bool(args.graphs),
             },
             'roofline': {'bound': 'hbm', 'kernel': dominant['kernel'], 'achieved': round(achieved, 1),
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),

@@ -31,7 +31,7 @@ def _slice(layers, lo, hi, cw):
     return out
 
 
-def _worker(rank, world, port, results):
+def _worker(rank, world, port, results, graphs, steps):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -42,13 +42,15 @@ def _worker(rank, world, port, results):
         from univer_ocr_amd.nn import CP
         CP.use_gpu(0)
         CP.set_dtype('float64')
+        CP.lazy_losses = graphs
         per = BATCH // world
-        trainer = PageTrainer(per, H, W, CW, optimizer='sgd', lr=0.01, seed=5 + rank, overlap=True)
+        trainer = PageTrainer(per, H, W, CW, optimizer='sgd', lr=0.01, seed=5 + rank, overlap=True, graphs=graphs)
         assert trainer.dp is not None
         layers = make_page_batch(BATCH, H, W, CW, seed=77)
         context = trainer.make_context(_slice(layers, rank * per, (rank + 1) * per, CW))
-        for _ in range(2):
+        for _ in range(steps):
             trainer.step(context)
+        assert (trainer._captured is not None) == graphs
         ok = all(trainer.dp.replicas_in_sync(m) for m in trainer.models.values())
         weights = {n: p.value.numpy() for m in trainer.models.values() for n, p in m.params().items()}
         results[rank] = (ok, weights)
@@ -56,13 +58,15 @@ def _worker(rank, world, port, results):
         dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process_on_the_whole_batch():
+@pytest.mark.parametrize('graphs,steps', [(False, 2), (True, 5)])
+def test_two_ranks_equal_one_process_on_the_whole_batch(graphs, steps):
+    """graphs=True: steps 3-5 replay the per-net HIP graphs with the all-reduce issued between them."""
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     with ctx.Manager() as manager:
         results = manager.dict()
-        mp.spawn(_worker, args=(world, port, results), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, results, graphs, steps), nprocs=world, join=True)
         results = dict(results)
     assert results[0][0] and results[1][0], 'replicas diverged'
     for name in results[0][1]:
@@ -77,7 +81,7 @@ def test_two_ranks_equal_one_process_on_the_whole_batch():
     try:
         trainer = PageTrainer(BATCH, H, W, CW, optimizer='sgd', lr=0.01, seed=5, data_parallel=False)
         context = trainer.make_context(make_page_batch(BATCH, H, W, CW, seed=77))
-        for _ in range(2):
+        for _ in range(steps):
             trainer.step(context)
         for model in trainer.models.values():
             for name, p in model.params().items():

@@ -225,3 +225,72 @@ def test_fused_activation_graph_matches_reference(net_name, dt):
     close(np.array(rows), g['sgd/step_losses'], STEP_TOL[dt], 'step_losses')
     for pn, p in model.params().items():
         check_sampled(pn, p.value, g, 'sgd/w3', STEP_TOL[dt])
+
+
+def test_skip_input_grads_leaves_losses_and_updates_unchanged():
+    """Model.skip_input_grads drops only the dX of the first convs: losses and weights after two SGD
+    steps are bit-identical to the default run (which computes dX like models.py:226-230)."""
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    from univer_ocr_amd.my_model.trainer import PageTrainer
+    from univer_ocr_amd.nn import CP
+    CP.use_gpu(0)
+    CP.set_dtype('float32')
+    layers = make_page_batch(2, 32, 64, 16, seed=5)
+    results = []
+    for input_grads in (True, False):
+        trainer = PageTrainer(2, 32, 64, 16, optimizer='sgd', lr=0.01, seed=3, input_grads=input_grads)
+        context = trainer.make_context(layers)
+        for _ in range(2):
+            losses = trainer.step(context)
+        weights = {}
+        for model in trainer.models.values():
+            weights.update(model.get_weights())
+        results.append(({n: [float(v) for v in l['output_losses']] for n, l in losses.items()}, weights))
+        if not input_grads:
+            assert all(m.input_grads == {} for m in trainer.models.values())
+    assert results[0][0] == results[1][0]
+    for name, w in results[0][1].items():
+        assert np.array_equal(np.asarray(w), np.asarray(results[1][1][name])), name
+
+
+def test_graph_replay_matches_eager_steps():
+    """PageTrainer(graphs=True): per-net HIP graphs replayed == the eager multi-stream step, bit for bit
+    (same kernels, same order per stream), including a change of the input batch after capture."""
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    from univer_ocr_amd.my_model.trainer import PageTrainer
+    from univer_ocr_amd.nn import CP
+    CP.use_gpu(0)
+    CP.set_dtype('float32')
+    batches = [make_page_batch(2, 32, 64, 16, seed=s) for s in (5, 6)]
+    results = []
+    lazy = CP.lazy_losses
+    CP.lazy_losses = True
+    try:
+        for graphs in (False, True):
+            trainer = PageTrainer(2, 32, 64, 16, optimizer='adam', lr=0.001, seed=3, graphs=graphs)
+            eager_maker = PageTrainer.make_context.__get__(PageTrainer.__new__(PageTrainer))
+            eager_maker.__self__.graphs = False
+            history = []
+            for i in range(8):                     # steps 0-1 eager, capture at step 2, replay after
+                if i < 5:                          # caller-owned arrays: copied into the graphs' statics
+                    context = eager_maker(batches[i % 2])
+                    keep = context['monochrome_X']
+                else:                              # trainer-owned input buffers, refilled in place
+                    context = trainer.make_context(batches[i % 2])
+                losses = trainer.step(context)
+                if i < 5:
+                    assert np.array_equal(CP.asnumpy(keep), batches[i % 2]['image'].astype(np.float32))
+                history.append({n: [float(v) for v in l['output_losses']] + [float(l['regularization_loss'])]
+                                for n, l in losses.items()})
+            assert (trainer._captured is not None) == graphs
+            weights = {}
+            for model in trainer.models.values():
+                weights.update(model.get_weights())
+            pred = CP.asnumpy(context['monochrome_pred'])
+            results.append((history, weights, pred))
+    finally:
+        CP.lazy_losses = lazy
+    assert results[0][0] == results[1][0]
+    assert np.array_equal(results[0][2], results[1][2])
+    for name, w in results[0][1].items():
+        assert np.array_equal(np.asarray(w), np.asarray(results[1][1][name])), name

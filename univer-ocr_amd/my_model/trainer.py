@@ -27,7 +27,7 @@ def make_optimizer(name, lr):
 class PageTrainer:
     def __init__(self, batch, height=256, width=512, char_width=64, optimizer='sgd', lr=0.0015, seed=0,
                  nets=('Monochrome', 'Paragraph', 'Line', 'Char'), data_parallel=None, overlap=True,
-                 init='kaiming_normal', fuse=True, lanes=True):
+                 init='kaiming_normal', fuse=True, lanes=True, input_grads=True, graphs=False, eager_nets=()):
         np.random.seed(seed)                        # kaiming_uniform draws from the NumPy global RNG
         self.batch = batch
         self.optimizer = make_optimizer(optimizer, lr)
@@ -41,11 +41,19 @@ class PageTrainer:
         self.models = {n: m for n, m in self.models.items() if n in nets}
         for model in self.models.values():
             model.enable_fusion(fuse)            # conv + LeakyReLU / Sigmoid as one forward kernel
+            model.skip_input_grads(not input_grads)   # False: drop the page-input gradient nobody reads
         # one stream (lane) per net: the nets are independent until the optimizer step
         self.lanes = None
         if lanes and CP.has_device() and len(self.models) > 1:
             rt = CP.runtime()
             self.lanes = {name: rt.add_lane() for name in self.models}
+        # HIP graphs: each net's forward+loss+backward and its L2+optimizer tail are captured once and
+        # replayed (two hipGraphLaunch per net and step instead of ~40 launches); needs lanes
+        self.graphs = bool(graphs) and self.lanes is not None
+        self.eager_nets = tuple(eager_nets)          # nets kept out of the graphs (e.g. to time one kernel)
+        self._captured = None
+        self._eager_steps = 0
+        self._input_buffers = {}
         self.dp = None
         if data_parallel is None:
             data_parallel = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -78,6 +86,17 @@ class PageTrainer:
                    'paragraph_X': 'monochrome', 'paragraph_y': 'paragraph',
                    'line_X': 'monochrome', 'line_y': 'line',
                    'char_X': 'char_lines', 'char_y': 'char_labels'}
+        if self.graphs:
+            # graph replay reads fixed addresses: the trainer owns one input buffer per layer tag and
+            # every make_context refills them in place (no device-to-device copy in step())
+            import torch
+            for tag in set(mapping.values()):
+                host = np.ascontiguousarray(layers[tag], dtype=CP.dtype)
+                if tag not in self._input_buffers:
+                    self._input_buffers[tag] = CP.copy(host)
+                else:
+                    self._input_buffers[tag].t.copy_(torch.from_numpy(host), non_blocking=False)
+            return {label: self._input_buffers[tag] for label, tag in mapping.items()}
         cache = {}
         context = {}
         for label, tag in mapping.items():
@@ -109,6 +128,12 @@ class PageTrainer:
         stream (the inputs) and the main stream ends the step by waiting for all of them.  With data
         parallelism each net's all-reduce is issued from its lane right after its backward."""
         import torch
+        if self.graphs:
+            if self._captured is None and self._eager_steps >= 2:     # lazy initialisation is over
+                self._capture(context)
+            if self._captured is not None:
+                return self._step_graphs(context)
+            self._eager_steps += 1
         rt = CP.runtime()
         main = torch.cuda.current_stream()
         start = torch.cuda.Event()
@@ -128,6 +153,118 @@ class PageTrainer:
                 done = torch.cuda.Event()
                 done.record(stream)
             main.wait_event(done)
+        return context['losses']
+
+    # -- HIP-graph replay of the step ----------------------------------------------------------------
+    def _capture(self, context):
+        """Record, per net, graph A = forward + loss + backward and graph B = L2 + optimizer + gradient
+        reset on the net's lane stream.  The gradient all-reduce of data parallelism stays outside the
+        graphs (issued eagerly between A and B).  The device arrays of `context` become the static
+        inputs of the graphs; the loss slots and the published outputs are static outputs."""
+        import torch
+        from ..nn.gpu import DeviceScalar
+        if not CP.lazy_losses:
+            raise RuntimeError('PageTrainer(graphs=True) needs CP.lazy_losses = True: a loss read with float() '
+                               'inside the step is a host sync, which a HIP graph cannot contain')
+        rt = CP.runtime()
+        captured = {}
+        for comp in self.model_system.components:
+            model = comp.model
+            if comp.name in self.eager_nets:
+                continue
+            sync, model.grad_sync = model.grad_sync, None         # collectives are not captured
+            comp.selector(context)
+            labels = (comp.selector.X_label, comp.selector.y_label)
+            X, y = (self._static_input(label, context[label]) for label in labels)
+            entry = {}
+            with rt.lane(self.lanes[comp.name]) as stream:
+                begin = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(begin, stream=stream):
+                    model.train_begin(X, y)
+                    comp._publish()
+                pending = model._pending_losses
+                finish = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(finish, stream=stream):
+                    losses = model.train_finish()
+            for value in pending + [losses['regularization_loss']]:
+                if not isinstance(value, DeviceScalar):
+                    raise RuntimeError('graph capture: a loss was materialised on the host')
+            entry.update(begin=begin, finish=finish, output_losses=[v.t for v in pending],
+                         regularization_loss=losses['regularization_loss'].t,
+                         prediction=context.get(comp.selector.pred_label))
+            model.grad_sync = sync
+            captured[comp.name] = entry
+        self._captured = captured
+        self._events = {comp.name: torch.cuda.Event() for comp in self.model_system.components}
+        self._start = torch.cuda.Event()
+
+    def capture(self, context):
+        """Run the eager steps still needed for lazy initialisation, then record the graphs now (step()
+        would do it on its third call)."""
+        assert self.graphs, 'PageTrainer was built without graphs=True'
+        while self._captured is None:
+            self.step(context)
+        return self
+
+    def _static_input(self, label, array):
+        """The array the graphs read for `label`: the trainer's own input buffer if the caller uses
+        make_context(), otherwise a private clone (a foreign array is never written to)."""
+        if not hasattr(self, '_statics'):
+            self._statics, self._clones = {}, {}
+        if any(array is own for own in self._input_buffers.values()):
+            static = array
+        else:
+            static = self._clones.get(id(array))
+            if static is None:
+                static = self._clones[id(array)] = array.copy()
+        self._statics[label] = static
+        return static
+
+    def _step_graphs(self, context):
+        import torch
+        from ..nn.gpu import DeviceScalar
+        rt = CP.runtime()
+        main = torch.cuda.current_stream()
+        comps = self.model_system.components
+        copied = set()
+        for label, static in self._statics.items():          # new batch -> the graphs' static inputs
+            fresh = context[label]
+            if fresh is not static and (id(fresh), id(static)) not in copied:
+                static.t.copy_(fresh.t, non_blocking=True)
+                copied.add((id(fresh), id(static)))
+        self._start.record(main)
+        for comp in comps:
+            entry = self._captured.get(comp.name)
+            with rt.lane(self.lanes[comp.name]) as stream:
+                stream.wait_event(self._start)
+                if entry is None:                             # eager net
+                    comp.selector(context)
+                    X, y = next(comp.selector.get())
+                    comp.model.train_begin(X, y)
+                    comp._publish()
+                    continue
+                entry['begin'].replay()
+                if comp.model.grad_sync is not None:
+                    comp.model.grad_sync(comp.model)          # RCCL all-reduce of the flat gradient
+        context['losses'] = {}
+        for comp in comps:
+            entry, model = self._captured.get(comp.name), comp.model
+            with rt.lane(self.lanes[comp.name]) as stream:
+                if entry is None:
+                    context['losses'][comp.name] = model.train_finish()
+                else:
+                    if model.grad_sync is not None and model.defer_grad_sync:
+                        model.grad_sync.__self__.wait(model)
+                    entry['finish'].replay()
+                self._events[comp.name].record(stream)
+            main.wait_event(self._events[comp.name])
+            if entry is None:
+                continue
+            if entry['prediction'] is not None:
+                context[comp.selector.pred_label] = entry['prediction']
+            context['losses'][comp.name] = {
+                'output_losses': [DeviceScalar(t) for t in entry['output_losses']],
+                'regularization_loss': DeviceScalar(entry['regularization_loss'])}
         return context['losses']
 
     def forward(self, context):

@@ -60,6 +60,8 @@ class Convolutional2D(BaseLayerGPU):
         X = self._mem[mem_id]
         ops.conv2d_bwd_weight(X, grad, self.w.grad, self.b.grad, self.stride, self.padding, self.padding_value,
                               self.bias, accumulate=True)
+        if not self.needs_input_grad:                 # Model.skip_input_grads: nobody reads dX of this layer
+            return None
         return ops.conv2d_bwd_data(grad, self.w.value, X.shape, self.stride, self.padding)
 
     # conv + following activation as ONE forward kernel (Model.enable_fusion): the pre-activation
@@ -87,7 +89,9 @@ class Convolutional2D(BaseLayerGPU):
         X = self._mem[0]
         ops.conv2d_bwd_weight(X, grad, self.w.grad, self.b.grad, self.stride, self.padding, self.padding_value,
                               self.bias, accumulate=True)
-        if input_activation is None:
+        if not self.needs_input_grad:
+            dx = None
+        elif input_activation is None:
             dx = ops.conv2d_bwd_data(grad, self.w.value, X.shape, self.stride, self.padding)
         else:
             dx = ops.conv2d_bwd_data(grad, self.w.value, X.shape, self.stride, self.padding, x_act=X,

@@ -112,6 +112,7 @@ class BaseLayer:
         self.input_shapes = input_shapes
         self.inputs_count = len(input_shapes) if input_shapes is not None else None
         self.trainable = trainable
+        self.needs_input_grad = True
         self.initializer = initializer
         self.regularizer = regularizer
         self.optimizer = Adam() if optimizer is None else optimizer

@@ -103,6 +103,7 @@ class Model(BaseModel):
         self.loss = SoftmaxCrossEntropy() if loss is None else loss
         self.layers_outputs = {}
         self.input_grads = {}
+        self._skipped_input_grads = False
         self.relations_backward = {}
         self.is_initialized = False
         self._plan = None
@@ -238,9 +239,25 @@ class Model(BaseModel):
                     input_activation=None if in_act is None else self.layers[in_act]))
             else:
                 grads_mem[node] = make_list_if_not(self.layers[node].backward(incoming(node)))
+        if self._skipped_input_grads:
+            self.input_grads = {}
+            return []
         self.input_grads = {key: incoming(key) for key in range(self.inputs_count)
                             if key in self.relations_backward}
         return [self.input_grads[k] for k in range(self.inputs_count)]
+
+    def skip_input_grads(self, on=True):
+        """Training never reads the gradient w.r.t. the model's inputs (the reference computes it in
+        every backward, models.py:226-230, and only gradient_check.py:152 looks at it).  With this on,
+        a Convolutional2D fed directly and only by model inputs skips its dX kernel and
+        `input_grads` stays empty; parameter gradients, losses and updates are unchanged."""
+        from .layers import Convolutional2D
+        firsts = [n for n in self._plan if all(isinstance(s, int) for s in self.relations[n])
+                  and isinstance(self.layers[n], Convolutional2D)]
+        for n in firsts:
+            self.layers[n].needs_input_grad = not on
+        self._skipped_input_grads = bool(on)
+        return self
 
     # -- conv + activation fusion (graph level; reference: none -- every layer is its own pass) -----
     def enable_fusion(self, on=True):
