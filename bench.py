@@ -25,6 +25,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+F32_PEAK_TFLOPS = 157.3        # dense f32 MFMA peak = f32 vector peak on gfx950 (same guide, peak table)
 
 
 class KernelProbe:
@@ -178,15 +179,19 @@ def main():
     layers = make_page_batch(args.batch, args.height, args.width, args.char_width, seed=1234 + rank)
     context = trainer.make_context(layers)       # inputs resident in HBM before the timed region
 
-    # dominant kernel = the single longest launch of the step in the rocprofv3 trace (profiles/):
-    # dx of Monochrome conv_2 (3x3, 16->1) with the LeakyReLU' epilogue of conv_1 folded in.  One launch
-    # reads dy (1 ch) and the activation output (16 ch, the mask) and writes dx (16 ch):
-    # algorithmic bytes = 4 * B*H*W * (1 + 16 + 16) + 4 * 144 (weights)
+    # dominant kernel = the single longest launch of the step in the rocprofv3 trace (profiles/): the fused
+    # backward of the Monochrome block (csrc/conv_pair.hip, entry uocr_conv_pair_bwd).  It recomputes the
+    # 16-channel activation on chip, so it is bound by f32 multiply-adds, not HBM: priced in FLOP/s against
+    # the f32 peak (157.3 TF, matrix = vector rate on gfx950).  ALGORITHMIC flops = the layer-by-layer
+    # algorithm, recompute not counted: conv_2 dw, conv_2 dx, conv_1 dw (+ conv_1 dx when the page-input
+    # gradient is wanted), each 2*9*16 per pixel.
     npix = args.batch * args.height * args.width
-    probe = KernelProbe(rt, 'uocr_conv2d_bwd_data',
-                        lambda a: a[7] == 16 and a[8] == 1 and a[9] == 3 and a[10] == 3)
-    dominant = {'kernel': "conv2d_bwd_data 3x3 16->1 + LeakyReLU' epilogue (Monochrome/conv_2 dx; conv_c16_expand<3,3,2,true>)",
-                'bytes': 4.0 * npix * 33 + 4 * 144}
+    n_convs = 3 if args.skip_input_grads else 4
+    probe = KernelProbe(rt, 'uocr_conv_pair_bwd', lambda a: True)
+    dominant = {'kernel': 'fused backward of conv3x3(1->16)+LeakyReLU+conv3x3(16->1)+Sigmoid (Monochrome; '
+                          'conv_pair_bwd_kernel + its finish kernel)',
+                'flops': 2.0 * 9 * 16 * n_convs * npix,
+                'bytes': 4.0 * npix * (4 if not args.skip_input_grads else 3)}
     traffic = None            # HBM bytes per launch from rocprofv3 PMC passes, when a profile is committed
     tpath = os.path.join(ROOT, 'profiles', 'dominant_kernel_traffic.json')
     if os.path.exists(tpath):
@@ -234,7 +239,7 @@ def main():
 
     if rank == 0:
         kernel_ms, launches = probe.mean_ms()
-        achieved = dominant['bytes'] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        achieved = dominant['flops'] / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
         solo_ms = probe.solo_ms() if args.solo_replay else None
         images = args.batch * world * args.steps
         out = {
@@ -257,14 +262,15 @@ def main():
                 'final_losses': final,
                 'h2d_inclusive': bool(args.h2d), 'input_grads': not args.skip_input_grads, 'hip_graphs': bool(args.graphs),
             },
-            'roofline': {'bound': 'hbm', 'kernel': dominant['kernel'], 'achieved': round(achieved, 1),
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+            'roofline': {'bound': 'mfma', 'kernel': dominant['kernel'], 'achieved': round(achieved, 2),
+                         'peak': F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / F32_PEAK_TFLOPS, 4),
                          'traffic': traffic, 'avg_launch_us': round(kernel_ms * 1e3, 2), 'launches_timed': launches,
+                         'algorithmic_flops_per_launch': dominant['flops'],
                          'algorithmic_bytes_per_launch': dominant['bytes'],
                          # in the timed region the four nets run on four streams, so this launch shares HBM
                          # with other kernels; the same launch replayed alone right after the loop:
                          'solo_launch_us': None if solo_ms is None else round(solo_ms * 1e3, 2),
-                         'solo_achieved': None if not solo_ms else round(dominant['bytes'] / (solo_ms * 1e-3) / 1e9, 1)},
+                         'solo_achieved': None if not solo_ms else round(dominant['flops'] / (solo_ms * 1e-3) / 1e12, 2)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.height, args.width, args.char_width, args.optimizer, args.lr)

@@ -12,7 +12,10 @@ for f in "$SRC"/*.hip; do
   o="$SRC/.obj/$(basename "${f%.hip}").o"
   if [[ ! -f "$o" || "$f" -nt "$o" || "$SRC/uocr_common.h" -nt "$o" || "$ROOT/include/univer_hip.h" -nt "$o" \
         || -n "$(find "$SRC" -name '*.h' -newer "$o" -print -quit)" ]]; then
-    "$HIPCC" "${FLAGS[@]}" -c "$f" -o "$o" &
+    # per-file extra flags: a line "// hipcc-flags: ..." in the source
+    extra=$(sed -n 's|^// hipcc-flags: ||p' "$f" | head -1)
+    # shellcheck disable=SC2086
+    "$HIPCC" "${FLAGS[@]}" $extra -c "$f" -o "$o" &
     pids+=($!)
   fi
 done

@@ -101,6 +101,22 @@ int uocr_conv2d_bwd_weight(uocr_ctx* ctx, int dtype, const void* x, const void* 
                            int ph, int pw, int oh, int ow, double pad_value, int use_bias,
                            int accumulate);
 
+/* The Monochrome block (my_model/model.py:108-135) as one forward and one backward kernel, float32:
+ *   y = act2( conv3x3( LeakyReLU_alpha1( conv3x3(x; w1,b1) ); w2,b2 ) ),  x,y: (n,h,w,1), w1: (3,3,1,16),
+ *   w2: (3,3,16,1), both convs stride 1 / padding 1 (convolutional.py:62-99 twice + layers.py:377-418),
+ *   conv_2's padding value 0.  The 16-channel activation and its gradient are recomputed in registers /
+ *   LDS instead of crossing HBM.  act2 = UOCR_ACT_NONE or UOCR_ACT_SIGMOID.
+ * bwd: dy = gradient w.r.t. y (AFTER act2; the kernel multiplies by act2'(y)); dw/db as
+ *   uocr_conv2d_bwd_weight (accumulate!=0 adds), dx may be NULL (page-input gradient not wanted).
+ * UOCR_ERR_UNSUPPORTED for float64 or cmid != 16: the caller then runs the layers one by one. */
+int uocr_conv_pair_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w1, const void* b1,
+                       const void* w2, const void* b2, void* y, int n, int h, int wd, int cmid,
+                       double pad_value1, int use_bias1, int use_bias2, double alpha1, int act2);
+int uocr_conv_pair_bwd(uocr_ctx* ctx, int dtype, const void* x, const void* y, const void* dy,
+                       const void* w1, const void* b1, const void* w2, void* dw1, void* db1, void* dw2,
+                       void* db2, void* dx, int n, int h, int wd, int cmid, double pad_value1,
+                       int use_bias1, int use_bias2, double alpha1, int act2, int accumulate);
+
 /* ---- MaxPool2D (layers/maxpool.py; the NumPy path :24-90 is the semantics) ---------------- */
 /* y = window max with zero padding; mask (uint8, shape (n, kh*oh, kw*ow, c), window-major) marks
  * every element equal to the max; windows running past the padded extent (ceil_mode) shrink. */

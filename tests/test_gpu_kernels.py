@@ -162,3 +162,87 @@ def test_fast_conv_kernels_against_oracle(case, pad_value, bias, f32):
         check(db, ref_db + 0.25, 2e-5, f'{mode} db')
     # the two kernels must have actually been different code paths yet agree closely
     check(results['fast'][0], CP.asnumpy(results['generic'][0]).astype(np.float64), 1e-5, 'fast vs generic y')
+
+
+PAIR_SHAPES = [(3, 37, 83), (2, 16, 32), (1, 1, 1), (2, 5, 200), (1, 70, 33), (4, 64, 96)]
+
+
+@pytest.mark.parametrize('shape', PAIR_SHAPES)
+@pytest.mark.parametrize('sigmoid,bias,pad1,need_dx', [(True, True, 0.0, True), (False, False, 0.25, True),
+                                                      (True, True, 0.0, False)])
+def test_conv_pair_kernels_against_oracle(shape, sigmoid, bias, pad1, need_dx, f32):
+    """uocr_conv_pair_fwd/bwd (conv3x3 1->16 + LeakyReLU + conv3x3 16->1 [+ Sigmoid] with the 16-channel
+    tensors recomputed on chip) == the oracle run layer by layer: ragged tiles, images smaller than a
+    tile, several row bands per block, both dx variants, padding value of the first conv, no bias."""
+    from univer_ocr_amd.hip import lib as hiplib
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    n, h, w = shape
+    rng = np.random.default_rng(sum(shape))
+    X = rng.standard_normal((n, h, w, 1))
+    w1 = rng.standard_normal((3, 3, 1, 16)) * 0.4
+    b1 = rng.standard_normal(16) * 0.3
+    w2 = rng.standard_normal((3, 3, 16, 1)) * 0.2
+    b2 = rng.standard_normal(1)
+    alpha = 0.01
+    z1 = O.conv2d_fwd(X, w1, b1, 1, 1, pad1, bias)
+    a1 = O.leaky_relu_fwd(z1, alpha)
+    z2 = O.conv2d_fwd(a1, w2, b2, 1, 1, 0.0, bias)
+    ref_y = O.sigmoid_fwd(z2) if sigmoid else z2
+    g = rng.standard_normal(ref_y.shape)
+    gz2 = O.sigmoid_bwd(z2, g) if sigmoid else g
+    ga1, ref_dw2, ref_db2 = O.conv2d_bwd(a1, w2, gz2, 1, 1, 0.0, bias)
+    gz1 = O.leaky_relu_bwd(z1, ga1, alpha)
+    ref_dx, ref_dw1, ref_db1 = O.conv2d_bwd(X, w1, gz1, 1, 1, pad1, bias)
+
+    act2 = hiplib.ACT_SIGMOID if sigmoid else hiplib.ACT_NONE
+    Xd, w1d, b1d, w2d, b2d, gd = (CP.copy(a) for a in (X, w1, b1, w2, b2, g))
+    y = ops.conv_pair_fwd(Xd, w1d, b1d, w2d, b2d, pad1, bias, bias, alpha, act2)
+    check(y, ref_y, 1e-5, 'y')
+    dw1, db1, dw2, db2 = CP.full(w1.shape, 0.5), CP.full(b1.shape, 0.25), CP.full(w2.shape, -0.5), CP.full(b2.shape, 2.0)
+    dx = ops.conv_pair_bwd(Xd, y, gd, w1d, b1d, w2d, dw1, db1, dw2, db2, pad1, bias, bias, alpha, act2,
+                           need_dx=need_dx, accumulate=True)
+    if need_dx:
+        check(dx, ref_dx, 2e-5, 'dx')
+    else:
+        assert dx is None
+    check(dw1, ref_dw1 + 0.5, 2e-5, 'dw1')
+    check(db1, ref_db1 + 0.25, 2e-5, 'db1')
+    check(dw2, ref_dw2 - 0.5, 2e-5, 'dw2')
+    check(db2, ref_db2 + 2.0, 2e-5, 'db2')
+    # accumulate = 0 overwrites
+    ops.conv_pair_bwd(Xd, y, gd, w1d, b1d, w2d, dw1, db1, dw2, db2, pad1, bias, bias, alpha, act2,
+                      need_dx=False, accumulate=False)
+    check(dw1, ref_dw1, 2e-5, 'dw1 overwrite')
+    check(dw2, ref_dw2, 2e-5, 'dw2 overwrite')
+
+
+def test_conv_pair_rejects_what_it_does_not_implement(f32):
+    from univer_ocr_amd.hip.lib import HipError
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    X = CP.copy(np.zeros((1, 8, 8, 1)))
+    w1, b1 = CP.copy(np.zeros((3, 3, 1, 8))), CP.copy(np.zeros(8))
+    w2, b2 = CP.copy(np.zeros((3, 3, 8, 1))), CP.copy(np.zeros(1))
+    with pytest.raises(HipError, match='16 middle channels'):
+        ops.conv_pair_fwd(X, w1, b1, w2, b2)
+
+
+@pytest.mark.parametrize('shape', [(2, 5, 8, 1), (3, 4, 6, 4), (1, 3, 5, 1), (2, 7, 12, 4), (1, 64, 128, 1)])
+def test_upsample2_vector_kernels_are_exact(shape, f32):
+    """2x2 upsampling: the 16-byte-per-thread kernels (1 / 4 channels, row length a multiple of 4 floats)
+    and the generic fallback (third shape) reproduce the oracle bit for bit, forward and backward."""
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    rng = np.random.default_rng(sum(shape))
+    X = rng.standard_normal(shape).astype(np.float32)
+    y = ops.upsample2d_fwd(CP.copy(X), (2, 2))
+    assert np.array_equal(CP.asnumpy(y), O.upsample2d_fwd(X, (2, 2)).astype(np.float32))
+    g = rng.standard_normal(y.shape).astype(np.float32)
+    dx = ops.upsample2d_bwd(CP.copy(g), X.shape, (2, 2))
+    n, h, w, c = shape
+    ref = np.zeros(shape, np.float32)
+    for j in range(2):                       # the reference's accumulation order (upsample.py:27-39)
+        for i in range(2):
+            ref = ref + g[:, j::2, i::2, :]
+    assert np.array_equal(CP.asnumpy(dx), ref)

@@ -63,7 +63,33 @@ def main():
         return ms.value * 1e3 / args.reps
 
     rng = np.random.default_rng(0)
+
+    def pair_rows():
+        # the fused Monochrome block (csrc/conv_pair.hip): FLOPs of the layer-by-layer algorithm
+        # (no recompute counted): fwd 2 convs, bwd dw1 + dw2 + conv_2 dx (+ conv_1 dx)
+        from univer_ocr_amd.hip import lib as hiplib
+        n, h, w = args.batch, 256, 512
+        x = CP.copy(rng.standard_normal((n, h, w, 1)).astype(np.float32))
+        w1 = CP.copy((rng.standard_normal((3, 3, 1, 16)) * 0.3).astype(np.float32))
+        w2 = CP.copy((rng.standard_normal((3, 3, 16, 1)) * 0.1).astype(np.float32))
+        b1, b2 = CP.zeros((16,)), CP.zeros((1,))
+        g = CP.copy(rng.standard_normal((n, h, w, 1)).astype(np.float32))
+        grads = [CP.zeros(w1.shape), CP.zeros((16,)), CP.zeros(w2.shape), CP.zeros((1,))]
+        sig = hiplib.ACT_SIGMOID
+        y = ops.conv_pair_fwd(x, w1, b1, w2, b2, act2=sig)
+        px, conv = n * h * w, 2.0 * 9 * 16
+        for op, fn, nbytes, flop in [
+                ('fwd', lambda: ops.conv_pair_fwd(x, w1, b1, w2, b2, act2=sig), 8 * px, 2 * conv * px),
+                ('bwd+dx', lambda: ops.conv_pair_bwd(x, y, g, w1, b1, w2, *grads, act2=sig), 16 * px, 4 * conv * px),
+                ('bwd', lambda: ops.conv_pair_bwd(x, y, g, w1, b1, w2, *grads, act2=sig, need_dx=False), 12 * px,
+                 3 * conv * px)]:
+            us = timed(fn)
+            print(f'{"mono.pair (fused)":18s} {op:6s} {us:9.1f} {nbytes / 1e6:8.1f} {nbytes / us / 1e3:8.0f} '
+                  f'{flop / 1e9:8.2f} {flop / us / 1e6:7.2f}')
+
     print(f'{"layer":18s} {"op":6s} {"us":>9s} {"MB":>8s} {"GB/s":>8s} {"GFLOP":>8s} {"TF/s":>7s}')
+    if args.filter in 'mono.pair (fused)':
+        pair_rows()
     for name, h, w, cin, cout, ks, st, pd in LAYERS:
         if args.filter not in name:
             continue

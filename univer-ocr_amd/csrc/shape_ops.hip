@@ -149,6 +149,64 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
     }
 }
 
+// 2x2 nearest upsampling of the my_model decoders (float32, 1 or 4 channels): one thread per 16 B of input
+// -- 4 pixels of a 1-channel row or one 4-channel pixel -- instead of one thread (and a 64-bit div/mod
+// chain) per output element.  `quads` = n*h*w*c/4.
+template <int CH>
+__global__ __launch_bounds__(256) void upsample2_fwd_vec(const float4* __restrict__ x, float4* __restrict__ y,
+                                                         size_t quads, int h, int row_quads) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < quads;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = idx / row_quads;              // b*h + iy
+        const int k = (int)(idx - row * row_quads);
+        const float4 v = x[idx];
+        float4 lo, hi;
+        if constexpr (CH == 4) {
+            lo = v;
+            hi = v;
+        } else {
+            lo = make_float4(v.x, v.x, v.y, v.y);
+            hi = make_float4(v.z, v.z, v.w, v.w);
+        }
+        float4* out = y + (row * 2) * (size_t)(2 * row_quads) + 2 * k;     // output row 2*(b*h + iy)
+        out[0] = lo;
+        out[1] = hi;
+        out[2 * row_quads] = lo;
+        out[2 * row_quads + 1] = hi;
+    }
+}
+
+// same summation order as upsample_bwd_kernel: ((dy00 + dy01) + dy10) + dy11 starting from 0
+template <int CH>
+__global__ __launch_bounds__(256) void upsample2_bwd_vec(const float4* __restrict__ dy, float4* __restrict__ dx,
+                                                         size_t quads, int h, int row_quads) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < quads;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = idx / row_quads;
+        const int k = (int)(idx - row * row_quads);
+        const float4* in = dy + (row * 2) * (size_t)(2 * row_quads) + 2 * k;
+        const float4 a0 = in[0], a1 = in[1], b0 = in[2 * row_quads], b1 = in[2 * row_quads + 1];
+        float4 r;
+        if constexpr (CH == 4) {
+            r.x = ((0.f + a0.x) + a1.x + b0.x) + b1.x;
+            r.y = ((0.f + a0.y) + a1.y + b0.y) + b1.y;
+            r.z = ((0.f + a0.z) + a1.z + b0.z) + b1.z;
+            r.w = ((0.f + a0.w) + a1.w + b0.w) + b1.w;
+        } else {
+            r.x = ((0.f + a0.x) + a0.y + b0.x) + b0.y;
+            r.y = ((0.f + a0.z) + a0.w + b0.z) + b0.w;
+            r.z = ((0.f + a1.x) + a1.y + b1.x) + b1.y;
+            r.w = ((0.f + a1.z) + a1.w + b1.z) + b1.w;
+        }
+        dx[idx] = r;
+    }
+}
+
+bool upsample2_vec_ok(int dtype, const void* a, const void* b, int wd, int c, int sy, int sx) {
+    return dtype == UOCR_F32 && sy == 2 && sx == 2 && (c == 1 || c == 4) && (wd * c) % 4 == 0 &&
+           ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0;
+}
+
 // y[(b*w + col), r, j, c] = xpad[b, r, col + j, c], xpad = x shifted right by width/2 inside a
 // zero row of length w + width (convolutional.py:335-349)
 template <typename T>
@@ -251,6 +309,18 @@ int uocr_upsample2d_fwd(uocr_ctx* ctx, int dtype, const void* x, void* y, int n,
     UOCR_CHECK_CTX(ctx);
     UOCR_REQUIRE(ctx, x && y && n > 0 && h > 0 && wd > 0 && c > 0 && sy > 0 && sx > 0);
     const size_t total = (size_t)n * h * sy * wd * sx * c;
+    if (upsample2_vec_ok(dtype, x, y, wd, c, sy, sx)) {
+        const size_t quads = (size_t)n * h * wd * c / 4;
+        const dim3 grid(uocr_blocks_for(quads, 256, UOCR_MAX_GRID * 4));
+        if (c == 4)
+            hipLaunchKernelGGL((upsample2_fwd_vec<4>), grid, dim3(256), 0, ctx->stream, (const float4*)x, (float4*)y,
+                               quads, h, wd * c / 4);
+        else
+            hipLaunchKernelGGL((upsample2_fwd_vec<1>), grid, dim3(256), 0, ctx->stream, (const float4*)x, (float4*)y,
+                               quads, h, wd * c / 4);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
     UOCR_DISPATCH(ctx, dtype, {
         hipLaunchKernelGGL((upsample_fwd_kernel<T>), dim3(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4)), dim3(256),
                            0, ctx->stream, (const T*)x, (T*)y, n, h, wd, c, sy, sx);
@@ -264,6 +334,18 @@ int uocr_upsample2d_bwd(uocr_ctx* ctx, int dtype, const void* dy, void* dx, int 
     UOCR_CHECK_CTX(ctx);
     UOCR_REQUIRE(ctx, dy && dx && n > 0 && h > 0 && wd > 0 && c > 0 && sy > 0 && sx > 0);
     const size_t total = (size_t)n * h * wd * c;
+    if (upsample2_vec_ok(dtype, dy, dx, wd, c, sy, sx)) {
+        const size_t quads = total / 4;
+        const dim3 grid(uocr_blocks_for(quads, 256, UOCR_MAX_GRID * 4));
+        if (c == 4)
+            hipLaunchKernelGGL((upsample2_bwd_vec<4>), grid, dim3(256), 0, ctx->stream, (const float4*)dy, (float4*)dx,
+                               quads, h, wd * c / 4);
+        else
+            hipLaunchKernelGGL((upsample2_bwd_vec<1>), grid, dim3(256), 0, ctx->stream, (const float4*)dy, (float4*)dx,
+                               quads, h, wd * c / 4);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
     UOCR_DISPATCH(ctx, dtype, {
         hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4)), dim3(256),
                            0, ctx->stream, (const T*)dy, (T*)dx, n, h, wd, c, sy, sx);

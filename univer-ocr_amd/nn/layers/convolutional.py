@@ -100,6 +100,32 @@ class Convolutional2D(BaseLayerGPU):
         self.clear_memory()
         return [dx]
 
+    # this conv as the SECOND of conv3x3(1->16)+LeakyReLU+conv3x3(16->1)[+Sigmoid]: one kernel each way
+    # (Model._find_pairs; csrc/conv_pair.hip); `first` is the 1->16 conv whose output is never stored
+    @track_method('forward')
+    def forward_pair(self, X, first, activation, out_activation):
+        X = ops.as_device(X)
+        first._mem[0] = X
+        y = ops.conv_pair_fwd(X, first.w.value, first.b.value, self.w.value, self.b.value, first.padding_value,
+                              first.bias, self.bias, activation.alpha,
+                              ops.ACT_CODES[None if out_activation is None else out_activation.kind])
+        self._fused_out = y
+        return y
+
+    @track_method('backward')
+    def backward_pair(self, grads, first, activation, out_activation):
+        grad = ops.as_device(make_list_if_not(grads)[0])
+        X = first._mem[0]
+        dx = ops.conv_pair_bwd(X, self._fused_out, grad, first.w.value, first.b.value, self.w.value,
+                               first.w.grad, first.b.grad, self.w.grad, self.b.grad, first.padding_value,
+                               first.bias, self.bias, activation.alpha,
+                               ops.ACT_CODES[None if out_activation is None else out_activation.kind],
+                               need_dx=first.needs_input_grad, accumulate=True)
+        self._fused_out = None
+        first.clear_memory()
+        self.clear_memory()
+        return dx
+
     def get_output_shapes(self, input_shapes):
         batch, height, width, _ = make_list_if_not(input_shapes)[0]
         oh, ow = ops.conv_out_hw(height, width, self.kernel_size, self.stride, self.padding)

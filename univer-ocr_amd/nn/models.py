@@ -194,9 +194,21 @@ class Model(BaseModel):
         self.clear_param_grads()                      # models.py:188 (per layer there, once here)
         outputs = {}
         fused_conv, fused_act = self._fusion_maps()
+        pairs = self._active_pairs(inputs)
+        pair_first = {first: second for second, (first, _, _) in pairs.items()}
         for node in self._plan:
+            if node in pair_first:                    # computed inside the pair kernel of its consumer
+                outputs[node] = None
+                continue
             if node in fused_act:                     # activation absorbed into its producing conv
                 outputs[node] = outputs[fused_act[node]]
+                continue
+            if node in pairs:
+                first, act_a, act_b = pairs[node]
+                src = self.relations[first][0]
+                x = inputs[src] if isinstance(src, int) else outputs[src]
+                outputs[node] = self.layers[node].forward_pair(
+                    x, self.layers[first], self.layers[act_a], None if act_b is None else self.layers[act_b])
                 continue
             args = [inputs[s] if isinstance(s, int) else outputs[s] for s in self.relations[node]]
             if node in fused_conv:
@@ -208,7 +220,15 @@ class Model(BaseModel):
             src = self.relations[k][0]
             outputs[k] = inputs[src] if isinstance(src, int) else outputs[src]
         self.layers_outputs = outputs
+        self._pairs_used = pairs
         return [outputs[k] for k in range(self.outputs_count)]
+
+    def _active_pairs(self, inputs):
+        """The pair kernels exist in float32 only; other dtypes run the layers one by one."""
+        pairs = getattr(self, '_pairs', {})
+        if pairs and all(self.layers[n].w.value.dtype == np.float32 for n in pairs):
+            return pairs
+        return {}
 
     @track_method('backward')
     def backward(self, grads):
@@ -225,10 +245,21 @@ class Model(BaseModel):
             return total
 
         fused_conv, fused_act = self._fusion_maps()
+        pairs = getattr(self, '_pairs_used', {})
+        pair_first = {first: second for second, (first, _, _) in pairs.items()}
         for node in reversed(self._plan):
             if node not in self.relations_backward:
                 continue
-            if node in fused_act:                     # its gradient is applied inside a conv's backward
+            if node in pairs:                         # dW of both convs and dX of the first in one kernel
+                first, act_a, act_b = pairs[node]
+                dx = self.layers[node].backward_pair(
+                    incoming(node), self.layers[first], self.layers[act_a],
+                    None if act_b is None else self.layers[act_b])
+                grads_mem[node] = [None]
+                grads_mem[first] = [dx]
+            elif node in pair_first or (node in fused_act and fused_act[node] in pair_first):
+                grads_mem.setdefault(node, [None])
+            elif node in fused_act:                   # its gradient is applied inside a conv's backward
                 grads_mem[node] = [incoming(node)]
             elif node in fused_conv or node in self._fusion[2]:
                 act = self.layers[fused_conv[node]] if node in fused_conv else None
@@ -260,18 +291,20 @@ class Model(BaseModel):
         return self
 
     # -- conv + activation fusion (graph level; reference: none -- every layer is its own pass) -----
-    def enable_fusion(self, on=True):
+    def enable_fusion(self, on=True, pairs=True):
         """Run every Convolutional2D whose ONLY consumer is a LeakyRelu(alpha > 0) / Sigmoid as one
         kernel with the activation in the epilogue.  Results are the same tensors the unfused graph
         produces for the activation layers; the conv's pre-activation output is not materialised
         (layers_outputs[conv] then aliases the activation output)."""
         self.fuse_activations = bool(on)
+        self.fuse_pairs = bool(pairs)        # also run conv(1->16)+LeakyReLU+conv(16->1) blocks as one kernel
         self._fusion = None
         return self
 
     def _fusion_maps(self):
         if not getattr(self, 'fuse_activations', False):
             self._fusion = ({}, {}, {}, set())
+            self._pairs = {}
             return {}, {}
         if self._fusion is None:
             from .layers import Convolutional2D, LeakyRelu, Sigmoid
@@ -303,7 +336,30 @@ class Model(BaseModel):
                     input_of[dst] = act_node
                     folded.add(act_node)
             self._fusion = (fused_conv, fused_act, input_of, folded)
+            self._pairs = self._find_pairs(fused_conv, input_of) if getattr(self, 'fuse_pairs', True) else {}
         return self._fusion[0], self._fusion[1]
+
+    def _find_pairs(self, fused_conv, input_of):
+        """conv3x3(1->16, pad 1) + LeakyReLU feeding only conv3x3(16->1, pad 1) [+ Sigmoid] -- the
+        Monochrome block (my_model/model.py:108-135) -- runs as ONE forward and ONE backward kernel
+        (csrc/conv_pair.hip) that never writes the 16-channel activation or its gradient to HBM.
+        Returns {second conv: (first conv, its LeakyReLU, the second conv's fused activation or None)}."""
+        from .layers import LeakyRelu, Sigmoid
+        pairs = {}
+        for conv_b, act_a in input_of.items():
+            conv_a = self._fusion[1][act_a]
+            a, b, act = self.layers[conv_a], self.layers[conv_b], self.layers[act_a]
+            if not isinstance(act, LeakyRelu):
+                continue
+            same = all(l.kernel_size == (3, 3) and l.stride == (1, 1) and l.padding == (1, 1) for l in (a, b))
+            if not (same and (a.in_channels, a.out_channels, b.in_channels, b.out_channels) == (1, 16, 16, 1)
+                    and b.padding_value == 0):
+                continue
+            act_b = fused_conv.get(conv_b)
+            if act_b is not None and not isinstance(self.layers[act_b], Sigmoid):
+                continue
+            pairs[conv_b] = (conv_a, act_a, act_b)
+        return pairs
 
     def _loss_func(self, key):
         return self.loss[key] if isinstance(self.loss, list) else self.loss

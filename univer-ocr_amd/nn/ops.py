@@ -85,6 +85,27 @@ def conv2d_bwd_weight(x, dy, dw, db, stride, padding, pad_value=0.0, bias=True, 
                int(bool(bias)), int(bool(accumulate)))
 
 
+def conv_pair_fwd(x, w1, b1, w2, b2, pad_value1=0.0, bias1=True, bias2=True, alpha=0.01, act2=hiplib.ACT_NONE):
+    """conv3x3(1->16) + LeakyReLU + conv3x3(16->1) [+ Sigmoid] as one kernel (float32, see univer_hip.h)."""
+    n, h, wd, _ = x.shape
+    code = _same_dtype(x, w1, b1, w2, b2)
+    y = CP.empty((n, h, wd, 1), x.dtype)
+    _rt().call('uocr_conv_pair_fwd', code, x.ptr, w1.ptr, b1.ptr, w2.ptr, b2.ptr, y.ptr, n, h, wd, w1.shape[3],
+               float(pad_value1), int(bool(bias1)), int(bool(bias2)), float(alpha), int(act2))
+    return y
+
+
+def conv_pair_bwd(x, y, dy, w1, b1, w2, dw1, db1, dw2, db2, pad_value1=0.0, bias1=True, bias2=True, alpha=0.01,
+                  act2=hiplib.ACT_NONE, need_dx=True, accumulate=True):
+    n, h, wd, _ = x.shape
+    code = _same_dtype(x, y, dy, w1, b1, w2, dw1, db1, dw2, db2)
+    dx = CP.empty(x.shape, x.dtype) if need_dx else None
+    _rt().call('uocr_conv_pair_bwd', code, x.ptr, y.ptr, dy.ptr, w1.ptr, b1.ptr, w2.ptr, dw1.ptr, db1.ptr, dw2.ptr,
+               db2.ptr, dx.ptr if need_dx else None, n, h, wd, w1.shape[3], float(pad_value1), int(bool(bias1)),
+               int(bool(bias2)), float(alpha), int(act2), int(bool(accumulate)))
+    return dx
+
+
 # ---- MaxPool2D ------------------------------------------------------------------------------------
 def pool_out_hw(h, w, ks, stride, padding, ceil_mode):
     """maxpool.py:204-216."""
