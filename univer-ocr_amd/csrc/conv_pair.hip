@@ -4,113 +4,97 @@
 // nn/layers/layers.py:377-418).
 //
 // Run layer by layer the 16-channel activation a1 (268 MB at 32x256x512) is written once and read three
-// times per train step (conv_2 forward, conv_2 dx + LeakyReLU', conv_2 dw) and its gradient (another
-// 268 MB) is written once and read once: 1.6 GB of the step's HBM traffic for 34 MB of real input and
-// output.  a1 costs 9 FMAs per channel to recompute from the 1-channel input, so neither tensor is
-// materialised here:
-//   forward : a block recomputes a1 on its 16x32 tile (+1 halo) into LDS and applies conv_2 from LDS.
-//   backward: per position q the lane recomputes a1[q], gathers g = dy * act2'(y) through the 3x3 window
-//             ONCE for both  dw2[t,c] += a1[q,c] g[q-t+1]  and  d_a1[q,c] = lrelu'(a1) sum_t w2[t,c] g[q-t+1],
-//             then  dw1[s,c] += x[q+s-1] d_a1[q,c],  db1 += d_a1,  db2 += g[q];
-//             dx (optional) in scatter form: u[q,s] = sum_c w1[s,c] d_a1[q,c] goes to LDS (9 floats per
-//             position instead of 16 channels x 9 reads), dx[p] = sum_s u[p-s+1, s].
-// Lane layout as in the c16 kernels of conv_fast.hip: 4 adjacent lanes share a position, each owns 4 of
-// the 16 channels (weights in VGPRs, partial sums combined with two quad shuffles).
-// HBM traffic per image pixel: forward 8 B, backward 12-16 B; the kernels are FMA-bound
-// (forward ~320, backward ~900 lane-FMAs per pixel).
-//
-// hipcc-flags: -fno-slp-vectorize
-// (gfx950 SIMDs are 32 lanes wide: v_fma_f32 issues in 2 cycles and v_pk_fma_f32 is no faster than the two
-// FMAs it replaces, while the SLP vectoriser's packing adds v_pk_mov / v_mov traffic to feed it)
+// times per train step and its gradient (another 268 MB) is written once and read once: 1.6 GB of HBM
+// traffic for 34 MB of real input and output.  Here neither tensor leaves the chip: a1 is recomputed from
+// the 1-channel input where it is needed, and every 16-channel contraction runs on the matrix cores as a
+// v_mfma_f32_16x16x4_f32 (exact f32 FMA chains) over groups of 16 positions (16 consecutive columns of a
+// row of the block's 16 x 32 region):
+//   forward   Z[ch,pos]   = W1^T[ch,tap] Xcol[tap,pos]        3 MFMAs (9 taps padded to 12)
+//             P[pos,tap]  = A1[pos,ch] W2^T[ch,tap]           4 MFMAs; y[p] = b2 + sum_t P[p+t-1, t] (LDS gather)
+//   backward  Z^T[pos,ch], S^T[pos,ch] = Gcol^T[pos,tap] W2[tap,ch]            3 + 3   (g = dy * act2'(y))
+//             d = S * lrelu'(Z)  (d_a1),  a = lrelu(Z)                          elementwise on the 4+4 results
+//             dW2^T[tap,ch] += Gshift[tap,pos] A[pos,ch],  dW1^T[tap,ch] += Xshift[tap,pos] D[pos,ch]   4 + 4
+//             U[pos,tap] = D[pos,ch] W1^T[ch,tap]  (dx only; D transposed through LDS)                  4
+//             dx[p] = sum_s U[p-s+1, s]  (LDS gather)
+// Operand trick: the K index of an MFMA may be permuted freely, so the 4 result registers of one MFMA
+// (rows 4*(lane/16)+i) are fed straight back as the A or B operand of chunk i of the next one.
+// The f32 MFMA rate equals the f32 vector rate (157 TF), but one MFMA replaces 16 v_fma plus their
+// operand moves, and it runs beside the VALU work (masks, LDS addressing): the quad-lane VALU version of
+// these kernels was issue-bound at 4 cycles per vector instruction (97 / 241 us; this one: see DESIGN.md).
 #include "uocr_common.h"
 
 namespace {
 
-constexpr int TH = 16, TW = 30;            // tile of positions owned by a block iteration
-constexpr int XH = TH + 4, XW = TW + 4;    // x / g tiles in LDS: halo 2
-constexpr int AH = TH + 2, AW = TW + 2;    // a1 / u region: halo 1 -- 18 x 32: one column per quad of a half block
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int RH = 16, RW = 32;            // region of positions one tile iteration computes (a1 / d_a1)
+constexpr int XH = RH + 2, XW = RW + 2;    // x / g tiles in LDS: region + halo 1
 constexpr int C = 16;
-constexpr int NA = 36 + 36 + 4 + 1;        // per-lane accumulators of the backward: dw1, dw2, db1, db2
+constexpr int NA = 36 + 36 + 4 + 1;        // layout of a partial row: dw1[tap*4+j], dw2, db1[j], db2 per channel quad
 constexpr int NPF = (XH * XW + 255) / 256; // x / g tile elements staged per thread
+constexpr int TS = 20;                     // row stride of the per-wave transpose scratch
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_move(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-
-// sum over the 4 lanes of a quad with two DPP quad_perm moves (VALU only; __shfl_xor would be two
-// dependent ds_bpermute round trips through LDS)
-__device__ __forceinline__ float quad_sum(float v) {
-    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
-    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
-    return v;
-}
-
-// sum over the 4 lanes {l, l+4, l+8, l+12} of a 16-lane row (same channel quad q = l & 3)
-__device__ __forceinline__ float row_sum_q(float v) {
-    v += dpp_move<0x124>(v);     // row_ror:4
-    v += dpp_move<0x128>(v);     // row_ror:8
-    return v;
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
 __device__ __forceinline__ float out_act(float v, int act) {
     return act == UOCR_ACT_SIGMOID ? 1.f / (1.f + expf(-v)) : v;
 }
 
-// 4 channels [q*4, q*4+4) of every tap of a (3,3,1,16) or (3,3,16,1) weight tensor: flat [tap*16 + ch]
-__device__ __forceinline__ void load_taps(float (&dst)[9][4], const float* __restrict__ w, int q) {
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const float4 v = *reinterpret_cast<const float4*>(w + t * C + q * 4);
-        dst[t][0] = v.x;
-        dst[t][1] = v.y;
-        dst[t][2] = v.z;
-        dst[t][3] = v.w;
-    }
-}
-
-// the x (or dy, y) values of the XH x XW tile at (y0-2, x0-2) this thread stages: clamped loads, `in` mask
+// the elements of the XH x XW tile with origin (ys, xs0) this thread stages: clamped offsets + in-image mask
 struct Stage {
     size_t off[NPF];
     bool in[NPF];
-    __device__ __forceinline__ void locate(int tid, int y0, int x0, int h, int wd) {
+    __device__ __forceinline__ void locate(int tid, int ys, int xs0, int h, int wd) {
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             const int i = tid + k * 256;
             const int r = i / XW, c = i - r * XW;
-            const int gy = y0 - 2 + r, gx = x0 - 2 + c;
+            const int gy = ys + r, gx = xs0 + c;
             in[k] = i < XH * XW && gy >= 0 && gy < h && gx >= 0 && gx < wd;
             off[k] = (size_t)min(max(gy, 0), h - 1) * wd + min(max(gx, 0), wd - 1);
         }
     }
 };
 
-// Block = column strip of TW outputs x rows [band*rows_per_block, +rows_per_block) of image blockIdx.z,
-// walked tile by tile; the next tile's x is in flight (registers) while the current one is computed.
+// Block = column strip of TW outputs x rows [band*rows_per_block, +rows_per_block) of image blockIdx.z, walked
+// tile by tile (TH x TW = 14 x 30 outputs need a1 on the 16 x 32 region); the next tile's x is in flight
+// (registers) while the current one is computed.  Wave w owns region rows 4w..4w+3 (8 groups of 16 positions).
 __global__ __launch_bounds__(256) void conv_pair_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
                                                             const float* __restrict__ b1,
                                                             const float* __restrict__ w2,
                                                             const float* __restrict__ b2, float* __restrict__ y,
                                                             int h, int wd, int rows_per_block, float pad1,
                                                             int use_b1, int use_b2, float alpha, int act2) {
+    constexpr int TH = RH - 2, TW = RW - 2;
     __shared__ float xs[XH * XW];
-    __shared__ float4 a1s[AH * AW * 4];
-    __shared__ float ws[2][9 * C];                       // both weight tensors: a phase keeps only its own in VGPRs
-    const int tid = threadIdx.x, q = tid & 3, quad = tid >> 2;
-    const int col = quad & 31, half = quad >> 5;
+    __shared__ float ps[RH * RW * 9];                    // P[pos][tap]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
     const int x0 = blockIdx.x * TW;
     const int row_begin = blockIdx.y * rows_per_block, row_end = min(h, row_begin + rows_per_block);
     const float* xb = x + (size_t)blockIdx.z * h * wd;
     float* yb = y + (size_t)blockIdx.z * h * wd;
-    for (int i = tid; i < 2 * 9 * C; i += 256) ws[i / (9 * C)][i % (9 * C)] = (i < 9 * C ? w1 : w2 - 9 * C)[i];
-    float wr[9][4], br[4];
+    // constant MFMA operands.  Z: A = W1^T (m = ch = n, k -> tap 4kc+kq), B = x at (pos n) + tap.
+    // P: A = a1 register j (m = pos n, k -> ch 4kq+j), B = W2^T (k -> ch 4kq+j, n = tap)
+    float w1a[3], w2b[4], bias4[4];
+    int xoff[3];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) br[j] = use_b1 ? b1[q * 4 + j] : 0.f;
+    for (int kc = 0; kc < 3; ++kc) {
+        const int tap = 4 * kc + kq, t = tap < 9 ? tap : 8;
+        w1a[kc] = tap < 9 ? w1[t * C + n] : 0.f;
+        xoff[kc] = (t / 3) * XW + t % 3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        w2b[j] = n < 9 ? w2[(n < 9 ? n : 0) * C + 4 * kq + j] : 0.f;
+        bias4[j] = use_b1 ? b1[4 * kq + j] : 0.f;
+    }
     const float bias2 = use_b2 ? b2[0] : 0.f;
 
     Stage st;
     float px[NPF];
-    st.locate(tid, row_begin, x0, h, wd);
+    st.locate(tid, row_begin - 2, x0 - 2, h, wd);
 #pragma unroll
     for (int k = 0; k < NPF; ++k) px[k] = xb[st.off[k]];
     for (int y0 = row_begin; y0 < row_end; y0 += TH) {
@@ -120,76 +104,48 @@ __global__ __launch_bounds__(256) void conv_pair_fwd_kernel(const float* __restr
             if (tid + k * 256 < XH * XW) xs[tid + k * 256] = st.in[k] ? px[k] : pad1;
         __syncthreads();
         if (y0 + TH < row_end) {                         // next tile: loads overlap this tile's math
-            st.locate(tid, y0 + TH, x0, h, wd);
+            st.locate(tid, y0 + TH - 2, x0 - 2, h, wd);
 #pragma unroll
             for (int k = 0; k < NPF; ++k) px[k] = xb[st.off[k]];
         }
-        // a1 = LeakyReLU(conv_1(x)) on the 18 x 32 region (tile + halo 1): a quad walks 9 rows of one
-        // column with a sliding 3x3 window; outside the image a1 is conv_2's zero padding
-        {
-            load_taps(wr, ws[0], q);
-            const int r0 = half * 9;
-            float xw[3][3], nx[3];
+        // region origin = (y0 - 1, x0 - 1), xs origin one further out: tap (ty,tx) of region (r,c) = xs[r+ty][c+tx]
+#pragma unroll 2
+        for (int k = 0; k < 8; ++k) {
+            const int gi = wv * 8 + k, r = gi >> 1, c0 = (gi & 1) * 16;
+            const float* xr = xs + r * XW + c0 + n;
+            f32x4 z = {bias4[0], bias4[1], bias4[2], bias4[3]};
 #pragma unroll
-            for (int sx = 0; sx < 3; ++sx) {
-                xw[1][sx] = xs[r0 * XW + col + sx];
-                xw[2][sx] = xs[(r0 + 1) * XW + col + sx];
-                nx[sx] = xs[(r0 + 2) * XW + col + sx];
+            for (int kc = 0; kc < 3; ++kc) z = mfma(w1a[kc], xr[xoff[kc]], z);
+            const int ay = y0 - 1 + r, ax = x0 - 1 + c0 + n;
+            const bool inside = ay >= 0 && ay < h && ax >= 0 && ax < wd;   // outside: conv_2's zero padding
+            f32x4 p = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = inside ? (z[j] >= 0.f ? z[j] : alpha * z[j]) : 0.f;
+                p = mfma(a, w2b[j], p);
             }
-#pragma unroll 1
-            for (int k = 0; k < 9; ++k) {
-                const int r = r0 + k;
+            if (n < 9) {
 #pragma unroll
-                for (int sx = 0; sx < 3; ++sx) {
-                    xw[0][sx] = xw[1][sx];
-                    xw[1][sx] = xw[2][sx];
-                    xw[2][sx] = nx[sx];
-                    nx[sx] = xs[min(r + 3, XH - 1) * XW + col + sx];   // next step's row, in flight during the math
-                }
-                float v[4] = {br[0], br[1], br[2], br[3]};
-#pragma unroll
-                for (int t = 0; t < 9; ++t)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += xw[t / 3][t % 3] * wr[t][j];
-                const int ay = y0 - 1 + r, ax = x0 - 1 + col;
-                const bool inside = ay >= 0 && ay < h && ax >= 0 && ax < wd;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = inside ? (v[j] >= 0.f ? v[j] : alpha * v[j]) : 0.f;
-                a1s[(r * AW + col) * 4 + q] = make_float4(v[0], v[1], v[2], v[3]);
+                for (int v = 0; v < 4; ++v) ps[(r * RW + c0 + 4 * kq + v) * 9 + n] = p[v];
             }
         }
         __syncthreads();
-        // conv_2: a quad owns 8 vertically adjacent outputs of one column and walks the 10 a1 rows they
-        // need once (3 float4 per row from LDS); an a1 row feeds tap row 0 of the output starting there,
-        // tap row 1 of the one above and completes the one two above (rolled loop: few live registers)
-        {
-            load_taps(wr, ws[1], q);
-            const int pc = col < TW ? col : 0, pr0 = half * 8;
-            float above2 = 0.f, above1 = 0.f;           // partial sums of outputs rr - 2 and rr - 1
-#pragma unroll 1
-            for (int rr = 0; rr < 10; ++rr) {
-                float t[3] = {0.f, 0.f, 0.f};
+        for (int p = tid; p < TH * TW; p += 256) {
+            const int pr = p / TW, pc = p - pr * TW;
+            const int gy = y0 + pr, gx = x0 + pc;
+            float v = bias2;
 #pragma unroll
-                for (int tx = 0; tx < 3; ++tx) {
-                    const float4 v = a1s[((pr0 + rr) * AW + pc + tx) * 4 + q];
+            for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
-                    for (int ty = 0; ty < 3; ++ty)
-                        t[ty] += v.x * wr[ty * 3 + tx][0] + v.y * wr[ty * 3 + tx][1] + v.z * wr[ty * 3 + tx][2] +
-                                 v.w * wr[ty * 3 + tx][3];
-                }
-                const float done = quad_sum(above2 + t[2]);
-                above2 = above1 + t[1];
-                above1 = t[0];
-                const int gy = y0 + pr0 + rr - 2, gx = x0 + col;
-                if (rr >= 2 && q == 0 && col < TW && gy < h && gx < wd)
-                    yb[(size_t)gy * wd + gx] = out_act(done + bias2, act2);
-            }
+                for (int tx = 0; tx < 3; ++tx) v += ps[((pr + ty) * RW + pc + tx) * 9 + ty * 3 + tx];
+            if (gy < row_end && gx < wd) yb[(size_t)gy * wd + gx] = out_act(v, act2);
         }
     }
 }
 
-// Same walk for the backward; the 77 accumulators stay in registers over all tiles of the block and are
-// reduced once: DPP over the 4 positions of a 16-lane row, LDS over the 16 rows.  partial[blk][q][NA]
+// Same walk for the backward.  DX: the tile owns the inner 14 x 30 positions of the region (d_a1 is needed
+// on a halo of 1 for dx); otherwise all 16 x 32.  Per block one reduction of the two 16 x 16 accumulator
+// tiles (4 VGPRs each) and of db1 / db2; partial[blk][q][NA] in the layout conv_pair_bwd_finish sums.
 template <bool DX>
 __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restrict__ x, const float* __restrict__ yout,
                                                             const float* __restrict__ dy,
@@ -199,40 +155,46 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restr
                                                             float* __restrict__ partial, float* __restrict__ dx,
                                                             int h, int wd, int rows_per_block, float pad1,
                                                             int use_b1, float alpha, int act2) {
-    constexpr int OFF = DX ? 0 : 1;                      // region origin - (xs origin + 1)
-    constexpr int RW = DX ? AW : TW;                     // region width: halo 1 only when dx is wanted
-    constexpr int RPQ = DX ? 9 : 8;                      // positions (rows) per quad: 2 halves x RPQ rows
+    constexpr int OFF = DX ? 1 : 0;
+    constexpr int TH = RH - 2 * OFF, TW = RW - 2 * OFF;
     __shared__ float xs[XH * XW];
     __shared__ float gs[XH * XW];
-    __shared__ float us[DX ? AH * AW * 9 : 1];
-    __shared__ float red[16][4][NA];
-    __shared__ float w2s[9 * C];                         // conv_2 weights: read per tap (frees 36 VGPRs)
-    const int tid = threadIdx.x, q = tid & 3, quad = tid >> 2;
-    const int col = quad & 31, half = quad >> 5;
-    const bool lane_on = col < RW;
-    const int c = lane_on ? col : 0;
+    __shared__ float us[DX ? RH * RW * 9 : 1];           // U[pos][tap]
+    __shared__ float tr[DX ? 4 * 16 * TS : 1];           // per wave: d_a1[pos][ch] of the current group
+    __shared__ float red[4][2][16][16];
+    __shared__ float reddb[4][4][16];
+    __shared__ float redb2[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
     const int x0 = blockIdx.x * TW;
     const int row_begin = blockIdx.y * rows_per_block, row_end = min(h, row_begin + rows_per_block);
     const size_t img = (size_t)blockIdx.z * h * wd;
     const float *xb = x + img, *gb = dy + img, *yb = yout + img;
-
-    float w1r[9][4], b1r[4];
-    load_taps(w1r, w1, q);
-    if (tid < 9 * C) w2s[tid] = w2[tid];
+    // constant operands.  Z^T / S^T: A = x or g at (pos n) shifted by tap 4kc+kq, B = W1 / W2 [tap][ch = n]
+    float w1b[3], w2b[3], w1u[4];
+    int xoff[3], goff[3];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b1r[j] = use_b1 ? b1[q * 4 + j] : 0.f;
-    float dw1[9][4], dw2[9][4], db1[4], db2 = 0.f;
+    for (int kc = 0; kc < 3; ++kc) {
+        const int tap = 4 * kc + kq, t = tap < 9 ? tap : 8;
+        w1b[kc] = tap < 9 ? w1[t * C + n] : 0.f;
+        w2b[kc] = tap < 9 ? w2[t * C + n] : 0.f;
+        xoff[kc] = (t / 3) * XW + t % 3;
+        goff[kc] = (2 - t / 3) * XW + 2 - t % 3;         // g[pos - tap + 1]
+    }
+    // dW^T: A = g / x around pos 4kq+i seen from tap n (rows 9..15 of the result are unused)
+    const bool tap_ok = n < 9;
+    const int tn = tap_ok ? n : 8;
+    const int xA = (tn / 3) * XW + tn % 3 + 4 * kq, gA = (2 - tn / 3) * XW + 2 - tn % 3 + 4 * kq;
+    // U: A = d_a1[pos n][ch 4kc+kq] (transposed through LDS), B = W1[tap n][ch 4kc+kq]
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dw1[t][j] = dw2[t][j] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) db1[j] = 0.f;
+    for (int kc = 0; kc < 4; ++kc) w1u[kc] = tap_ok ? w1[tn * C + 4 * kc + kq] : 0.f;
+    const float bias = use_b1 ? b1[n] : 0.f;
+    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // dW1^T, dW2^T [tap 4kq+v][ch n]
+    float db1acc = 0.f, db2acc = 0.f;
 
     Stage st;
     float px[NPF], pg[NPF];
     auto prefetch = [&](int y0) {
-        st.locate(tid, y0, x0, h, wd);
+        st.locate(tid, y0 - OFF - 1, x0 - OFF - 1, h, wd);
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             px[k] = xb[st.off[k]];
@@ -254,127 +216,98 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restr
             }
         __syncthreads();
         if (y0 + TH < row_end) prefetch(y0 + TH);
-        // a quad walks RPQ rows of one region column; 3x3 windows of x and g slide down in registers
-        const int r0 = half * RPQ;
-        float xw[3][3], gw[3][3], nx[3], ng[3];
+        const int ry = y0 - OFF, rx = x0 - OFF;          // region origin; xs / gs origin one further out
+#pragma unroll 2
+        for (int k = 0; k < 8; ++k) {
+            const int gi = wv * 8 + k, r = gi >> 1, c0 = (gi & 1) * 16;
+            const float* xr = xs + r * XW + c0;
+            const float* gr = gs + r * XW + c0;
+            f32x4 z = {bias, bias, bias, bias}, s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int sx = 0; sx < 3; ++sx) {
-            const int o = c + OFF + sx;
-            xw[1][sx] = xs[(r0 + OFF) * XW + o];
-            gw[1][sx] = gs[(r0 + OFF) * XW + o];
-            xw[2][sx] = xs[(r0 + OFF + 1) * XW + o];
-            gw[2][sx] = gs[(r0 + OFF + 1) * XW + o];
-            nx[sx] = xs[(r0 + OFF + 2) * XW + o];
-            ng[sx] = gs[(r0 + OFF + 2) * XW + o];
-        }
-#pragma unroll 1
-        for (int k = 0; k < RPQ; ++k) {
-            const int r = r0 + k;
-#pragma unroll
-            for (int sx = 0; sx < 3; ++sx) {
-                const int o = min(r + OFF + 3, XH - 1) * XW + c + OFF + sx;
-                xw[0][sx] = xw[1][sx];
-                xw[1][sx] = xw[2][sx];
-                xw[2][sx] = nx[sx];
-                gw[0][sx] = gw[1][sx];
-                gw[1][sx] = gw[2][sx];
-                gw[2][sx] = ng[sx];
-                nx[sx] = xs[o];                          // next step's row, in flight during the math
-                ng[sx] = gs[o];
+            for (int kc = 0; kc < 3; ++kc) {
+                z = mfma(xr[n + xoff[kc]], w1b[kc], z);
+                s = mfma(gr[n + goff[kc]], w2b[kc], s);
             }
-            const int ay = y0 - (DX ? 1 : 0) + r, ax = x0 - (DX ? 1 : 0) + c;
-            const bool inside = lane_on && ay >= 0 && ay < h && ax >= 0 && ax < wd;
-            const bool owned = inside && (!DX || (r >= 1 && r <= TH && c >= 1 && c <= TW));
-            // a1 of this position (pre-activation z), recomputed
-            float z[4] = {b1r[0], b1r[1], b1r[2], b1r[3]};
+            // results: channel n at positions (r, c0 + 4kq + i)
+            const int ay = ry + r;
+            const bool row_in = ay >= 0 && ay < h, row_own = row_in && (!DX || (r >= 1 && r <= TH)) && ay < row_end;
+            float a[4], d[4], dn[4];
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) z[j] += xw[t / 3][t % 3] * w1r[t][j];
-            float a[4], slope[4], s[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                slope[j] = z[j] >= 0.f ? 1.f : alpha;
-                a[j] = owned ? z[j] * slope[j] : 0.f;
-                s[j] = 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const int c = c0 + 4 * kq + i, ax = rx + c;
+                const bool inside = row_in && ax >= 0 && ax < wd;
+                const bool owned = row_own && ax >= 0 && ax < wd && (!DX || (c >= 1 && c <= TW));
+                const float slope = z[i] >= 0.f ? 1.f : alpha;
+                a[i] = owned ? z[i] * slope : 0.f;
+                d[i] = inside ? s[i] * slope : 0.f;
+                dn[i] = owned ? d[i] : 0.f;
+                db1acc += dn[i];
             }
-            // one pass over the 3x3 window of g for dw2 and for conv_2's dx: tap t pairs with g[q - t + 1]
-            int wofs = q * 4;
-            asm volatile("" : "+v"(wofs));               // keeps the w2 reads inside the loop (36 VGPRs otherwise)
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float g = gw[2 - t / 3][2 - t % 3];
-                const float4 wt = *reinterpret_cast<const float4*>(w2s + t * C + wofs);
-                const float w2t[4] = {wt.x, wt.y, wt.z, wt.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    dw2[t][j] += a[j] * g;
-                    s[j] += w2t[j] * g;
-                }
+            for (int i = 0; i < 4; ++i) {
+                const float gv = gr[i + gA], xv = xr[i + xA];
+                acc2 = mfma(tap_ok ? gv : 0.f, a[i], acc2);
+                acc1 = mfma(tap_ok ? xv : 0.f, dn[i], acc1);
             }
-            float d[4], dn[4];                           // d_a1 (also on the halo, for dx); dn: owned only
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                d[j] = inside ? s[j] * slope[j] : 0.f;
-                dn[j] = owned ? d[j] : 0.f;
-                db1[j] += dn[j];
-            }
-            db2 += owned ? gw[1][1] : 0.f;
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dw1[t][j] += xw[t / 3][t % 3] * dn[j];
             if constexpr (DX) {
+                float* t = tr + wv * 16 * TS;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    float u = w1r[t][0] * d[0] + w1r[t][1] * d[1] + w1r[t][2] * d[2] + w1r[t][3] * d[3];
-                    u = quad_sum(u);
-                    if ((t & 3) == q) us[(r * AW + col) * 9 + t] = u;
+                for (int i = 0; i < 4; ++i) t[(4 * kq + i) * TS + n] = d[i];
+                __builtin_amdgcn_wave_barrier();         // same wave: LDS executes its instructions in order
+                f32x4 u = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) u = mfma(t[n * TS + 4 * kc + kq], w1u[kc], u);
+                __builtin_amdgcn_wave_barrier();
+                if (tap_ok) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) us[(r * RW + c0 + 4 * kq + v) * 9 + n] = u[v];
                 }
             }
         }
-        if constexpr (DX) {
-            __syncthreads();
-            for (int p = tid; p < TH * TW; p += 256) {
-                const int pr = p / TW, pc = p - pr * TW;
-                const int gy = y0 + pr, gx = x0 + pc;
+        if constexpr (DX) __syncthreads();
+        for (int p = tid; p < TH * TW; p += 256) {
+            const int pr = p / TW, pc = p - pr * TW;
+            const int gy = y0 + pr, gx = x0 + pc;
+            if (gy >= row_end || gx >= wd) continue;
+            db2acc += gs[(pr + OFF + 1) * XW + pc + OFF + 1];
+            if constexpr (DX) {
                 float v = 0.f;
 #pragma unroll
                 for (int sy = 0; sy < 3; ++sy)
 #pragma unroll
                     for (int sx = 0; sx < 3; ++sx)
-                        v += us[((pr + 2 - sy) * AW + pc + 2 - sx) * 9 + sy * 3 + sx];
-                if (gy < h && gx < wd) dx[img + (size_t)gy * wd + gx] = v;
+                        v += us[((pr + 2 - sy) * RW + pc + 2 - sx) * 9 + sy * 3 + sx];
+                dx[img + (size_t)gy * wd + gx] = v;
             }
         }
     }
-    // reduction: 4 positions of a 16-lane row by DPP, the 16 rows of the block through LDS
-    const int row = tid >> 4;
-    const bool writer = (tid & 15) < 4;
+    // block reduction through LDS
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float v1 = row_sum_q(dw1[t][j]), v2 = row_sum_q(dw2[t][j]);
-            if (writer) {
-                red[row][q][t * 4 + j] = v1;
-                red[row][q][36 + t * 4 + j] = v2;
-            }
-        }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float v = row_sum_q(db1[j]);
-        if (writer) red[row][q][72 + j] = v;
+    for (int v = 0; v < 4; ++v) {
+        red[wv][0][4 * kq + v][n] = acc1[v];
+        red[wv][1][4 * kq + v][n] = acc2[v];
     }
-    db2 = row_sum_q(db2);
-    if (writer) red[row][q][76] = db2;
+    reddb[wv][kq][n] = db1acc;
+    db2acc = wave_reduce_sum(db2acc);
+    if (lane == 0) redb2[wv] = db2acc;
     __syncthreads();
     const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     float* out = partial + (size_t)blk * 4 * NA;
     for (int i = tid; i < 4 * NA; i += 256) {
+        const int q = i / NA, k = i - q * NA;
         float v = 0.f;
+        if (k < 72) {
+            const int which = k / 36, kk = k - which * 36, tap = kk >> 2, ch = q * 4 + (kk & 3);
+            v = red[0][which][tap][ch] + red[1][which][tap][ch] + red[2][which][tap][ch] + red[3][which][tap][ch];
+        } else if (k < 76) {
+            const int ch = q * 4 + (k - 72);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v += red[k][0][i];
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) v += reddb[w][g4][ch];
+        } else {
+            v = redb2[0] + redb2[1] + redb2[2] + redb2[3];
+        }
         out[i] = v;
     }
 }
@@ -406,10 +339,10 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_finish(const float* __restr
     *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
 
-// rows per block = a multiple of the tile height giving at most ~8 blocks per CU
-int pair_rows_per_block(int strips, int h, int n) {
-    int rows = TH;
-    while (rows < h && (size_t)strips * ((h + rows - 1) / rows) * n > 2048u) rows += TH;
+// rows per block = a multiple of the tile height th giving at most ~8 blocks per CU
+int pair_rows_per_block(int strips, int h, int n, int th) {
+    int rows = th;
+    while (rows < h && (size_t)strips * ((h + rows - 1) / rows) * n > 2048u) rows += th;
     return rows;
 }
 
@@ -431,8 +364,8 @@ extern "C" int uocr_conv_pair_fwd(uocr_ctx* ctx, int dtype, const void* x, const
     UOCR_REQUIRE(ctx, x && w1 && b1 && w2 && b2 && y);
     int rc = check_pair(ctx, dtype, n, h, w, cmid, act2);
     if (rc != UOCR_OK) return rc;
-    const int strips = (w + TW - 1) / TW;
-    const int rows_per_block = pair_rows_per_block(strips, h, n);
+    const int strips = (w + RW - 3) / (RW - 2);
+    const int rows_per_block = pair_rows_per_block(strips, h, n, RH - 2);
     const dim3 grid(strips, (h + rows_per_block - 1) / rows_per_block, n);
     hipLaunchKernelGGL(conv_pair_fwd_kernel, grid, dim3(256), 0, ctx->stream, (const float*)x, (const float*)w1,
                        (const float*)b1, (const float*)w2, (const float*)b2, (float*)y, h, w, rows_per_block,
@@ -449,8 +382,9 @@ extern "C" int uocr_conv_pair_bwd(uocr_ctx* ctx, int dtype, const void* x, const
     UOCR_REQUIRE(ctx, x && y && dy && w1 && b1 && w2 && dw1 && db1 && dw2 && db2);
     int rc = check_pair(ctx, dtype, n, h, w, cmid, act2);
     if (rc != UOCR_OK) return rc;
-    const int strips = (w + TW - 1) / TW;
-    const int rows_per_block = pair_rows_per_block(strips, h, n);
+    const int tw = dx ? RW - 2 : RW, th = dx ? RH - 2 : RH;
+    const int strips = (w + tw - 1) / tw;
+    const int rows_per_block = pair_rows_per_block(strips, h, n, th);
     const int bands = (h + rows_per_block - 1) / rows_per_block;
     const int nblocks = strips * bands * n;
     rc = uocr_need_workspace(ctx, (size_t)nblocks * 4 * NA * sizeof(float));
