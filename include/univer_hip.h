@@ -117,6 +117,23 @@ int uocr_conv_pair_bwd(uocr_ctx* ctx, int dtype, const void* x, const void* y, c
                        void* db2, void* dx, int n, int h, int wd, int cmid, double pad_value1,
                        int use_bias1, int use_bias2, double alpha1, int act2, int accumulate);
 
+/* Upsample2D(2) + Convolutional2D(5x5, stride 1, padding 2, padding value 0, 4 -> 4 channels) as one op on
+ * the LOW-RES tensor x_low (n,hl,wl,4) -> y (n,2hl,2wl,4): the decoder blocks `up_i` of the Line net
+ * (my_model/model.py:194-247 = upsample.py:21-39 + convolutional.py:62-145).  Each output parity phase sees
+ * a 3x3 block of source pixels with the 5x5 taps summed in groups, so the upsampled tensor is never built
+ * (float32; results equal the two-layer path to rounding, not bit for bit).  Arguments as uocr_conv2d_*,
+ * with hl, wl the LOW-RES size; bwd_data returns the gradient w.r.t. x_low (= upsample backward of the conv's
+ * dx).  UOCR_ERR_UNSUPPORTED for any other shape or dtype: the caller then runs the two layers. */
+int uocr_upconv2x_fwd(uocr_ctx* ctx, int dtype, const void* x_low, const void* w, const void* b, void* y,
+                      int n, int hl, int wl, int cin, int cout, int kh, int kw, int ph, int pw,
+                      int use_bias, int act, double act_alpha);
+int uocr_upconv2x_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, const void* w, void* dx_low,
+                           int n, int hl, int wl, int cin, int cout, int kh, int kw, int ph, int pw,
+                           const void* x_act, int act, double act_alpha);
+int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_low, const void* dy, void* dw, void* db,
+                             int n, int hl, int wl, int cin, int cout, int kh, int kw, int ph, int pw,
+                             int use_bias, int accumulate);
+
 /* ---- MaxPool2D (layers/maxpool.py; the NumPy path :24-90 is the semantics) ---------------- */
 /* y = window max with zero padding; mask (uint8, shape (n, kh*oh, kw*ow, c), window-major) marks
  * every element equal to the max; windows running past the padded extent (ceil_mode) shrink. */

@@ -246,3 +246,55 @@ def test_upsample2_vector_kernels_are_exact(shape, f32):
         for i in range(2):
             ref = ref + g[:, j::2, i::2, :]
     assert np.array_equal(CP.asnumpy(dx), ref)
+
+
+UP_SHAPES = [(2, 16, 32), (3, 7, 19), (1, 1, 1), (2, 33, 40), (1, 5, 70), (4, 40, 64)]
+
+
+@pytest.mark.parametrize('shape', UP_SHAPES)
+@pytest.mark.parametrize('bias,act', [(True, 'leaky'), (False, None)])
+def test_upconv2x_kernels_against_oracle(shape, bias, act, f32):
+    """uocr_upconv2x_* (Upsample2D(2) + 5x5 conv 4->4 evaluated on the low-res tensor as a 3x3 conv to 16
+    phase channels) == the oracle's upsample followed by its conv, forward, dx (with and without the
+    LeakyReLU' epilogue) and dw/db: ragged tiles, images smaller than a tile, several row bands."""
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    n, hl, wl = shape
+    rng = np.random.default_rng(sum(shape) + 7)
+    xl = rng.standard_normal((n, hl, wl, 4))
+    w = rng.standard_normal((5, 5, 4, 4)) * 0.1
+    b = rng.standard_normal(4)
+    alpha = 0.01
+    xu = O.upsample2d_fwd(xl, (2, 2))
+    z = O.conv2d_fwd(xu, w, b, 1, 2, 0.0, bias)
+    ref_y = O.leaky_relu_fwd(z, alpha) if act else z
+    g = rng.standard_normal(ref_y.shape)
+    gz = O.leaky_relu_bwd(z, g, alpha) if act else g
+    dxu, ref_dw, ref_db = O.conv2d_bwd(xu, w, gz, 1, 2, 0.0, bias)
+    ref_dx = O.upsample2d_bwd(dxu, (2, 2))
+
+    xd, wd, bd = CP.copy(xl), CP.copy(w), CP.copy(b)
+    y = ops.upconv2x_fwd(xd, wd, bd, (2, 2), bias, act, alpha)
+    check(y, ref_y, 1e-5, 'y')
+    gd = CP.copy(gz)
+    dx = ops.upconv2x_bwd_data(gd, wd, xl.shape, (2, 2))
+    check(dx, ref_dx, 1e-5, 'dx')
+    # epilogue: dx *= LeakyReLU'(x_act) with x_act = the low-res input seen as an activation output
+    dxm = ops.upconv2x_bwd_data(gd, wd, xl.shape, (2, 2), x_act=xd, act='leaky', alpha=alpha)
+    check(dxm, ref_dx * ((xl >= 0) + alpha * (xl < 0)), 1e-5, 'dx with mask')
+    dw, db = CP.full(w.shape, 0.5), CP.full(b.shape, 0.25)
+    ops.upconv2x_bwd_weight(xd, gd, dw, db, (2, 2), bias, accumulate=True)
+    check(dw, ref_dw + 0.5, 2e-5, 'dw')
+    check(db, ref_db + 0.25, 2e-5, 'db')
+    ops.upconv2x_bwd_weight(xd, gd, dw, db, (2, 2), bias, accumulate=False)
+    check(dw, ref_dw, 2e-5, 'dw overwrite')
+
+
+def test_upconv2x_rejects_other_shapes(f32):
+    from univer_ocr_amd.hip.lib import HipError
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    x = CP.copy(np.zeros((1, 4, 4, 1)))
+    w, b = CP.copy(np.zeros((5, 5, 1, 1))), CP.copy(np.zeros(1))
+    with pytest.raises(HipError, match='4 -> 4 channels only'):
+        ops.upconv2x_fwd(x, w, b, (2, 2))

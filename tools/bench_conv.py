@@ -87,9 +87,30 @@ def main():
             print(f'{"mono.pair (fused)":18s} {op:6s} {us:9.1f} {nbytes / 1e6:8.1f} {nbytes / us / 1e3:8.0f} '
                   f'{flop / 1e9:8.2f} {flop / us / 1e6:7.2f}')
 
+    def up_rows():
+        # Upsample2D(2) + conv5x5 4->4 on the low-res tensor (csrc/conv_up.hip); FLOPs of the 5x5 on the
+        # upsampled tensor (what the two-layer path computes), bytes = low-res tensor + high-res tensor
+        for name, hl, wl in (('line.up_2 (fused)', 64, 128), ('line.up_1 (fused)', 128, 256)):
+            n = args.batch
+            xl = CP.copy(rng.standard_normal((n, hl, wl, 4)).astype(np.float32))
+            wt = CP.copy((rng.standard_normal((5, 5, 4, 4)) * 0.1).astype(np.float32))
+            b = CP.zeros((4,))
+            g = CP.copy(rng.standard_normal((n, 2 * hl, 2 * wl, 4)).astype(np.float32))
+            dw, db = CP.zeros(wt.shape), CP.zeros((4,))
+            nbytes = 4 * n * hl * wl * 4 * 5
+            flop = 2.0 * n * 4 * hl * wl * 400
+            for op, fn in [('fwd', lambda: ops.upconv2x_fwd(xl, wt, b, (2, 2), True, 'leaky', 0.01)),
+                           ('dgrad', lambda: ops.upconv2x_bwd_data(g, wt, xl.shape, (2, 2))),
+                           ('wgrad', lambda: ops.upconv2x_bwd_weight(xl, g, dw, db, (2, 2)))]:
+                us = timed(fn)
+                print(f'{name:18s} {op:6s} {us:9.1f} {nbytes / 1e6:8.1f} {nbytes / us / 1e3:8.0f} {flop / 1e9:8.2f} '
+                      f'{flop / us / 1e6:7.2f}')
+
     print(f'{"layer":18s} {"op":6s} {"us":>9s} {"MB":>8s} {"GB/s":>8s} {"GFLOP":>8s} {"TF/s":>7s}')
     if args.filter in 'mono.pair (fused)':
         pair_rows()
+    if args.filter in 'line.up_1 (fused)' or args.filter in 'line.up_2 (fused)':
+        up_rows()
     for name, h, w, cin, cout, ks, st, pd in LAYERS:
         if args.filter not in name:
             continue

@@ -1,0 +1,382 @@
+// Upsample2D(2) followed by Convolutional2D(5x5, stride 1, padding 2, zero padding value), 4 -> 4 channels,
+// as ONE op on the LOW-RESOLUTION tensor (float32): the decoder blocks of the Line net
+// (reference: my_model/model.py:194-247 `up_i` = nn/layers/upsample.py:21-39 + nn/layers/convolutional.py:62-145).
+//
+// Nearest-neighbour upsampling makes 4 high-res pixels share one source pixel, so the 5x5 window of an
+// output pixel only sees a 3x3 block of source pixels, with the 25 taps summed in groups that depend on
+// the output's parity phase (py, px).  Per axis, source offset m = floor((phase + k - 2) / 2):
+//        phase 0: k {0,1} -> -1, {2,3} -> 0, {4} -> +1          phase 1: k {0} -> -1, {1,2} -> 0, {3,4} -> +1
+//   Weff[tap m][c][(phase, o)] = sum of w[ky][kx][c][o] over the groups  (9 x 4 x 16, made by a tiny kernel)
+//   y[2P + phase][o] = b[o] + sum_{m,c} Weff[m][c][(phase,o)] xl[P + m][c]
+// i.e. a 3x3 convolution 4 -> 16 on the low-res tensor followed by depth-to-space: 2.8x fewer multiply-adds
+// than the 5x5 on the upsampled tensor, no 4x larger intermediate (written once, read twice per step before),
+// and -- 16 output columns, K = 36 -- a shape the matrix cores take without padding:
+//   forward   Y^T[(phase,o), pos] = Weff^T[(phase,o), (m,c)] Xcol[(m,c), pos]      9 MFMAs (16x16x4) per 16 positions;
+//             the 4 result registers of a lane are the 4 channels of ONE high-res pixel -> one 16-B store
+//   dw        dWeff[(m,c), (phase,o)] += Xcol^T[(m,c), pos] dY[pos, (phase,o)]      12 MFMAs per 16 positions,
+//             then dw[ky][kx] (+)= sum over the phases of the group it belongs to (finish kernel)
+//   dx        dxl[Q][c] = sum_{m,(phase,o)} Weff[m][c][(phase,o)] dy[2(Q - m) + phase][o]: only 4 output columns,
+//             so it stays on the vector ALU: one tap (64 weights in SGPRs) per iteration of a rolled loop,
+//             dy window from an LDS tile, optional LeakyReLU' epilogue (ActMask as in conv_dims.h)
+// Sums of weights first / different summation order: results agree with the layer-by-layer path to
+// float32 rounding (tests: 1e-5 normalised), not bit for bit.
+#include "conv_dims.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int CH = 4;
+constexpr int RH = 16, RW = 32;                 // low-res positions per tile
+constexpr int XH = RH + 2, XW = RW + 2;         // xl tile: halo 1
+constexpr int XPLANE = 624;                     // >= XH*XW, = 16 mod 32: the 4 channel planes of a half wave on disjoint banks
+constexpr int NWEFF = 9 * CH * 16;
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float act_apply(float v, int act, float alpha) {
+    switch (act) {
+        case UOCR_ACT_RELU: return v * (v >= 0.f ? 1.f : 0.f);
+        case UOCR_ACT_LEAKY: return v * ((v >= 0.f ? 1.f : 0.f) + alpha * (v < 0.f ? 1.f : 0.f));
+        case UOCR_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+// taps k of one axis that land on source offset m (index mi = m + 1) for output parity `phase`: [lo, hi)
+__host__ __device__ __forceinline__ void tap_group(int phase, int mi, int& lo, int& hi) {
+    if (phase == 0) {
+        lo = 2 * mi;
+        hi = mi == 2 ? 5 : 2 * mi + 2;
+    } else {
+        lo = mi == 0 ? 0 : 2 * mi - 1;
+        hi = mi == 0 ? 1 : 2 * mi + 1;
+    }
+}
+
+// weff[(m*4 + c)*16 + phase*4 + o], m = my*3 + mx, phase = py*2 + px
+__global__ __launch_bounds__(256) void upconv_weff_kernel(const float* __restrict__ w, float* __restrict__ weff) {
+    for (int i = threadIdx.x; i < NWEFF; i += blockDim.x) {
+        const int o = i & 3, phase = (i >> 2) & 3, c = (i >> 4) & 3, m = i >> 6;
+        int ylo, yhi, xlo, xhi;
+        tap_group(phase >> 1, m / 3, ylo, yhi);
+        tap_group(phase & 1, m % 3, xlo, xhi);
+        float s = 0.f;
+        for (int ky = ylo; ky < yhi; ++ky)
+            for (int kx = xlo; kx < xhi; ++kx) s += w[((ky * 5 + kx) * CH + c) * CH + o];
+        weff[i] = s;
+    }
+}
+
+// xl tile (halo 1) of the region at low-res origin (ry, rx), channel-planar in LDS; zero outside the image
+__device__ __forceinline__ void stage_planar(float* __restrict__ xs, const float* __restrict__ xb, int ry, int rx,
+                                             int hl, int wl, int tid) {
+    for (int i = tid; i < XH * XW; i += 256) {
+        const int r = i / XW, c = i - r * XW;
+        const int gy = ry - 1 + r, gx = rx - 1 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < hl && gx >= 0 && gx < wl) v = *reinterpret_cast<const float4*>(xb + ((size_t)gy * wl + gx) * CH);
+        xs[i] = v.x;
+        xs[XPLANE + i] = v.y;
+        xs[2 * XPLANE + i] = v.z;
+        xs[3 * XPLANE + i] = v.w;
+    }
+}
+
+// forward.  Block = 16 x 32 low-res positions per tile iteration over a band of rows; wave w owns rows
+// 4w..4w+3 (8 groups of 16 consecutive positions).
+__global__ __launch_bounds__(256) void upconv_fwd_kernel(const float* __restrict__ xl, const float* __restrict__ weff,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         int hl, int wl, int rows_per_block, int use_bias, int act,
+                                                         float alpha) {
+    __shared__ float xs[CH * XPLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
+    const int rx = blockIdx.x * RW;
+    const int row_begin = blockIdx.y * rows_per_block, row_end = min(hl, row_begin + rows_per_block);
+    const float* xb = xl + (size_t)blockIdx.z * hl * wl * CH;
+    const int W = 2 * wl;
+    float* yb = y + (size_t)blockIdx.z * (2 * hl) * W * CH;
+    // A = Weff^T: lane (m = (phase,o) = n, k = channel kq), one register per tap
+    float wa[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wa[t] = weff[(t * CH + kq) * 16 + n];
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (use_bias) b4 = f32x4{bias[0], bias[1], bias[2], bias[3]};
+    for (int ry = row_begin; ry < row_end; ry += RH) {
+        __syncthreads();
+        stage_planar(xs, xb, ry, rx, hl, wl, tid);
+        __syncthreads();
+#pragma unroll 2
+        for (int k = 0; k < 8; ++k) {
+            const int gi = wv * 8 + k, r = gi >> 1, c0 = (gi & 1) * 16;
+            // B = Xcol: lane (k = channel kq, n = position): x at position + tap
+            const float* xr = xs + kq * XPLANE + r * XW + c0 + n;
+            f32x4 acc = b4;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc = mfma(wa[t], xr[(t / 3) * XW + t % 3], acc);
+            // lane: phase = kq, registers = the 4 channels of high-res pixel (2P + phase)
+            const int py = ry + r, pxl = rx + c0 + n;
+            if (py < row_end && pxl < wl) {
+                float4 out;
+                out.x = act_apply(acc[0], act, alpha);
+                out.y = act_apply(acc[1], act, alpha);
+                out.z = act_apply(acc[2], act, alpha);
+                out.w = act_apply(acc[3], act, alpha);
+                *reinterpret_cast<float4*>(yb + ((size_t)(2 * py + (kq >> 1)) * W + 2 * pxl + (kq & 1)) * CH) = out;
+            }
+        }
+    }
+}
+
+// dw: partial[blk][48][16] (rows 36..47 unused) + partial_db[blk][4]
+__global__ __launch_bounds__(256) void upconv_wgrad_kernel(const float* __restrict__ xl, const float* __restrict__ dy,
+                                                           float* __restrict__ partial, int hl, int wl,
+                                                           int rows_per_block) {
+    __shared__ float xs[CH * XPLANE];
+    __shared__ float red[4][48][16];
+    __shared__ float reddb[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
+    const int rx = blockIdx.x * RW;
+    const int row_begin = blockIdx.y * rows_per_block, row_end = min(hl, row_begin + rows_per_block);
+    const float* xb = xl + (size_t)blockIdx.z * hl * wl * CH;
+    const int W = 2 * wl;
+    const float* gb = dy + (size_t)blockIdx.z * (2 * hl) * W * CH;
+    // A = Xcol^T: lane (m = K index 16j + n -> tap K/4, channel K%4; k = position 4i + kq)
+    int aoff[3];
+    bool aok[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int K = 16 * j + n;
+        aok[j] = K < 36;
+        const int Kc = aok[j] ? K : 35, t = Kc >> 2;
+        aoff[j] = (Kc & 3) * XPLANE + (t / 3) * XW + t % 3 + kq;
+    }
+    // B = dY: lane (k = position 4i + kq, n = (phase, o))
+    const int boff = ((n >> 3) * W + ((n >> 2) & 1)) * CH + (n & 3);
+    f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float dbacc = 0.f;
+    for (int ry = row_begin; ry < row_end; ry += RH) {
+        __syncthreads();
+        stage_planar(xs, xb, ry, rx, hl, wl, tid);
+        __syncthreads();
+#pragma unroll 2
+        for (int k = 0; k < 8; ++k) {
+            const int gi = wv * 8 + k, r = gi >> 1, c0 = (gi & 1) * 16;
+            const int py = ry + r;
+            const bool row_ok = py < row_end;
+            const float* xr = xs + r * XW + c0;
+            const float* gr = gb + ((size_t)(2 * min(py, hl - 1)) * W + 2 * rx) * CH + boff;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int pl = c0 + 4 * i + kq;          // position of this lane's K slot
+                const bool ok = row_ok && rx + pl < wl;
+                float g = gr[(size_t)2 * min(pl, wl - 1 - rx) * CH];
+                g = ok ? g : 0.f;
+                dbacc += g;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float xv = xr[4 * i + aoff[j]];
+                    acc[j] = mfma(aok[j] ? xv : 0.f, g, acc[j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) red[wv][16 * j + 4 * kq + v][n] = acc[j][v];
+    reddb[wv][lane] = dbacc;
+    __syncthreads();
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    float* out = partial + (size_t)blk * (36 * 16 + 4);
+    for (int i = tid; i < 36 * 16; i += 256) {
+        const int K = i >> 4, col = i & 15;
+        out[i] = red[0][K][col] + red[1][K][col] + red[2][K][col] + red[3][K][col];
+    }
+    if (tid < 4) {                                       // db[o]: lanes with (n & 3) == o
+        float s = 0.f;
+        for (int w = 0; w < 4; ++w)
+            for (int l = tid; l < 64; l += 4) s += reddb[w][l];
+        out[36 * 16 + tid] = s;
+    }
+}
+
+// block i < 400: dw[ky][kx][c][o] (+)= sum over blocks and phases of dWeff[(m(py,ky), m(px,kx)), c, (phase,o)];
+// blocks 400..403: db[o]
+__global__ __launch_bounds__(256) void upconv_wgrad_finish(const float* __restrict__ partial, float* __restrict__ dw,
+                                                           float* __restrict__ db, int nblocks, int use_bias,
+                                                           int accumulate) {
+    __shared__ double smem[16];
+    const int e = blockIdx.x;
+    double s = 0.0;
+    float* dst;
+    if (e < 400) {
+        const int o = e & 3, c = (e >> 2) & 3, kk = e >> 4, ky = kk / 5, kx = kk % 5;
+        int idx[4];
+#pragma unroll
+        for (int phase = 0; phase < 4; ++phase) {
+            int my = 0, mx = 0, lo, hi;
+            for (int mi = 0; mi < 3; ++mi) {
+                tap_group(phase >> 1, mi, lo, hi);
+                if (ky >= lo && ky < hi) my = mi;
+                tap_group(phase & 1, mi, lo, hi);
+                if (kx >= lo && kx < hi) mx = mi;
+            }
+            idx[phase] = ((my * 3 + mx) * CH + c) * 16 + phase * 4 + o;
+        }
+        for (int blk = threadIdx.x; blk < nblocks; blk += blockDim.x) {
+            const float* p = partial + (size_t)blk * (36 * 16 + 4);
+            s += (double)p[idx[0]] + (double)p[idx[1]] + (double)p[idx[2]] + (double)p[idx[3]];
+        }
+        dst = dw + e;
+    } else {
+        const int o = e - 400;
+        for (int blk = threadIdx.x; blk < nblocks; blk += blockDim.x)
+            s += (double)partial[(size_t)blk * (36 * 16 + 4) + 36 * 16 + o];
+        dst = db + o;
+    }
+    s = block_reduce_sum(s, smem);
+    if (threadIdx.x != 0) return;
+    if (e >= 400 && !use_bias) s = 0.0;
+    *dst = accumulate ? (float)((double)*dst + s) : (float)s;
+}
+
+// dx on the vector ALU.  Block = 16 x 32 low-res positions, 2 per thread (rows r and r + 8); dy tile of the
+// (16 + 2) x (32 + 2) source blocks = 36 x 68 high-res pixels in LDS.
+constexpr int GH = 2 * (RH + 2), GW = 2 * (RW + 2);
+__global__ __launch_bounds__(256) void upconv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ weff,
+                                                           float* __restrict__ dxl, int hl, int wl,
+                                                           const float* __restrict__ mask_y, int mask_act,
+                                                           float mask_alpha) {
+    __shared__ float4 gs[GH * GW];
+    const int tid = threadIdx.x;
+    const int rx = blockIdx.x * RW, ry = blockIdx.y * RH;
+    const int H = 2 * hl, W = 2 * wl;
+    const float* gb = dy + (size_t)blockIdx.z * H * W * CH;
+    for (int i = tid; i < GH * GW; i += 256) {
+        const int r = i / GW, c = i - r * GW;
+        const int gy = 2 * (ry - 1) + r, gx = 2 * (rx - 1) + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const float4*>(gb + ((size_t)gy * W + gx) * CH);
+        gs[i] = v;
+    }
+    __syncthreads();
+    const int c = tid & 31, r0 = tid >> 5;               // positions (r0, c) and (r0 + 8, c)
+    float acc[2][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[p][j] = 0.f;
+#pragma unroll 1
+    for (int m = 0; m < 9; ++m) {
+        const float* wt = weff + m * 64;                 // [c][phase][o]: uniform -> scalar loads
+        const int my = m / 3 - 1, mx = m % 3 - 1;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = r0 + 8 * p;
+            // source block Q - m: tile rows 2(r - my + 1) + py, cols 2(c - mx + 1) + px
+            const float4* g0 = gs + (2 * (r - my + 1)) * GW + 2 * (c - mx + 1);
+            const float4 g[4] = {g0[0], g0[1], g0[GW], g0[GW + 1]};
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                for (int phase = 0; phase < 4; ++phase) {
+                    const float* wv = wt + ch * 16 + phase * 4;
+                    acc[p][ch] += wv[0] * g[phase].x + wv[1] * g[phase].y + wv[2] * g[phase].z + wv[3] * g[phase].w;
+                }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int qy = ry + r0 + 8 * p, qx = rx + c;
+        if (qy >= hl || qx >= wl) continue;
+        const size_t off = (((size_t)blockIdx.z * hl + qy) * wl + qx) * CH;
+        float4 out = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
+        if (mask_act != UOCR_ACT_NONE) {
+            const float4 yv = *reinterpret_cast<const float4*>(mask_y + off);
+            out.x *= act_grad_from_output<float>(yv.x, mask_act, mask_alpha);
+            out.y *= act_grad_from_output<float>(yv.y, mask_act, mask_alpha);
+            out.z *= act_grad_from_output<float>(yv.z, mask_act, mask_alpha);
+            out.w *= act_grad_from_output<float>(yv.w, mask_act, mask_alpha);
+        }
+        *reinterpret_cast<float4*>(dxl + off) = out;
+    }
+}
+
+int up_rows_per_block(int strips, int hl, int n) {
+    int rows = RH;
+    while (rows < hl && (size_t)strips * ((hl + rows - 1) / rows) * n > 2048u) rows += RH;
+    return rows;
+}
+
+int check_up(uocr_ctx* ctx, int dtype, int n, int hl, int wl, int cin, int cout, int kh, int kw, int ph, int pw) {
+    if (dtype != UOCR_F32) UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "upconv2x: float32 only");
+    if (cin != CH || cout != CH || kh != 5 || kw != 5 || ph != 2 || pw != 2)
+        UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "upconv2x: 5x5 / padding 2 / 4 -> 4 channels only (got %dx%d pad %d,%d %d -> %d)",
+                  kh, kw, ph, pw, cin, cout);
+    UOCR_REQUIRE(ctx, n > 0 && hl > 0 && wl > 0 && n <= 65535);
+    return UOCR_OK;
+}
+
+}  // namespace
+
+extern "C" int uocr_upconv2x_fwd(uocr_ctx* ctx, int dtype, const void* x_low, const void* w, const void* b, void* y,
+                                 int n, int hl, int wl, int cin, int cout, int kh, int kw, int ph, int pw,
+                                 int use_bias, int act, double act_alpha) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, x_low && w && b && y);
+    int rc = check_up(ctx, dtype, n, hl, wl, cin, cout, kh, kw, ph, pw);
+    if (rc != UOCR_OK) return rc;
+    rc = uocr_need_workspace(ctx, NWEFF * sizeof(float));
+    if (rc != UOCR_OK) return rc;
+    float* weff = (float*)ctx->workspace;
+    hipLaunchKernelGGL(upconv_weff_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)w, weff);
+    const int strips = (wl + RW - 1) / RW, rows = up_rows_per_block(strips, hl, n);
+    hipLaunchKernelGGL(upconv_fwd_kernel, dim3(strips, (hl + rows - 1) / rows, n), dim3(256), 0, ctx->stream,
+                       (const float*)x_low, (const float*)weff, (const float*)b, (float*)y, hl, wl, rows, use_bias,
+                       act, (float)act_alpha);
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
+}
+
+extern "C" int uocr_upconv2x_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, const void* w, void* dx_low, int n,
+                                      int hl, int wl, int cin, int cout, int kh, int kw, int ph, int pw,
+                                      const void* x_act, int act, double act_alpha) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, dy && w && dx_low);
+    UOCR_REQUIRE(ctx, act == UOCR_ACT_NONE || x_act != nullptr);
+    int rc = check_up(ctx, dtype, n, hl, wl, cin, cout, kh, kw, ph, pw);
+    if (rc != UOCR_OK) return rc;
+    rc = uocr_need_workspace(ctx, NWEFF * sizeof(float));
+    if (rc != UOCR_OK) return rc;
+    float* weff = (float*)ctx->workspace;
+    hipLaunchKernelGGL(upconv_weff_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)w, weff);
+    hipLaunchKernelGGL(upconv_dgrad_kernel, dim3((wl + RW - 1) / RW, (hl + RH - 1) / RH, n), dim3(256), 0, ctx->stream,
+                       (const float*)dy, (const float*)weff, (float*)dx_low, hl, wl, (const float*)x_act, act,
+                       (float)act_alpha);
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
+}
+
+extern "C" int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_low, const void* dy, void* dw, void* db,
+                                        int n, int hl, int wl, int cin, int cout, int kh, int kw, int ph, int pw,
+                                        int use_bias, int accumulate) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, x_low && dy && dw && db);
+    int rc = check_up(ctx, dtype, n, hl, wl, cin, cout, kh, kw, ph, pw);
+    if (rc != UOCR_OK) return rc;
+    const int strips = (wl + RW - 1) / RW, rows = up_rows_per_block(strips, hl, n);
+    const int bands = (hl + rows - 1) / rows, nblocks = strips * bands * n;
+    rc = uocr_need_workspace(ctx, (size_t)nblocks * (36 * 16 + 4) * sizeof(float));
+    if (rc != UOCR_OK) return rc;
+    float* partial = (float*)ctx->workspace;
+    hipLaunchKernelGGL(upconv_wgrad_kernel, dim3(strips, bands, n), dim3(256), 0, ctx->stream, (const float*)x_low,
+                       (const float*)dy, partial, hl, wl, rows);
+    UOCR_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(upconv_wgrad_finish, dim3(404), dim3(256), 0, ctx->stream, (const float*)partial, (float*)dw,
+                       (float*)db, nblocks, use_bias, accumulate);
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
+}

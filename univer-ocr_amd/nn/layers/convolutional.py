@@ -100,6 +100,36 @@ class Convolutional2D(BaseLayerGPU):
         self.clear_memory()
         return [dx]
 
+    # Upsample2D(2) + this conv evaluated on the low-res tensor (Model._find_ups; csrc/conv_up.hip)
+    @track_method('forward')
+    def forward_up(self, x_low, activation=None):
+        x_low = ops.as_device(x_low)
+        assert x_low.shape[3] == self.in_channels
+        self._mem[0] = x_low
+        y = ops.upconv2x_fwd(x_low, self.w.value, self.b.value, self.padding, self.bias,
+                             None if activation is None else activation.kind,
+                             0.0 if activation is None else activation.alpha)
+        self._fused_out = y if activation is not None else None
+        return y
+
+    @track_method('backward')
+    def backward_up(self, grads, activation=None, act_grad_applied=False, input_activation=None):
+        """Returns the gradient w.r.t. the LOW-RES input (upsample backward included); the arguments as
+        backward_fused."""
+        grad = ops.as_device(make_list_if_not(grads)[0])
+        if activation is not None and not act_grad_applied:
+            grad = ops.act_bwd_from_output(activation.kind, self._fused_out, grad, activation.alpha)
+        x_low = self._mem[0]
+        ops.upconv2x_bwd_weight(x_low, grad, self.w.grad, self.b.grad, self.padding, self.bias, accumulate=True)
+        if input_activation is None:
+            dx = ops.upconv2x_bwd_data(grad, self.w.value, x_low.shape, self.padding)
+        else:
+            dx = ops.upconv2x_bwd_data(grad, self.w.value, x_low.shape, self.padding, x_act=x_low,
+                                       act=input_activation.kind, alpha=input_activation.alpha)
+        self._fused_out = None
+        self.clear_memory()
+        return dx
+
     # this conv as the SECOND of conv3x3(1->16)+LeakyReLU+conv3x3(16->1)[+Sigmoid]: one kernel each way
     # (Model._find_pairs; csrc/conv_pair.hip); `first` is the 1->16 conv whose output is never stored
     @track_method('forward')

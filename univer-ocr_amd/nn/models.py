@@ -196,9 +196,17 @@ class Model(BaseModel):
         fused_conv, fused_act = self._fusion_maps()
         pairs = self._active_pairs(inputs)
         pair_first = {first: second for second, (first, _, _) in pairs.items()}
+        ups = self._active_ups()
+        up_nodes = {up for up, _ in ups.values()}
         for node in self._plan:
-            if node in pair_first:                    # computed inside the pair kernel of its consumer
+            if node in pair_first or node in up_nodes:   # computed inside the kernel of its consumer
                 outputs[node] = None
+                continue
+            if node in ups:                           # upsample + conv on the low-res tensor
+                src = self.relations[ups[node][0]][0]
+                x_low = inputs[src] if isinstance(src, int) else outputs[src]
+                act = self.layers[fused_conv[node]] if node in fused_conv else None
+                outputs[node] = self.layers[node].forward_up(x_low, act)
                 continue
             if node in fused_act:                     # activation absorbed into its producing conv
                 outputs[node] = outputs[fused_act[node]]
@@ -221,6 +229,7 @@ class Model(BaseModel):
             outputs[k] = inputs[src] if isinstance(src, int) else outputs[src]
         self.layers_outputs = outputs
         self._pairs_used = pairs
+        self._ups_used = ups
         return [outputs[k] for k in range(self.outputs_count)]
 
     def _active_pairs(self, inputs):
@@ -247,10 +256,22 @@ class Model(BaseModel):
         fused_conv, fused_act = self._fusion_maps()
         pairs = getattr(self, '_pairs_used', {})
         pair_first = {first: second for second, (first, _, _) in pairs.items()}
+        ups = getattr(self, '_ups_used', {})
+        up_nodes = {up for up, _ in ups.values()}
         for node in reversed(self._plan):
             if node not in self.relations_backward:
                 continue
-            if node in pairs:                         # dW of both convs and dX of the first in one kernel
+            if node in ups:                           # dW, and dX w.r.t. the LOW-RES input, in one go
+                up_node, act_in = ups[node]
+                act = self.layers[fused_conv[node]] if node in fused_conv else None
+                dx_low = self.layers[node].backward_up(
+                    incoming(node), act, act_grad_applied=act is not None and self._act_folded(fused_conv[node]),
+                    input_activation=None if act_in is None else self.layers[act_in])
+                grads_mem[node] = [None]
+                grads_mem[up_node] = [dx_low]
+            elif node in up_nodes:
+                grads_mem.setdefault(node, [None])
+            elif node in pairs:                         # dW of both convs and dX of the first in one kernel
                 first, act_a, act_b = pairs[node]
                 dx = self.layers[node].backward_pair(
                     incoming(node), self.layers[first], self.layers[act_a],
@@ -263,7 +284,7 @@ class Model(BaseModel):
                 grads_mem[node] = [incoming(node)]
             elif node in fused_conv or node in self._fusion[2]:
                 act = self.layers[fused_conv[node]] if node in fused_conv else None
-                folded = node in fused_conv and fused_conv[node] in self._fusion[3]
+                folded = node in fused_conv and self._act_folded(fused_conv[node])
                 in_act = self._fusion[2].get(node)
                 grads_mem[node] = make_list_if_not(self.layers[node].backward_fused(
                     incoming(node), act, act_grad_applied=folded,
@@ -305,6 +326,7 @@ class Model(BaseModel):
         if not getattr(self, 'fuse_activations', False):
             self._fusion = ({}, {}, {}, set())
             self._pairs = {}
+            self._ups = {}
             return {}, {}
         if self._fusion is None:
             from .layers import Convolutional2D, LeakyRelu, Sigmoid
@@ -337,7 +359,44 @@ class Model(BaseModel):
                     folded.add(act_node)
             self._fusion = (fused_conv, fused_act, input_of, folded)
             self._pairs = self._find_pairs(fused_conv, input_of) if getattr(self, 'fuse_pairs', True) else {}
+            self._ups = self._find_ups(fused_act) if getattr(self, 'fuse_pairs', True) else {}
         return self._fusion[0], self._fusion[1]
+
+    def _find_ups(self, fused_act):
+        """Upsample2D(2) feeding only a 5x5 / stride 1 / padding 2 / 4->4 Convolutional2D -- the decoder blocks
+        of the Line net (my_model/model.py:194-247) -- runs as one op on the low-res tensor (csrc/conv_up.hip);
+        the upsampled tensor is never built.  Returns {conv: (upsample node, fused activation that feeds only
+        this upsample, or None)}; that activation's backward is folded into the op's dx epilogue."""
+        from .layers import Convolutional2D, Upsample2D
+        ups = {}
+        for node in self._plan:
+            layer = self.layers[node]
+            consumers = self.relations_backward.get(node, {})
+            if not isinstance(layer, Upsample2D) or tuple(layer.scale_factor) != (2, 2) or len(consumers) != 1:
+                continue
+            (dst, _), = consumers.items()
+            if isinstance(dst, int) or self.relations[dst] != [node]:
+                continue
+            conv = self.layers[dst]
+            if not (isinstance(conv, Convolutional2D) and conv.kernel_size == (5, 5) and conv.stride == (1, 1)
+                    and conv.padding == (2, 2) and conv.padding_value == 0
+                    and (conv.in_channels, conv.out_channels) == (4, 4)):
+                continue
+            src = self.relations[node]
+            act_in = None
+            if len(src) == 1 and src[0] in fused_act and len(self.relations_backward.get(src[0], {})) == 1:
+                act_in = src[0]
+            ups[dst] = (node, act_in)
+        return ups
+
+    def _active_ups(self):
+        """float32 only, like the pair kernels."""
+        ups = getattr(self, '_ups', {})
+        return {conv: v for conv, v in ups.items() if self.layers[conv].w.value.dtype == np.float32}
+
+    def _act_folded(self, act_node):
+        """Is the backward of this fused activation applied by its consumer's dx kernel?"""
+        return act_node in self._fusion[3] or any(a == act_node for _, a in getattr(self, '_ups_used', {}).values())
 
     def _find_pairs(self, fused_conv, input_of):
         """conv3x3(1->16, pad 1) + LeakyReLU feeding only conv3x3(16->1, pad 1) [+ Sigmoid] -- the

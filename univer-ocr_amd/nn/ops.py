@@ -106,6 +106,39 @@ def conv_pair_bwd(x, y, dy, w1, b1, w2, dw1, db1, dw2, db2, pad_value1=0.0, bias
     return dx
 
 
+def _up_dims(x_low_shape, w_shape, padding):
+    n, hl, wl, cin = x_low_shape
+    kh, kw, wcin, cout = w_shape
+    assert wcin == cin
+    return n, hl, wl, cin, cout, kh, kw, padding[0], padding[1]
+
+
+def upconv2x_fwd(x_low, w, b, padding, bias=True, act=None, alpha=0.0):
+    """Upsample2D(2) + conv (stride 1) on the low-res tensor (float32 5x5 4->4 only, see univer_hip.h)."""
+    dims = _up_dims(x_low.shape, w.shape, padding)
+    code = _same_dtype(x_low, w, b)
+    y = CP.empty((dims[0], 2 * dims[1], 2 * dims[2], dims[4]), x_low.dtype)
+    _rt().call('uocr_upconv2x_fwd', code, x_low.ptr, w.ptr, b.ptr, y.ptr, *dims, int(bool(bias)), ACT_CODES[act],
+               float(alpha))
+    return y
+
+
+def upconv2x_bwd_data(dy, w, x_low_shape, padding, x_act=None, act=None, alpha=0.0):
+    dims = _up_dims(x_low_shape, w.shape, padding)
+    code = _same_dtype(dy, w)
+    dx = CP.empty(x_low_shape, dy.dtype)
+    _rt().call('uocr_upconv2x_bwd_data', code, dy.ptr, w.ptr, dx.ptr, *dims, None if x_act is None else x_act.ptr,
+               ACT_CODES[act if x_act is not None else None], float(alpha))
+    return dx
+
+
+def upconv2x_bwd_weight(x_low, dy, dw, db, padding, bias=True, accumulate=True):
+    dims = _up_dims(x_low.shape, dw.shape, padding)
+    code = _same_dtype(x_low, dy, dw, db)
+    _rt().call('uocr_upconv2x_bwd_weight', code, x_low.ptr, dy.ptr, dw.ptr, db.ptr, *dims, int(bool(bias)),
+               int(bool(accumulate)))
+
+
 # ---- MaxPool2D ------------------------------------------------------------------------------------
 def pool_out_hw(h, w, ks, stride, padding, ceil_mode):
     """maxpool.py:204-216."""
