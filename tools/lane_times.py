@@ -1,0 +1,79 @@
+"""When does each net's lane finish inside the concurrent step?  (timing events at fork and at each join)"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from univer_ocr_amd.my_model.synthetic import make_page_batch
+from univer_ocr_amd.my_model.trainer import PageTrainer
+from univer_ocr_amd.nn import CP
+
+CP.use_gpu(0)
+CP.set_dtype('float32')
+CP.lazy_losses = True
+trainer = PageTrainer(32)
+context = trainer.make_context(make_page_batch(32, seed=1))
+for _ in range(5):
+    trainer.step(context)
+rt = CP.runtime()
+acc = {}
+reps = 20
+for _ in range(reps):
+    torch.cuda.synchronize()
+    main = torch.cuda.current_stream()
+    start = torch.cuda.Event(enable_timing=True)
+    start.record(main)
+    comps = trainer.model_system.components
+    mids, ends = {}, {}
+    for comp in comps:
+        with rt.lane(trainer.lanes[comp.name]) as stream:
+            stream.wait_event(start)
+            comp.selector(context)
+            X, y = next(comp.selector.get())
+            comp.model.train_begin(X, y)
+            mids[comp.name] = torch.cuda.Event(enable_timing=True)
+            mids[comp.name].record(stream)
+    for comp in comps:
+        with rt.lane(trainer.lanes[comp.name]) as stream:
+            comp.model.train_finish()
+            ends[comp.name] = torch.cuda.Event(enable_timing=True)
+            ends[comp.name].record(stream)
+    torch.cuda.synchronize()
+    for name in mids:
+        a = acc.setdefault(name, [0.0, 0.0])
+        a[0] += start.elapsed_time(mids[name])
+        a[1] += start.elapsed_time(ends[name])
+for name, (m, e) in acc.items():
+    print(f'{name:12s} fwd+bwd done at {m / reps:6.3f} ms, step done at {e / reps:6.3f} ms')
+
+# the same with the per-net HIP graphs (host enqueue out of the picture)
+trainer = PageTrainer(32, graphs=True)
+context = trainer.make_context(make_page_batch(32, seed=1))
+trainer.capture(context)
+for _ in range(3):
+    trainer.step(context)
+acc = {}
+for _ in range(reps):
+    torch.cuda.synchronize()
+    main = torch.cuda.current_stream()
+    start = torch.cuda.Event(enable_timing=True)
+    start.record(main)
+    mids, ends = {}, {}
+    for comp in trainer.model_system.components:
+        with rt.lane(trainer.lanes[comp.name]) as stream:
+            stream.wait_event(start)
+            trainer._captured[comp.name]['begin'].replay()
+            mids[comp.name] = torch.cuda.Event(enable_timing=True)
+            mids[comp.name].record(stream)
+            trainer._captured[comp.name]['finish'].replay()
+            ends[comp.name] = torch.cuda.Event(enable_timing=True)
+            ends[comp.name].record(stream)
+    torch.cuda.synchronize()
+    for name in mids:
+        a = acc.setdefault(name, [0.0, 0.0])
+        a[0] += start.elapsed_time(mids[name])
+        a[1] += start.elapsed_time(ends[name])
+print('with graphs:')
+for name, (m, e) in acc.items():
+    print(f'{name:12s} fwd+bwd done at {m / reps:6.3f} ms, step done at {e / reps:6.3f} ms')

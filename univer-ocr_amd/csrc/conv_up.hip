@@ -87,7 +87,7 @@ __device__ __forceinline__ void stage_planar(float* __restrict__ xs, const float
 
 // forward.  Block = 16 x 32 low-res positions per tile iteration over a band of rows; wave w owns rows
 // 4w..4w+3 (8 groups of 16 consecutive positions).
-__global__ __launch_bounds__(256) void upconv_fwd_kernel(const float* __restrict__ xl, const float* __restrict__ weff,
+__global__ __launch_bounds__(256) void upconv_fwd_kernel(const float* __restrict__ xl, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y,
                                                          int hl, int wl, int rows_per_block, int use_bias, int act,
                                                          float alpha) {
@@ -98,10 +98,19 @@ __global__ __launch_bounds__(256) void upconv_fwd_kernel(const float* __restrict
     const float* xb = xl + (size_t)blockIdx.z * hl * wl * CH;
     const int W = 2 * wl;
     float* yb = y + (size_t)blockIdx.z * (2 * hl) * W * CH;
-    // A = Weff^T: lane (m = (phase,o) = n, k = channel kq), one register per tap
+    // A = Weff^T: lane (m = (phase,o) = n, k = channel kq), one register per tap, summed here from the 25
+    // taps of w (each belongs to exactly one source offset for this lane's phase)
     float wa[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wa[t] = weff[(t * CH + kq) * 16 + n];
+    for (int t = 0; t < 9; ++t) {
+        int ylo, yhi, xlo, xhi;
+        tap_group(n >> 3, t / 3, ylo, yhi);
+        tap_group((n >> 2) & 1, t % 3, xlo, xhi);
+        float s = 0.f;
+        for (int ky = ylo; ky < yhi; ++ky)
+            for (int kx = xlo; kx < xhi; ++kx) s += w[((ky * 5 + kx) * CH + kq) * CH + (n & 3)];
+        wa[t] = s;
+    }
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (use_bias) b4 = f32x4{bias[0], bias[1], bias[2], bias[3]};
     for (int ry = row_begin; ry < row_end; ry += RH) {
@@ -329,13 +338,9 @@ extern "C" int uocr_upconv2x_fwd(uocr_ctx* ctx, int dtype, const void* x_low, co
     UOCR_REQUIRE(ctx, x_low && w && b && y);
     int rc = check_up(ctx, dtype, n, hl, wl, cin, cout, kh, kw, ph, pw);
     if (rc != UOCR_OK) return rc;
-    rc = uocr_need_workspace(ctx, NWEFF * sizeof(float));
-    if (rc != UOCR_OK) return rc;
-    float* weff = (float*)ctx->workspace;
-    hipLaunchKernelGGL(upconv_weff_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)w, weff);
     const int strips = (wl + RW - 1) / RW, rows = up_rows_per_block(strips, hl, n);
     hipLaunchKernelGGL(upconv_fwd_kernel, dim3(strips, (hl + rows - 1) / rows, n), dim3(256), 0, ctx->stream,
-                       (const float*)x_low, (const float*)weff, (const float*)b, (float*)y, hl, wl, rows, use_bias,
+                       (const float*)x_low, (const float*)w, (const float*)b, (float*)y, hl, wl, rows, use_bias,
                        act, (float)act_alpha);
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;

@@ -46,6 +46,7 @@ class PageTrainer:
         self.lanes = None
         if lanes and CP.has_device() and len(self.models) > 1:
             rt = CP.runtime()
+            # (high-priority streams for the latency-bound nets were tried: 1.44 -> 2.54 ms/step)
             self.lanes = {name: rt.add_lane() for name in self.models}
         # HIP graphs: each net's forward+loss+backward and its L2+optimizer tail are captured once and
         # replayed (two hipGraphLaunch per net and step instead of ~40 launches); needs lanes
@@ -123,6 +124,12 @@ class PageTrainer:
             context['losses'][comp.name] = comp.model.train_finish()
         return context['losses']
 
+    def _lane_order(self):
+        """Enqueue order of the lanes: the nets that are long chains of short kernels first (their chain is
+        the critical path of the concurrent step), the nets of few long kernels last."""
+        rank = {'Char': 0, 'Paragraph': 1, 'Line': 2, 'Monochrome': 3}
+        return sorted(self.model_system.components, key=lambda comp: rank.get(comp.name, 9))
+
     def _step_lanes(self, context):
         """Every net on its own stream.  The lanes start after everything already queued on the main
         stream (the inputs) and the main stream ends the step by waiting for all of them.  With data
@@ -139,7 +146,7 @@ class PageTrainer:
         start = torch.cuda.Event()
         start.record(main)
         context['losses'] = {}
-        comps = self.model_system.components
+        comps = self._lane_order()
         for comp in comps:
             with rt.lane(self.lanes[comp.name]) as stream:
                 stream.wait_event(start)
@@ -225,7 +232,7 @@ class PageTrainer:
         from ..nn.gpu import DeviceScalar
         rt = CP.runtime()
         main = torch.cuda.current_stream()
-        comps = self.model_system.components
+        comps = self._lane_order()
         copied = set()
         for label, static in self._statics.items():          # new batch -> the graphs' static inputs
             fresh = context[label]

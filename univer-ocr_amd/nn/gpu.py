@@ -54,7 +54,7 @@ class Runtime:
         self._lanes = [(self.ctx, self.stream)]      # lane 0 = the main stream
 
     # -- lanes: extra (context, stream) pairs so independent models run concurrently ---------------
-    def add_lane(self, workspace_mb=64):
+    def add_lane(self, workspace_mb=64, priority=0):
         """A further HIP context of the library with its own stream and workspace.  The four my_model
         nets are independent, so each trains on its own lane: the latency-bound kernels of the small
         nets run under the bandwidth-bound kernels of the large ones."""
@@ -63,7 +63,7 @@ class Runtime:
         rc = self.lib.uocr_ctx_create(self.device_index, int(workspace_mb) << 20, C.byref(handle))
         if rc != 0:
             raise HipError(f'uocr_ctx_create (lane) failed with code {rc}')
-        stream = torch.cuda.Stream(device=self.device)
+        stream = torch.cuda.Stream(device=self.device, priority=priority)   # -1 = high
         main = self.ctx
         self.ctx = handle
         self.call('uocr_ctx_set_stream', C.c_void_p(stream.cuda_stream))

@@ -27,6 +27,7 @@ class Param:
     def __init__(self, value, optimizer=None):
         self._value = CP.copy(value)
         self._grad = CP.zeros(self._value.shape, self._value.dtype)
+        self._pack = None                 # set by ParamPack: any access to .grad marks the flat buffer dirty
         self.optimizer = optimizer
         if optimizer is not None:
             optimizer.add_param(self)
@@ -55,6 +56,8 @@ class Param:
 
     @property
     def grad(self):
+        if self._pack is not None:
+            self._pack.grad_dirty = True
         return self._grad
 
     @grad.setter
@@ -83,20 +86,30 @@ class ParamPack:
             off += -(-size // PACK_ALIGN) * PACK_ALIGN
         self.total = max(off, PACK_ALIGN)
         self.value = CP.zeros((self.total,), self.dtype)
-        self.grad = CP.zeros((self.total,), self.dtype)
+        self._grad = CP.zeros((self.total,), self.dtype)
         for p, off, size in self.entries:
             v = self.view_of(self.value, off, size, p.value.shape)
-            g = self.view_of(self.grad, off, size, p.value.shape)
+            g = self.view_of(self._grad, off, size, p.value.shape)
             v.t.copy_(p._value.t)
             g.t.copy_(p._grad.t)
-            p._value, p._grad = v, g
+            p._value, p._grad, p._pack = v, g, self
+        self.grad_dirty = True            # False only right after zero_grad(): the next zero_grad() is then free
+
+    @property
+    def grad(self):
+        self.grad_dirty = True
+        return self._grad
 
     @staticmethod
     def view_of(flat, off, size, shape):
         return DeviceArray(flat.t[off:off + size].view(*shape))
 
     def zero_grad(self):
-        ops.zero_(self.grad)
+        """The reference zeroes every gradient at the start of forward AND after the update
+        (models.py:188,282); the second memset of the pair finds the buffer untouched and is skipped."""
+        if self.grad_dirty:
+            ops.zero_(self._grad)
+            self.grad_dirty = False
 
     def same_optimizer(self):
         opts = {id(p.optimizer) for p in self.params}

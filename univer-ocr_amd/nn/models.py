@@ -505,14 +505,16 @@ class Model(BaseModel):
         layers = [layer for layer in self.layers.values() if layer.regularizer is not None and layer.params()]
         if not layers:
             return 0
-        slot = CP.zeros((1,), np.float64)
         if self._pack is not None:
             # neighbouring parameters with the same regulariser are one range of the flat pack
-            # (alignment gaps hold zeros and contribute nothing): one launch per range
-            for (kind, strength), lo, hi in self._regularizer_ranges():
+            # (alignment gaps hold zeros and contribute nothing): one launch per range; the first
+            # range overwrites the loss slot, so the slot needs no zero-fill launch
+            slot = CP.empty((1,), np.float64)
+            for i, ((kind, strength), lo, hi) in enumerate(self._regularizer_ranges()):
                 ops.regularize(kind, self._pack.view_of(self._pack.value, lo, hi - lo, (hi - lo,)),
-                               self._pack.view_of(self._pack.grad, lo, hi - lo, (hi - lo,)), strength, slot, True)
+                               self._pack.view_of(self._pack.grad, lo, hi - lo, (hi - lo,)), strength, slot, i > 0)
         else:
+            slot = CP.zeros((1,), np.float64)
             for layer in layers:
                 layer.regularize(slot)
         return DeviceScalar(slot.t) if CP.lazy_losses else float(slot.t.item())
