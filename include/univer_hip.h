@@ -188,9 +188,11 @@ int uocr_convert(uocr_ctx* ctx, int src_dtype, const void* src, int dst_dtype, v
 int uocr_u8_to_float(uocr_ctx* ctx, int dtype, const uint8_t* src, void* dst, double scale, size_t count);
 
 /* ---- losses (losses.py) : grad tensor + float64 loss scalar at *loss_out (device) --------- */
+/* out_act = UOCR_ACT_SIGMOID: pred is the output of a Sigmoid layer (layers.py:407-418) and grad is taken
+ * w.r.t. that layer's INPUT (its backward folded in); UOCR_ACT_NONE: grad w.r.t. pred (losses.py:24,41) */
 int uocr_seg_loss(uocr_ctx* ctx, int dtype, int kind /*UOCR_LOSS_DICE|JACCARD*/, const void* pred,
                   const void* gt, void* grad /*may be NULL*/, double* loss_out,
-                  int n, int hw, int c);                                   /* losses.py:9-42 */
+                  int n, int hw, int c, int out_act);                                   /* losses.py:9-42 */
 int uocr_softmax_ce(uocr_ctx* ctx, int dtype, const void* pred, const void* gt, void* grad /*may be NULL*/,
                     double* loss_out, int m, int c);                       /* losses.py:60-73 */
 int uocr_sigmoid_ce(uocr_ctx* ctx, int dtype, const void* pred, const void* gt, void* grad /*may be NULL*/,

@@ -298,3 +298,28 @@ def test_upconv2x_rejects_other_shapes(f32):
     w, b = CP.copy(np.zeros((5, 5, 1, 1))), CP.copy(np.zeros(1))
     with pytest.raises(HipError, match='4 -> 4 channels only'):
         ops.upconv2x_fwd(x, w, b, (2, 2))
+
+
+@pytest.mark.parametrize('kind', ['dice', 'jaccard'])
+@pytest.mark.parametrize('shape', [(3, 9, 14, 2), (2, 100, 90, 1), (1, 1, 1, 1)])
+def test_seg_loss_with_folded_output_sigmoid(kind, shape, f32):
+    """uocr_seg_loss(out_act = sigmoid): the gradient w.r.t. the INPUT of the Sigmoid that produced pred
+    == oracle loss gradient times p (1 - p); loss value and plain gradient unchanged (several chunks per
+    image in the second shape)."""
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    rng = np.random.default_rng(sum(shape))
+    z = rng.standard_normal(shape)
+    pred = O.sigmoid_fwd(z)
+    gt = (rng.random(shape) > 0.6).astype(np.float64)
+    ref_loss, ref_grad = (O.dice_loss if kind == 'dice' else O.jaccard_loss)(pred, gt)
+    pd, gd = CP.copy(pred), CP.copy(gt)
+    loss, grad = ops.seg_loss(kind, pd, gd, True)
+    assert abs(float(loss) - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    check(grad, ref_grad, 1e-5, 'grad')
+    loss2, grad2 = ops.seg_loss(kind, pd, gd, True, out_act='sigmoid')
+    assert float(loss2) == float(loss)
+    p32 = pred.astype(np.float32).astype(np.float64)
+    check(grad2, ref_grad * p32 * (1 - p32), 1e-5, 'grad through sigmoid')
+    loss3, none = ops.seg_loss(kind, pd, gd, False)
+    assert none is None and float(loss3) == float(loss)

@@ -40,13 +40,46 @@ __global__ __launch_bounds__(256) void seg_partial_kernel(const T* __restrict__ 
     }
 }
 
-// stage 2 (one block): per pair num/den, loss = sum over pairs; stats[pair] = {num, den}
+// stage 2: block (chunk, pair) first sums its pair's chunk partials (num, den -> the gradient is LINEAR in
+// the label: dice r = (-2/den) g + 2 num/den^2 ; jaccard r = -((den + num)/den^2) g + num/den^2, the same
+// values as losses.py:24,41), then writes its pixel range; block (0,0) also adds up the loss of all pairs.
+// out_act == UOCR_ACT_SIGMOID: pred is the output of a Sigmoid and the gradient is taken w.r.t. that
+// Sigmoid's INPUT (r * p (1 - p)) -- folds the backward pass of a fused conv+Sigmoid output layer.
 template <int KIND>
-__global__ __launch_bounds__(256) void seg_finish_kernel(const double* __restrict__ partial, double* __restrict__ stats,
-                                                         double* __restrict__ loss_out, int npairs, int nchunks) {
+__device__ __forceinline__ void seg_num_den(double s_pg, double s_p, double s_g, double& num, double& den) {
+    num = s_pg + SEG_EPS;
+    den = KIND == UOCR_LOSS_DICE ? s_p + s_g + 2 * SEG_EPS             // losses.py:19-20
+                                 : s_p + s_g - num + 2 * SEG_EPS;      // losses.py:38
+}
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void seg_grad_kernel(const T* __restrict__ pred, const T* __restrict__ gt,
+                                                       const double* __restrict__ partial, T* __restrict__ grad,
+                                                       double* __restrict__ loss_out, int hw, int c, int nchunks,
+                                                       int npairs, int out_act) {
     __shared__ double smem[16];
-    double loss = 0.0;
-    for (int pair = threadIdx.x; pair < npairs; pair += blockDim.x) {
+    __shared__ double coef[2];
+    const int chunk = blockIdx.x, pair = blockIdx.y;
+    if (chunk == 0 && pair == 0) {                       // the loss: sum over all pairs
+        double loss = 0.0;
+        for (int q = threadIdx.x; q < npairs; q += blockDim.x) {
+            double s_pg = 0.0, s_p = 0.0, s_g = 0.0;
+            for (int k = 0; k < nchunks; ++k) {
+                const double* o = partial + ((size_t)q * nchunks + k) * 3;
+                s_pg += o[0];
+                s_p += o[1];
+                s_g += o[2];
+            }
+            double num, den;
+            seg_num_den<KIND>(s_pg, s_p, s_g, num, den);
+            loss += KIND == UOCR_LOSS_DICE ? 1.0 - 2.0 * num / den : 1.0 - num / den;   // losses.py:22,40
+        }
+        loss = block_reduce_sum(loss, smem);
+        if (threadIdx.x == 0) *loss_out = loss;
+        __syncthreads();
+    }
+    if (!grad) return;
+    if (threadIdx.x == 0) {                              // nchunks <= 64: a serial sum in chunk order
         double s_pg = 0.0, s_p = 0.0, s_g = 0.0;
         for (int k = 0; k < nchunks; ++k) {
             const double* o = partial + ((size_t)pair * nchunks + k) * 3;
@@ -54,34 +87,29 @@ __global__ __launch_bounds__(256) void seg_finish_kernel(const double* __restric
             s_p += o[1];
             s_g += o[2];
         }
-        const double num = s_pg + SEG_EPS;
-        double den;
+        double num, den;
+        seg_num_den<KIND>(s_pg, s_p, s_g, num, den);
         if (KIND == UOCR_LOSS_DICE) {
-            den = s_p + s_g + 2 * SEG_EPS;            // losses.py:19-20
-            loss += 1.0 - 2.0 * num / den;            // :22
+            coef[0] = -2.0 / den;
+            coef[1] = 2.0 * num / (den * den);
         } else {
-            den = s_p + s_g - num + 2 * SEG_EPS;      // losses.py:38
-            loss += 1.0 - num / den;                  // :40
+            coef[0] = -(den + num) / (den * den);
+            coef[1] = num / (den * den);
         }
-        stats[2 * pair] = num;
-        stats[2 * pair + 1] = den;
     }
-    loss = block_reduce_sum(loss, smem);
-    if (threadIdx.x == 0) *loss_out = loss;
-}
-
-// stage 3: dice grad = -2 (g den - num) / den^2 ; jaccard grad = -(g den - num (1 - g)) / den^2
-template <typename T, int KIND>
-__global__ __launch_bounds__(256) void seg_grad_kernel(const T* __restrict__ gt, const double* __restrict__ stats,
-                                                       T* __restrict__ grad, size_t total, int hwc, int c) {
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int b = (int)(idx / hwc), ch = (int)(idx % c);
-        const double num = stats[2 * (b * c + ch)], den = stats[2 * (b * c + ch) + 1];
-        const double g = (double)gt[idx];
-        double r;
-        if (KIND == UOCR_LOSS_DICE) r = -2.0 * (g * den - num) / (den * den);
-        else r = -(g * den - num * (1.0 - g)) / (den * den);
+    __syncthreads();
+    const double ca = coef[0], cb = coef[1];
+    const int b = pair / c, ch = pair % c;
+    const int per = (hw + nchunks - 1) / nchunks;
+    const int p0 = chunk * per, p1 = min(hw, p0 + per);
+    const size_t base = (size_t)b * hw * c + ch;
+    for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+        const size_t idx = base + (size_t)p * c;
+        double r = ca * (double)gt[idx] + cb;
+        if (out_act == UOCR_ACT_SIGMOID) {
+            const double pv = (double)pred[idx];
+            r *= pv * (1.0 - pv);
+        }
         grad[idx] = (T)r;
     }
 }
@@ -139,42 +167,34 @@ __global__ __launch_bounds__(256) void sigmoid_ce_kernel(const T* __restrict__ p
 extern "C" {
 
 int uocr_seg_loss(uocr_ctx* ctx, int dtype, int kind, const void* pred, const void* gt, void* grad,
-                  double* loss_out, int n, int hw, int c) {
+                  double* loss_out, int n, int hw, int c, int out_act) {
     UOCR_CHECK_CTX(ctx);
     UOCR_REQUIRE(ctx, pred && gt && loss_out && n > 0 && hw > 0 && c > 0);
     UOCR_REQUIRE(ctx, kind == UOCR_LOSS_DICE || kind == UOCR_LOSS_JACCARD);
+    UOCR_REQUIRE(ctx, out_act == UOCR_ACT_NONE || out_act == UOCR_ACT_SIGMOID);
     const int npairs = n * c;
     int nchunks = (hw + 8191) / 8192;
     if (nchunks > 64) nchunks = 64;
     const size_t part_bytes = (size_t)npairs * nchunks * 3 * sizeof(double);
-    const size_t stats_bytes = (size_t)npairs * 2 * sizeof(double);
-    int rc = uocr_need_workspace(ctx, part_bytes + stats_bytes);
+    int rc = uocr_need_workspace(ctx, part_bytes);
     if (rc) return rc;
     double* partial = (double*)ctx->workspace;
-    double* stats = (double*)((char*)ctx->workspace + part_bytes);
-    const size_t total = (size_t)n * hw * c;
     UOCR_REQUIRE(ctx, (size_t)hw * c < (size_t)INT32_MAX && npairs <= 65535);
     UOCR_DISPATCH(ctx, dtype, {
         hipLaunchKernelGGL((seg_partial_kernel<T>), dim3(nchunks, npairs), dim3(256), 0, ctx->stream, (const T*)pred,
                            (const T*)gt, partial, hw, c, nchunks);
         UOCR_LAUNCH_CHECK(ctx);
+        // without a gradient only block (0,0) has work
+        const dim3 grid = grad ? dim3(nchunks, npairs) : dim3(1, 1);
         if (kind == UOCR_LOSS_DICE)
-            hipLaunchKernelGGL((seg_finish_kernel<UOCR_LOSS_DICE>), dim3(1), dim3(256), 0, ctx->stream,
-                               (const double*)partial, stats, loss_out, npairs, nchunks);
+            hipLaunchKernelGGL((seg_grad_kernel<T, UOCR_LOSS_DICE>), grid, dim3(256), 0, ctx->stream, (const T*)pred,
+                               (const T*)gt, (const double*)partial, (T*)grad, loss_out, hw, c, nchunks, npairs,
+                               out_act);
         else
-            hipLaunchKernelGGL((seg_finish_kernel<UOCR_LOSS_JACCARD>), dim3(1), dim3(256), 0, ctx->stream,
-                               (const double*)partial, stats, loss_out, npairs, nchunks);
+            hipLaunchKernelGGL((seg_grad_kernel<T, UOCR_LOSS_JACCARD>), grid, dim3(256), 0, ctx->stream,
+                               (const T*)pred, (const T*)gt, (const double*)partial, (T*)grad, loss_out, hw, c,
+                               nchunks, npairs, out_act);
         UOCR_LAUNCH_CHECK(ctx);
-        if (grad) {
-            const dim3 grid(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4));
-            if (kind == UOCR_LOSS_DICE)
-                hipLaunchKernelGGL((seg_grad_kernel<T, UOCR_LOSS_DICE>), grid, dim3(256), 0, ctx->stream,
-                                   (const T*)gt, (const double*)stats, (T*)grad, total, hw * c, c);
-            else
-                hipLaunchKernelGGL((seg_grad_kernel<T, UOCR_LOSS_JACCARD>), grid, dim3(256), 0, ctx->stream,
-                                   (const T*)gt, (const double*)stats, (T*)grad, total, hw * c, c);
-            UOCR_LAUNCH_CHECK(ctx);
-        }
     });
     return UOCR_OK;
 }

@@ -80,7 +80,7 @@ _PROTOS = {
     'uocr_fill': [_ctx, _i, _vp, _d, _sz],
     'uocr_convert': [_ctx, _i, _vp, _i, _vp, _sz],
     'uocr_u8_to_float': [_ctx, _i, _vp, _vp, _d, _sz],
-    'uocr_seg_loss': [_ctx, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i],
+    'uocr_seg_loss': [_ctx, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
     'uocr_softmax_ce': [_ctx, _i, _vp, _vp, _vp, _vp, _i, _i],
     'uocr_sigmoid_ce': [_ctx, _i, _vp, _vp, _vp, _vp, _i, _sz],
     'uocr_l2_reg': [_ctx, _i, _vp, _vp, _sz, _d, _vp, _i],

@@ -15,16 +15,20 @@ class BaseLoss:
 
 
 class SegmentationDice2D(BaseLoss):
-    def __call__(self, prediction, ground_truth, need_grad=True):
-        return ops.seg_loss('dice', ops.as_device(prediction), ops.as_device(ground_truth), need_grad)
+    folds_sigmoid = True      # __call__(..., out_act='sigmoid'): gradient w.r.t. the input of a fused output Sigmoid
+
+    def __call__(self, prediction, ground_truth, need_grad=True, out_act=None):
+        return ops.seg_loss('dice', ops.as_device(prediction), ops.as_device(ground_truth), need_grad, out_act)
 
     def value_only(self, prediction, ground_truth):
         return self(prediction, ground_truth, need_grad=False)[0]
 
 
 class SegmentationJaccard2D(BaseLoss):
-    def __call__(self, prediction, ground_truth, need_grad=True):
-        return ops.seg_loss('jaccard', ops.as_device(prediction), ops.as_device(ground_truth), need_grad)
+    folds_sigmoid = True
+
+    def __call__(self, prediction, ground_truth, need_grad=True, out_act=None):
+        return ops.seg_loss('jaccard', ops.as_device(prediction), ops.as_device(ground_truth), need_grad, out_act)
 
     def value_only(self, prediction, ground_truth):
         return self(prediction, ground_truth, need_grad=False)[0]

@@ -395,8 +395,22 @@ class Model(BaseModel):
         return {conv: v for conv, v in ups.items() if self.layers[conv].w.value.dtype == np.float32}
 
     def _act_folded(self, act_node):
-        """Is the backward of this fused activation applied by its consumer's dx kernel?"""
-        return act_node in self._fusion[3] or any(a == act_node for _, a in getattr(self, '_ups_used', {}).values())
+        """Is the backward of this fused activation applied by its consumer (a conv's dx kernel, or the
+        loss kernel for an output Sigmoid)?"""
+        return act_node in self._fusion[3] or act_node in getattr(self, '_loss_folded', ()) or \
+            any(a == act_node for _, a in getattr(self, '_ups_used', {}).values())
+
+    def _foldable_output_sigmoid(self, key):
+        """Model output `key` = a Sigmoid fused into its conv (not a pair kernel, which applies Sigmoid'
+        itself) and consumed by nothing else: its backward can move into the loss-gradient kernel."""
+        from .layers import Sigmoid
+        node = self.relations[key][0]
+        fused_act = self._fusion[1] if self._fusion else {}
+        if isinstance(node, int) or node not in fused_act or not isinstance(self.layers[node], Sigmoid):
+            return None
+        if fused_act[node] in getattr(self, '_pairs_used', {}) or len(self.relations_backward.get(node, {})) != 1:
+            return None
+        return node
 
     def _find_pairs(self, fused_conv, input_of):
         """conv3x3(1->16, pad 1) + LeakyReLU feeding only conv3x3(16->1, pad 1) [+ Sigmoid] -- the
@@ -427,11 +441,19 @@ class Model(BaseModel):
         predicted = self.forward(make_list_if_not(X))
         y = make_list_if_not(y)
         losses, gradients = [], []
+        self._loss_folded = set()
         for key in range(self.outputs_count):
-            loss, grad = self._loss_func(key)(predicted[key], ops.as_device(y[key]))
+            func, act_node = self._loss_func(key), self._foldable_output_sigmoid(key)
+            if act_node is not None and getattr(func, 'folds_sigmoid', False):
+                # the loss kernel writes the gradient w.r.t. the INPUT of the fused output Sigmoid
+                loss, grad = func(predicted[key], ops.as_device(y[key]), out_act='sigmoid')
+                self._loss_folded.add(act_node)
+            else:
+                loss, grad = func(predicted[key], ops.as_device(y[key]))
             losses.append(loss)
             gradients.append(grad)
         self.backward(gradients)
+        self._loss_folded = set()
         if self.grad_sync is not None:
             self.grad_sync(self)                      # data parallel: RCCL all-reduce of pack.grad
         return losses

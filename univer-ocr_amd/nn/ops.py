@@ -317,14 +317,15 @@ def _finish_loss(slot):
     return DeviceScalar(slot.t) if CP.lazy_losses else float(slot.t.item())
 
 
-def seg_loss(kind, pred, gt, need_grad=True):
+def seg_loss(kind, pred, gt, need_grad=True, out_act=None):
+    """out_act='sigmoid': pred is a Sigmoid output and the gradient is w.r.t. the Sigmoid's input."""
     n, h, w, c = pred.shape
     if gt.shape != pred.shape:
         raise AssertionError(f'ground truth {gt.shape} != prediction {pred.shape}')
     grad = CP.empty(pred.shape, pred.dtype) if need_grad else None
     slot = _loss_slot()
     _rt().call('uocr_seg_loss', _same_dtype(pred, gt), hiplib.LOSS_DICE if kind == 'dice' else hiplib.LOSS_JACCARD,
-               pred.ptr, gt.ptr, grad.ptr if need_grad else None, slot.ptr, n, h * w, c)
+               pred.ptr, gt.ptr, grad.ptr if need_grad else None, slot.ptr, n, h * w, c, ACT_CODES[out_act])
     return _finish_loss(slot), grad
 
 
