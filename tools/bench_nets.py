@@ -14,6 +14,8 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--skip-input-grads', action='store_true')
     ap.add_argument('--graphs', action='store_true')
+    ap.add_argument('--option', action='append', default=[], help='ctx option key=value (applied to every lane)')
+    ap.add_argument('--only', default='', help='comma-separated nets: time just this combination')
     args = ap.parse_args()
     import torch
     from univer_ocr_amd.my_model.synthetic import make_page_batch
@@ -24,9 +26,13 @@ def main():
     CP.lazy_losses = True          # as bench.py: losses stay on the device until read
     layers = make_page_batch(args.batch, 256, 512, 64, seed=1)
     all_nets = ('Monochrome', 'Paragraph', 'Line', 'Char')
-    for nets in [(n,) for n in all_nets] + [all_nets]:
+    combos = [tuple(args.only.split(','))] if args.only else [(n,) for n in all_nets] + [all_nets]
+    for nets in combos:
         trainer = PageTrainer(args.batch, 256, 512, 64, nets=nets, input_grads=not args.skip_input_grads,
                               graphs=args.graphs)
+        for opt in args.option:
+            k, v = opt.split('=')
+            CP.runtime().set_option(k, int(v))
         context = trainer.make_context(layers)
         for _ in range(5):
             trainer.step(context)

@@ -422,8 +422,11 @@ int launch_mfma(uocr_ctx* ctx, const ALoader& A, const BRowMajor& B, const Epilo
     int nsplit = 1;
     // Small GEMMs are latency-bound per block (a depth tile is ~1k MFMA cycles against a 1-2 us global
     // load round trip), so aim for ~4 resident blocks per CU: split the depth until there are ~1024 blocks
-    if (allow_split && gm * gn < 1024 && ntiles >= 4) {
-        nsplit = (1024 + gm * gn - 1) / (gm * gn);
+    // (a fused reduction by the last-arriving block was tried: the agent-scope release/acquire it needs
+    // writes back and invalidates the XCD's L2 per block -- the Char net went from 0.57 to 2.55 ms/step)
+    const int target = ctx->opt_split;
+    if (allow_split && target > 0 && gm * gn < target && ntiles >= 4) {
+        nsplit = (target + gm * gn - 1) / (gm * gn);
         if (nsplit > ntiles / 2) nsplit = ntiles / 2;
         if (nsplit > 32) nsplit = 32;
         const size_t per = (size_t)M * N * sizeof(float);

@@ -19,10 +19,26 @@ __global__ __launch_bounds__(256) void seg_partial_kernel(const T* __restrict__ 
     const int chunk = blockIdx.x, pair = blockIdx.y;
     const int b = pair / c, ch = pair % c;
     const int per = (hw + nchunks - 1) / nchunks;
-    const int p0 = chunk * per, p1 = min(hw, p0 + per);
+    const int p0 = chunk * per;
+    int p1 = min(hw, p0 + per);
     const T* pp = pred + (size_t)b * hw * c + ch;
     const T* gp = gt + (size_t)b * hw * c + ch;
     double s_pg = 0.0, s_p = 0.0, s_g = 0.0;
+    if constexpr (sizeof(T) == 4) {
+        // one channel, 16-byte aligned rows: 4 pixels per load (the per-chunk sums only change their order
+        // of addition within a thread)
+        if (c == 1 && (hw & 3) == 0 && (per & 3) == 0 && ((uintptr_t)pred & 15) == 0 && ((uintptr_t)gt & 15) == 0) {
+            const float4* p4 = reinterpret_cast<const float4*>(pp);
+            const float4* g4 = reinterpret_cast<const float4*>(gp);
+            for (int q = p0 / 4 + threadIdx.x; q < p1 / 4; q += blockDim.x) {
+                const float4 pv = p4[q], gv = g4[q];
+                s_pg += (double)pv.x * gv.x + (double)pv.y * gv.y + (double)pv.z * gv.z + (double)pv.w * gv.w;
+                s_p += (double)pv.x + (double)pv.y + (double)pv.z + (double)pv.w;
+                s_g += (double)gv.x + (double)gv.y + (double)gv.z + (double)gv.w;
+            }
+            p1 = p0;                                     // nothing left for the scalar loop
+        }
+    }
     for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
         const double pv = (double)pp[(size_t)p * c], gv = (double)gp[(size_t)p * c];
         s_pg += pv * gv;
@@ -101,8 +117,32 @@ __global__ __launch_bounds__(256) void seg_grad_kernel(const T* __restrict__ pre
     const double ca = coef[0], cb = coef[1];
     const int b = pair / c, ch = pair % c;
     const int per = (hw + nchunks - 1) / nchunks;
-    const int p0 = chunk * per, p1 = min(hw, p0 + per);
+    const int p0 = chunk * per;
+    int p1 = min(hw, p0 + per);
     const size_t base = (size_t)b * hw * c + ch;
+    if constexpr (sizeof(T) == 4) {
+        if (c == 1 && (hw & 3) == 0 && (per & 3) == 0 && ((uintptr_t)pred & 15) == 0 && ((uintptr_t)gt & 15) == 0 &&
+            ((uintptr_t)grad & 15) == 0) {
+            const float4* p4 = reinterpret_cast<const float4*>(pred + base);
+            const float4* g4 = reinterpret_cast<const float4*>(gt + base);
+            float4* o4 = reinterpret_cast<float4*>(grad + base);
+            const bool sig = out_act == UOCR_ACT_SIGMOID;
+            for (int q = p0 / 4 + threadIdx.x; q < p1 / 4; q += blockDim.x) {
+                const float4 gv = g4[q];
+                double r[4] = {ca * (double)gv.x + cb, ca * (double)gv.y + cb, ca * (double)gv.z + cb,
+                               ca * (double)gv.w + cb};
+                if (sig) {
+                    const float4 pv = p4[q];
+                    r[0] *= (double)pv.x * (1.0 - (double)pv.x);
+                    r[1] *= (double)pv.y * (1.0 - (double)pv.y);
+                    r[2] *= (double)pv.z * (1.0 - (double)pv.z);
+                    r[3] *= (double)pv.w * (1.0 - (double)pv.w);
+                }
+                o4[q] = make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
+            }
+            p1 = p0;
+        }
+    }
     for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
         const size_t idx = base + (size_t)p * c;
         double r = ca * (double)gt[idx] + cb;

@@ -17,6 +17,7 @@ struct uocr_ctx {
     int opt_mfma;        // 0 = never, 1 = auto (default), 2 = whenever eligible (tests)
     int opt_fast;        // 0 = generic kernels only, 1 = shape-specialised fast paths (default)
     int opt_tiled;       // 0 = no LDS-tiled conv kernels, 1 = use them where instantiated (default)
+    int opt_split;       // MFMA GEMMs split their depth until there are about this many blocks (0 = never)
     char err[512];
 };
 
