@@ -215,6 +215,21 @@ struct AConvDgrad {
         if (gy * d.sh != ty || gx * d.sw != tx || gy >= d.oh || gx >= d.ow) return f4_zero();
         return *reinterpret_cast<const F4*>(dy + (((long)r.b * d.oh + gy) * d.ow + gx) * d.cout + c0);
     }
+    // A strided transposed conv multiplies structural zeros: input row y only receives tap rows ky with
+    // (y + ph - ky) divisible by the stride and inside the output.  When the BM rows of a block lie in ONE
+    // image row (Char net: w = 64 = BM) whole depth tiles are zero for the block and are skipped
+    // (stride (2,1), kh = 5: 2 or 3 of 5 tap rows remain).
+    __device__ __forceinline__ bool tile_is_zero(int m0, int bm, int tile) const {
+        const int last = min(m0 + bm, m) - 1;
+        const int r0 = m0 / d.w, r1 = last / d.w;
+        if (r0 != r1) return false;
+        const int y = r0 % d.h;
+        const int kk = tile / (d.cout / BD), ky = kk / d.kw;
+        const int ty = y + d.ph - ky;
+        if (ty < 0) return true;
+        const int gy = ty / d.sh;
+        return gy * d.sh != ty || gy >= d.oh;
+    }
 };
 
 // conv dw/db: rows = (ky,kx,ic) [+ one bias row], depth = output pixels; requires cin % 4 == 0
@@ -334,15 +349,23 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, 
     const int fk = lane >> 5;                    // depth offset inside a 2-deep MFMA step
     const int fj = wn * (BN / WN) + (lane & 31); // B fragment column (first 32x32 block)
 
-    if (t_begin < t_end) {
-        load_tile(t_begin);
+    // depth tiles that are zero for the whole block (block-uniform) are stepped over
+    auto next_tile = [&](int t) {
+        if constexpr (requires { A.tile_is_zero(0, 0, 0); }) {
+            while (t < t_end && A.tile_is_zero(m0, BM, t)) ++t;
+        }
+        return t;
+    };
+    int t = next_tile(t_begin);
+    if (t < t_end) {
+        load_tile(t);
         store_tile(0);
     }
     __syncthreads();
-    for (int t = t_begin; t < t_end; ++t) {
-        const int buf = (t - t_begin) & 1;
-        const bool more = t + 1 < t_end;
-        if (more) load_tile(t + 1);
+    for (int buf = 0; t < t_end; buf ^= 1) {
+        const int tn = next_tile(t + 1);
+        const bool more = tn < t_end;
+        if (more) load_tile(tn);
         const float* as = As[buf];
         const float* bs = Bs[buf];
 #pragma unroll
@@ -356,6 +379,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, 
         }
         if (more) store_tile(buf ^ 1);
         __syncthreads();
+        t = tn;
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
