@@ -252,8 +252,9 @@ UP_SHAPES = [(2, 16, 32), (3, 7, 19), (1, 1, 1), (2, 33, 40), (1, 5, 70), (4, 40
 
 
 @pytest.mark.parametrize('shape', UP_SHAPES)
+@pytest.mark.parametrize('ch', [4, 1])
 @pytest.mark.parametrize('bias,act', [(True, 'leaky'), (False, None)])
-def test_upconv2x_kernels_against_oracle(shape, bias, act, f32):
+def test_upconv2x_kernels_against_oracle(shape, ch, bias, act, f32):
     """uocr_upconv2x_* (Upsample2D(2) + 5x5 conv 4->4 evaluated on the low-res tensor as a 3x3 conv to 16
     phase channels) == the oracle's upsample followed by its conv, forward, dx (with and without the
     LeakyReLU' epilogue) and dw/db: ragged tiles, images smaller than a tile, several row bands."""
@@ -261,9 +262,9 @@ def test_upconv2x_kernels_against_oracle(shape, bias, act, f32):
     CP = f32
     n, hl, wl = shape
     rng = np.random.default_rng(sum(shape) + 7)
-    xl = rng.standard_normal((n, hl, wl, 4))
-    w = rng.standard_normal((5, 5, 4, 4)) * 0.1
-    b = rng.standard_normal(4)
+    xl = rng.standard_normal((n, hl, wl, ch))
+    w = rng.standard_normal((5, 5, ch, ch)) * 0.1
+    b = rng.standard_normal(ch)
     alpha = 0.01
     xu = O.upsample2d_fwd(xl, (2, 2))
     z = O.conv2d_fwd(xu, w, b, 1, 2, 0.0, bias)
@@ -294,9 +295,9 @@ def test_upconv2x_rejects_other_shapes(f32):
     from univer_ocr_amd.hip.lib import HipError
     from univer_ocr_amd.nn import ops
     CP = f32
-    x = CP.copy(np.zeros((1, 4, 4, 1)))
-    w, b = CP.copy(np.zeros((5, 5, 1, 1))), CP.copy(np.zeros(1))
-    with pytest.raises(HipError, match='4 -> 4 channels only'):
+    x = CP.copy(np.zeros((1, 4, 4, 2)))
+    w, b = CP.copy(np.zeros((5, 5, 2, 2))), CP.copy(np.zeros(2))
+    with pytest.raises(HipError, match='channels only'):
         ops.upconv2x_fwd(x, w, b, (2, 2))
 
 

@@ -216,10 +216,11 @@ def test_fused_activation_graph_matches_reference(net_name, dt):
     X, y = CP.copy(g['sgd/X']), CP.copy(g['sgd/y'])
     close(model.predict(X)[0], g['sgd/pred0'], PASS_TOL[dt], 'pred0')
     # the multi-layer kernels exist in float32 only: Monochrome = one conv pair (csrc/conv_pair.hip), Line =
+    # Line / Paragraph =
     # two upsample+conv blocks on the low-res tensor (csrc/conv_up.hip); float64 runs layer by layer
     f32 = np.dtype(dt) == np.float32
     assert len(model._pairs_used) == (1 if f32 and net_name == 'Monochrome' else 0)
-    assert len(model._ups_used) == (2 if f32 and net_name == 'Line' else 0)
+    assert len(model._ups_used) == (2 if f32 and net_name in ('Line', 'Paragraph') else 0)
     losses = model.compute_loss_and_gradients(X, y)
     close(losses_row(losses), g['sgd/grad_loss'], PASS_TOL[dt], 'loss')
     close(model.input_grads[0], g['sgd/input_grad'], PASS_TOL[dt] * 2, 'input_grad')

@@ -314,6 +314,188 @@ __global__ __launch_bounds__(256) void upconv_dgrad_kernel(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 1 -> 1 channel (Paragraph decoder): 36 multiply-adds per low-res position, everything on the vector ALU;
+// the kernels are bound by their HBM bytes (low-res tensor + high-res tensor) and launch latency.
+// weff1[m*4 + phase], built per thread from the 25 taps (uniform loads)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void weff1_build(float (&we)[36], const float* __restrict__ w) {
+#pragma unroll
+    for (int m = 0; m < 9; ++m)
+#pragma unroll
+        for (int phase = 0; phase < 4; ++phase) {
+            int ylo, yhi, xlo, xhi;
+            tap_group(phase >> 1, m / 3, ylo, yhi);
+            tap_group(phase & 1, m % 3, xlo, xhi);
+            float s = 0.f;
+            for (int ky = ylo; ky < yhi; ++ky)
+                for (int kx = xlo; kx < xhi; ++kx) s += w[ky * 5 + kx];
+            we[m * 4 + phase] = s;
+        }
+}
+
+// block = 16 x 32 low-res positions, 2 per thread (rows r0 and r0 + 8)
+__global__ __launch_bounds__(256) void up1_fwd_kernel(const float* __restrict__ xl, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y, int hl,
+                                                      int wl, int use_bias, int act, float alpha) {
+    __shared__ float xs[XH * XW];
+    const int tid = threadIdx.x;
+    const int rx = blockIdx.x * RW, ry = blockIdx.y * RH;
+    const float* xb = xl + (size_t)blockIdx.z * hl * wl;
+    for (int i = tid; i < XH * XW; i += 256) {
+        const int r = i / XW, c = i - r * XW;
+        const int gy = ry - 1 + r, gx = rx - 1 + c;
+        xs[i] = (gy >= 0 && gy < hl && gx >= 0 && gx < wl) ? xb[(size_t)gy * wl + gx] : 0.f;
+    }
+    float we[36];
+    weff1_build(we, w);
+    const float b0 = use_bias ? bias[0] : 0.f;
+    __syncthreads();
+    const int c = tid & 31, r0 = tid >> 5;
+    const int W = 2 * wl;
+    float* yb = y + (size_t)blockIdx.z * (2 * hl) * W;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = r0 + 8 * p, py = ry + r, pxl = rx + c;
+        float acc[4] = {b0, b0, b0, b0};
+#pragma unroll
+        for (int m = 0; m < 9; ++m) {
+            const float xv = xs[(r + m / 3) * XW + c + m % 3];
+#pragma unroll
+            for (int phase = 0; phase < 4; ++phase) acc[phase] += xv * we[m * 4 + phase];
+        }
+        if (py < hl && pxl < wl) {
+            float* o = yb + (size_t)(2 * py) * W + 2 * pxl;
+            *reinterpret_cast<float2*>(o) = make_float2(act_apply(acc[0], act, alpha), act_apply(acc[1], act, alpha));
+            *reinterpret_cast<float2*>(o + W) = make_float2(act_apply(acc[2], act, alpha), act_apply(acc[3], act, alpha));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void up1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                        float* __restrict__ dxl, int hl, int wl,
+                                                        const float* __restrict__ mask_y, int mask_act,
+                                                        float mask_alpha) {
+    __shared__ float gs[GH * GW];
+    const int tid = threadIdx.x;
+    const int rx = blockIdx.x * RW, ry = blockIdx.y * RH;
+    const int H = 2 * hl, W = 2 * wl;
+    const float* gb = dy + (size_t)blockIdx.z * H * W;
+    for (int i = tid; i < GH * GW; i += 256) {
+        const int r = i / GW, c = i - r * GW;
+        const int gy = 2 * (ry - 1) + r, gx = 2 * (rx - 1) + c;
+        gs[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gb[(size_t)gy * W + gx] : 0.f;
+    }
+    float we[36];
+    weff1_build(we, w);
+    __syncthreads();
+    const int c = tid & 31, r0 = tid >> 5;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = r0 + 8 * p;
+        float acc = 0.f;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) {
+            const int my = m / 3 - 1, mx = m % 3 - 1;
+            const float* g0 = gs + (2 * (r - my + 1)) * GW + 2 * (c - mx + 1);   // source block Q - m
+            acc += we[m * 4] * g0[0] + we[m * 4 + 1] * g0[1] + we[m * 4 + 2] * g0[GW] + we[m * 4 + 3] * g0[GW + 1];
+        }
+        const int qy = ry + r, qx = rx + c;
+        if (qy >= hl || qx >= wl) continue;
+        const size_t off = ((size_t)blockIdx.z * hl + qy) * wl + qx;
+        if (mask_act != UOCR_ACT_NONE) acc *= act_grad_from_output<float>(mask_y[off], mask_act, mask_alpha);
+        dxl[off] = acc;
+    }
+}
+
+// partial[blk][37]: dWeff[m*4 + phase] and db
+__global__ __launch_bounds__(256) void up1_wgrad_kernel(const float* __restrict__ xl, const float* __restrict__ dy,
+                                                        float* __restrict__ partial, int hl, int wl,
+                                                        int rows_per_block) {
+    __shared__ float xs[XH * XW];
+    __shared__ float red[4][37];
+    const int tid = threadIdx.x;
+    const int rx = blockIdx.x * RW;
+    const int row_begin = blockIdx.y * rows_per_block, row_end = min(hl, row_begin + rows_per_block);
+    const float* xb = xl + (size_t)blockIdx.z * hl * wl;
+    const int W = 2 * wl;
+    const float* gb = dy + (size_t)blockIdx.z * (2 * hl) * W;
+    const int c = tid & 31, r0 = tid >> 5;
+    float acc[36], dbacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = 0.f;
+    for (int ry = row_begin; ry < row_end; ry += RH) {
+        __syncthreads();
+        for (int i = tid; i < XH * XW; i += 256) {
+            const int r = i / XW, cc = i - r * XW;
+            const int gy = ry - 1 + r, gx = rx - 1 + cc;
+            xs[i] = (gy >= 0 && gy < hl && gx >= 0 && gx < wl) ? xb[(size_t)gy * wl + gx] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = r0 + 8 * p, py = ry + r, pxl = rx + c;
+            if (py >= row_end || pxl >= wl) continue;
+            const float* g0 = gb + (size_t)(2 * py) * W + 2 * pxl;
+            const float2 ga = *reinterpret_cast<const float2*>(g0), gbv = *reinterpret_cast<const float2*>(g0 + W);
+            const float g[4] = {ga.x, ga.y, gbv.x, gbv.y};
+            dbacc += (g[0] + g[1]) + (g[2] + g[3]);
+#pragma unroll
+            for (int m = 0; m < 9; ++m) {
+                const float xv = xs[(r + m / 3) * XW + c + m % 3];
+#pragma unroll
+                for (int phase = 0; phase < 4; ++phase) acc[m * 4 + phase] += xv * g[phase];
+            }
+        }
+    }
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+        const float v = wave_reduce_sum(acc[i]);
+        if (lane == 0) red[wv][i] = v;
+    }
+    dbacc = wave_reduce_sum(dbacc);
+    if (lane == 0) red[wv][36] = dbacc;
+    __syncthreads();
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (tid < 37) partial[(size_t)blk * 37 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// block e < 25: dw[ky][kx] (+)= sum over blocks and phases of dWeff[m(phase, k)][phase]; block 25: db
+__global__ __launch_bounds__(256) void up1_wgrad_finish(const float* __restrict__ partial, float* __restrict__ dw,
+                                                        float* __restrict__ db, int nblocks, int use_bias,
+                                                        int accumulate) {
+    __shared__ double smem[16];
+    const int e = blockIdx.x;
+    double s = 0.0;
+    if (e < 25) {
+        const int ky = e / 5, kx = e % 5;
+        int idx[4];
+#pragma unroll
+        for (int phase = 0; phase < 4; ++phase) {
+            int my = 0, mx = 0, lo, hi;
+            for (int mi = 0; mi < 3; ++mi) {
+                tap_group(phase >> 1, mi, lo, hi);
+                if (ky >= lo && ky < hi) my = mi;
+                tap_group(phase & 1, mi, lo, hi);
+                if (kx >= lo && kx < hi) mx = mi;
+            }
+            idx[phase] = (my * 3 + mx) * 4 + phase;
+        }
+        for (int blk = threadIdx.x; blk < nblocks; blk += blockDim.x) {
+            const float* p = partial + (size_t)blk * 37;
+            s += (double)p[idx[0]] + (double)p[idx[1]] + (double)p[idx[2]] + (double)p[idx[3]];
+        }
+    } else {
+        for (int blk = threadIdx.x; blk < nblocks; blk += blockDim.x) s += (double)partial[(size_t)blk * 37 + 36];
+    }
+    s = block_reduce_sum(s, smem);
+    if (threadIdx.x != 0) return;
+    float* dst = e < 25 ? dw + e : db;
+    if (e == 25 && !use_bias) s = 0.0;
+    *dst = accumulate ? (float)((double)*dst + s) : (float)s;
+}
+
 int up_rows_per_block(int strips, int hl, int n) {
     int rows = RH;
     while (rows < hl && (size_t)strips * ((hl + rows - 1) / rows) * n > 2048u) rows += RH;
@@ -322,9 +504,10 @@ int up_rows_per_block(int strips, int hl, int n) {
 
 int check_up(uocr_ctx* ctx, int dtype, int n, int hl, int wl, int cin, int cout, int kh, int kw, int ph, int pw) {
     if (dtype != UOCR_F32) UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "upconv2x: float32 only");
-    if (cin != CH || cout != CH || kh != 5 || kw != 5 || ph != 2 || pw != 2)
-        UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "upconv2x: 5x5 / padding 2 / 4 -> 4 channels only (got %dx%d pad %d,%d %d -> %d)",
-                  kh, kw, ph, pw, cin, cout);
+    if (!((cin == CH && cout == CH) || (cin == 1 && cout == 1)) || kh != 5 || kw != 5 || ph != 2 || pw != 2)
+        UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED,
+                  "upconv2x: 5x5 / padding 2 / 4 -> 4 or 1 -> 1 channels only (got %dx%d pad %d,%d %d -> %d)", kh, kw, ph,
+                  pw, cin, cout);
     UOCR_REQUIRE(ctx, n > 0 && hl > 0 && wl > 0 && n <= 65535);
     return UOCR_OK;
 }
@@ -338,6 +521,13 @@ extern "C" int uocr_upconv2x_fwd(uocr_ctx* ctx, int dtype, const void* x_low, co
     UOCR_REQUIRE(ctx, x_low && w && b && y);
     int rc = check_up(ctx, dtype, n, hl, wl, cin, cout, kh, kw, ph, pw);
     if (rc != UOCR_OK) return rc;
+    if (cin == 1) {
+        hipLaunchKernelGGL(up1_fwd_kernel, dim3((wl + RW - 1) / RW, (hl + RH - 1) / RH, n), dim3(256), 0, ctx->stream,
+                           (const float*)x_low, (const float*)w, (const float*)b, (float*)y, hl, wl, use_bias, act,
+                           (float)act_alpha);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
     const int strips = (wl + RW - 1) / RW, rows = up_rows_per_block(strips, hl, n);
     hipLaunchKernelGGL(upconv_fwd_kernel, dim3(strips, (hl + rows - 1) / rows, n), dim3(256), 0, ctx->stream,
                        (const float*)x_low, (const float*)w, (const float*)b, (float*)y, hl, wl, rows, use_bias,
@@ -354,6 +544,13 @@ extern "C" int uocr_upconv2x_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, 
     UOCR_REQUIRE(ctx, act == UOCR_ACT_NONE || x_act != nullptr);
     int rc = check_up(ctx, dtype, n, hl, wl, cin, cout, kh, kw, ph, pw);
     if (rc != UOCR_OK) return rc;
+    if (cin == 1) {
+        hipLaunchKernelGGL(up1_dgrad_kernel, dim3((wl + RW - 1) / RW, (hl + RH - 1) / RH, n), dim3(256), 0, ctx->stream,
+                           (const float*)dy, (const float*)w, (float*)dx_low, hl, wl, (const float*)x_act, act,
+                           (float)act_alpha);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
     rc = uocr_need_workspace(ctx, NWEFF * sizeof(float));
     if (rc != UOCR_OK) return rc;
     float* weff = (float*)ctx->workspace;
@@ -377,6 +574,15 @@ extern "C" int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_
     rc = uocr_need_workspace(ctx, (size_t)nblocks * (36 * 16 + 4) * sizeof(float));
     if (rc != UOCR_OK) return rc;
     float* partial = (float*)ctx->workspace;
+    if (cin == 1) {
+        hipLaunchKernelGGL(up1_wgrad_kernel, dim3(strips, bands, n), dim3(256), 0, ctx->stream, (const float*)x_low,
+                           (const float*)dy, partial, hl, wl, rows);
+        UOCR_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(up1_wgrad_finish, dim3(26), dim3(256), 0, ctx->stream, (const float*)partial, (float*)dw,
+                           (float*)db, nblocks, use_bias, accumulate);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
     hipLaunchKernelGGL(upconv_wgrad_kernel, dim3(strips, bands, n), dim3(256), 0, ctx->stream, (const float*)x_low,
                        (const float*)dy, partial, hl, wl, rows);
     UOCR_LAUNCH_CHECK(ctx);

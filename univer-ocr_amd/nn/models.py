@@ -363,8 +363,8 @@ class Model(BaseModel):
         return self._fusion[0], self._fusion[1]
 
     def _find_ups(self, fused_act):
-        """Upsample2D(2) feeding only a 5x5 / stride 1 / padding 2 / 4->4 Convolutional2D -- the decoder blocks
-        of the Line net (my_model/model.py:194-247) -- runs as one op on the low-res tensor (csrc/conv_up.hip);
+        """Upsample2D(2) feeding only a 5x5 / stride 1 / padding 2 Convolutional2D with 4->4 or 1->1 channels -- the
+        decoder blocks of the Line and Paragraph nets (my_model/model.py:138-247) -- runs as one op on the low-res tensor (csrc/conv_up.hip);
         the upsampled tensor is never built.  Returns {conv: (upsample node, fused activation that feeds only
         this upsample, or None)}; that activation's backward is folded into the op's dx epilogue."""
         from .layers import Convolutional2D, Upsample2D
@@ -380,7 +380,7 @@ class Model(BaseModel):
             conv = self.layers[dst]
             if not (isinstance(conv, Convolutional2D) and conv.kernel_size == (5, 5) and conv.stride == (1, 1)
                     and conv.padding == (2, 2) and conv.padding_value == 0
-                    and (conv.in_channels, conv.out_channels) == (4, 4)):
+                    and (conv.in_channels, conv.out_channels) in ((4, 4), (1, 1))):
                 continue
             src = self.relations[node]
             act_in = None
