@@ -339,10 +339,11 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_finish(const float* __restr
     *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
 
-// rows per block = a multiple of the tile height th giving at most ~8 blocks per CU
-int pair_rows_per_block(int strips, int h, int n, int th) {
+// rows per block = a multiple of the tile height th giving at most max_blocks blocks (measured at
+// 32 x 256 x 512: forward / backward with dx 4096 blocks = 4 rounds of resident blocks, backward without dx 2048)
+int pair_rows_per_block(int strips, int h, int n, int th, unsigned max_blocks) {
     int rows = th;
-    while (rows < h && (size_t)strips * ((h + rows - 1) / rows) * n > 2048u) rows += th;
+    while (rows < h && (size_t)strips * ((h + rows - 1) / rows) * n > max_blocks) rows += th;
     return rows;
 }
 
@@ -365,7 +366,7 @@ extern "C" int uocr_conv_pair_fwd(uocr_ctx* ctx, int dtype, const void* x, const
     int rc = check_pair(ctx, dtype, n, h, w, cmid, act2);
     if (rc != UOCR_OK) return rc;
     const int strips = (w + RW - 3) / (RW - 2);
-    const int rows_per_block = pair_rows_per_block(strips, h, n, RH - 2);
+    const int rows_per_block = pair_rows_per_block(strips, h, n, RH - 2, 4096u);
     const dim3 grid(strips, (h + rows_per_block - 1) / rows_per_block, n);
     hipLaunchKernelGGL(conv_pair_fwd_kernel, grid, dim3(256), 0, ctx->stream, (const float*)x, (const float*)w1,
                        (const float*)b1, (const float*)w2, (const float*)b2, (float*)y, h, w, rows_per_block,
@@ -384,7 +385,7 @@ extern "C" int uocr_conv_pair_bwd(uocr_ctx* ctx, int dtype, const void* x, const
     if (rc != UOCR_OK) return rc;
     const int tw = dx ? RW - 2 : RW, th = dx ? RH - 2 : RH;
     const int strips = (w + tw - 1) / tw;
-    const int rows_per_block = pair_rows_per_block(strips, h, n, th);
+    const int rows_per_block = pair_rows_per_block(strips, h, n, th, dx ? 4096u : 2048u);
     const int bands = (h + rows_per_block - 1) / rows_per_block;
     const int nblocks = strips * bands * n;
     rc = uocr_need_workspace(ctx, (size_t)nblocks * 4 * NA * sizeof(float));

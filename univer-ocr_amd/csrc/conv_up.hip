@@ -496,9 +496,9 @@ __global__ __launch_bounds__(256) void up1_wgrad_finish(const float* __restrict_
     *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
 
-int up_rows_per_block(int strips, int hl, int n) {
+int up_rows_per_block(int strips, int hl, int n, unsigned max_blocks = 2048u) {
     int rows = RH;
-    while (rows < hl && (size_t)strips * ((hl + rows - 1) / rows) * n > 2048u) rows += RH;
+    while (rows < hl && (size_t)strips * ((hl + rows - 1) / rows) * n > max_blocks) rows += RH;
     return rows;
 }
 
@@ -569,7 +569,8 @@ extern "C" int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_
     UOCR_REQUIRE(ctx, x_low && dy && dw && db);
     int rc = check_up(ctx, dtype, n, hl, wl, cin, cout, kh, kw, ph, pw);
     if (rc != UOCR_OK) return rc;
-    const int strips = (wl + RW - 1) / RW, rows = up_rows_per_block(strips, hl, n);
+    // fewer, longer blocks than the forward: every block ends with a reduction and a partial row for the finish kernel
+    const int strips = (wl + RW - 1) / RW, rows = up_rows_per_block(strips, hl, n, 1024u);
     const int bands = (hl + rows - 1) / rows, nblocks = strips * bands * n;
     rc = uocr_need_workspace(ctx, (size_t)nblocks * (36 * 16 + 4) * sizeof(float));
     if (rc != UOCR_OK) return rc;
