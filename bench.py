@@ -134,6 +134,10 @@ def main():
     ap.add_argument('--lr', type=float, default=0.0015)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-overlap', action='store_true')
+    ap.add_argument('--no-pipeline', action='store_true',
+                    help='end every step with the main stream waiting for all four net streams (default: a net starts '
+                         'its next step as soon as ITS previous step is done; the timed region still ends with a full '
+                         'device synchronisation)')
     ap.add_argument('--graphs', action='store_true',
                     help='replay Paragraph, Line and Char as HIP graphs (PageTrainer(graphs=True)); Monochrome stays eager '
                          'so that the HIP events around the dominant kernel keep working')
@@ -175,7 +179,8 @@ def main():
 
     trainer = PageTrainer(args.batch, args.height, args.width, args.char_width, args.optimizer, args.lr,
                           seed=0, overlap=not args.no_overlap, input_grads=not args.skip_input_grads,
-                          graphs=args.graphs, eager_nets=('Monochrome',))   # probed kernel stays eager
+                          graphs=args.graphs, eager_nets=('Monochrome',),    # probed kernel stays eager
+                          pipelined=not args.no_pipeline)
     layers = make_page_batch(args.batch, args.height, args.width, args.char_width, seed=1234 + rank)
     context = trainer.make_context(layers)       # inputs resident in HBM before the timed region
 
@@ -260,7 +265,7 @@ def main():
                 'page': [args.height, args.width], 'optimizer': args.optimizer,
                 'parallelism': f'dp{world}', 'grad_allreduce': 'rccl, 1 flat buffer per net' if world > 1 else None,
                 'final_losses': final,
-                'h2d_inclusive': bool(args.h2d), 'input_grads': not args.skip_input_grads, 'hip_graphs': bool(args.graphs),
+                'h2d_inclusive': bool(args.h2d), 'input_grads': not args.skip_input_grads, 'hip_graphs': bool(args.graphs), 'pipelined_lanes': not args.no_pipeline,
             },
             'roofline': {'bound': 'mfma', 'kernel': dominant['kernel'], 'achieved': round(achieved, 2),
                          'peak': F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / F32_PEAK_TFLOPS, 4),

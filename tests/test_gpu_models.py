@@ -300,3 +300,42 @@ def test_graph_replay_matches_eager_steps():
     assert np.array_equal(results[0][2], results[1][2])
     for name, w in results[0][1].items():
         assert np.array_equal(np.asarray(w), np.asarray(results[1][1][name])), name
+
+
+@pytest.mark.parametrize('graphs', [False, True])
+def test_pipelined_lanes_match_joined_steps(graphs):
+    """PageTrainer(pipelined=True): no per-step join of the four streams (a lane starts its next step when
+    ITS previous one is done).  Losses of every step (read later through DeviceScalar.ready), the published
+    prediction after join() and the final weights are bit-identical to the joined step, also when every step
+    gets a fresh batch whose arrays the caller drops right away."""
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    from univer_ocr_amd.my_model.trainer import PageTrainer
+    from univer_ocr_amd.nn import CP
+    CP.use_gpu(0)
+    CP.set_dtype('float32')
+    batches = [make_page_batch(2, 32, 64, 16, seed=s) for s in (11, 12, 13)]
+    lazy = CP.lazy_losses
+    CP.lazy_losses = True
+    results = []
+    try:
+        for pipelined in (False, True):
+            trainer = PageTrainer(2, 32, 64, 16, optimizer='sgd', lr=0.01, seed=4, graphs=graphs, pipelined=pipelined)
+            kept = []
+            for i in range(7):
+                context = trainer.make_context(batches[i % 3])
+                kept.append(trainer.step(context))        # lazy losses, read only at the end
+                last = context
+            trainer.join()
+            pred = CP.asnumpy(last['line_pred'])
+            history = [{n: [float(v) for v in l['output_losses']] + [float(l['regularization_loss'])]
+                        for n, l in losses.items()} for losses in kept[-2:]]
+            weights = {}
+            for model in trainer.models.values():
+                weights.update(model.get_weights())
+            results.append((history, pred, weights))
+    finally:
+        CP.lazy_losses = lazy
+    assert results[0][0] == results[1][0]
+    assert np.array_equal(results[0][1], results[1][1])
+    for name, w in results[0][2].items():
+        assert np.array_equal(np.asarray(w), np.asarray(results[1][2][name])), name

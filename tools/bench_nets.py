@@ -14,6 +14,7 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--skip-input-grads', action='store_true')
     ap.add_argument('--graphs', action='store_true')
+    ap.add_argument('--pipelined', action='store_true')
     ap.add_argument('--option', action='append', default=[], help='ctx option key=value (applied to every lane)')
     ap.add_argument('--only', default='', help='comma-separated nets: time just this combination')
     args = ap.parse_args()
@@ -29,7 +30,7 @@ def main():
     combos = [tuple(args.only.split(','))] if args.only else [(n,) for n in all_nets] + [all_nets]
     for nets in combos:
         trainer = PageTrainer(args.batch, 256, 512, 64, nets=nets, input_grads=not args.skip_input_grads,
-                              graphs=args.graphs)
+                              graphs=args.graphs, pipelined=args.pipelined)
         for opt in args.option:
             k, v = opt.split('=')
             CP.runtime().set_option(k, int(v))

@@ -27,7 +27,7 @@ def make_optimizer(name, lr):
 class PageTrainer:
     def __init__(self, batch, height=256, width=512, char_width=64, optimizer='sgd', lr=0.0015, seed=0,
                  nets=('Monochrome', 'Paragraph', 'Line', 'Char'), data_parallel=None, overlap=True,
-                 init='kaiming_normal', fuse=True, lanes=True, input_grads=True, graphs=False, eager_nets=()):
+                 init='kaiming_normal', fuse=True, lanes=True, input_grads=True, graphs=False, eager_nets=(), pipelined=False):
         np.random.seed(seed)                        # kaiming_uniform draws from the NumPy global RNG
         self.batch = batch
         self.optimizer = make_optimizer(optimizer, lr)
@@ -51,6 +51,11 @@ class PageTrainer:
         # HIP graphs: each net's forward+loss+backward and its L2+optimizer tail are captured once and
         # replayed (two hipGraphLaunch per net and step instead of ~40 launches); needs lanes
         self.graphs = bool(graphs) and self.lanes is not None
+        # pipelined: step() does not end with the main stream waiting for every lane, so a lane starts its
+        # next step as soon as ITS previous step is done instead of when the slowest net is; results are
+        # the same, losses / outputs are read after their lane's event (DeviceScalar.ready) or join()
+        self.pipelined = bool(pipelined) and self.lanes is not None
+        self._lane_done = {}
         self.eager_nets = tuple(eager_nets)          # nets kept out of the graphs (e.g. to time one kernel)
         self._captured = None
         self._eager_steps = 0
@@ -91,6 +96,7 @@ class PageTrainer:
             # graph replay reads fixed addresses: the trainer owns one input buffer per layer tag and
             # every make_context refills them in place (no device-to-device copy in step())
             import torch
+            self.join()
             for tag in set(mapping.values()):
                 host = np.ascontiguousarray(layers[tag], dtype=CP.dtype)
                 if tag not in self._input_buffers:
@@ -152,6 +158,9 @@ class PageTrainer:
                 stream.wait_event(start)
                 comp.selector(context)
                 X, y = next(comp.selector.get())
+                if self.pipelined:                     # the caller may drop these arrays before the lane is done
+                    X.t.record_stream(stream)
+                    y.t.record_stream(stream)
                 comp.model.train_begin(X, y)
                 comp._publish()
         for comp in comps:
@@ -159,8 +168,27 @@ class PageTrainer:
                 context['losses'][comp.name] = comp.model.train_finish()
                 done = torch.cuda.Event()
                 done.record(stream)
-            main.wait_event(done)
+            self._finish_lane(comp.name, done, context['losses'][comp.name], main)
         return context['losses']
+
+    def _finish_lane(self, name, done, losses, main):
+        if not self.pipelined:
+            main.wait_event(done)
+            return
+        self._lane_done[name] = done
+        from ..nn.gpu import DeviceScalar
+        for value in list(losses['output_losses']) + [losses['regularization_loss']]:
+            if isinstance(value, DeviceScalar):
+                value.ready = done
+
+    def join(self):
+        """Pipelined mode: make the current stream wait for every lane (before reading outputs or
+        overwriting inputs on it)."""
+        import torch
+        main = torch.cuda.current_stream()
+        for done in self._lane_done.values():
+            main.wait_event(done)
+        self._lane_done = {}
 
     # -- HIP-graph replay of the step ----------------------------------------------------------------
     def _capture(self, context):
@@ -233,6 +261,8 @@ class PageTrainer:
         rt = CP.runtime()
         main = torch.cuda.current_stream()
         comps = self._lane_order()
+        if self.pipelined and any(context[label] is not static for label, static in self._statics.items()):
+            self.join()                                      # the copies below overwrite what the lanes read
         copied = set()
         for label, static in self._statics.items():          # new batch -> the graphs' static inputs
             fresh = context[label]
@@ -263,15 +293,17 @@ class PageTrainer:
                     if model.grad_sync is not None and model.defer_grad_sync:
                         model.grad_sync.__self__.wait(model)
                     entry['finish'].replay()
-                self._events[comp.name].record(stream)
-            main.wait_event(self._events[comp.name])
+                done = self._events[comp.name] if not self.pipelined else torch.cuda.Event()
+                done.record(stream)
             if entry is None:
+                self._finish_lane(comp.name, done, context['losses'][comp.name], main)
                 continue
             if entry['prediction'] is not None:
                 context[comp.selector.pred_label] = entry['prediction']
             context['losses'][comp.name] = {
                 'output_losses': [DeviceScalar(t) for t in entry['output_losses']],
                 'regularization_loss': DeviceScalar(entry['regularization_loss'])}
+            self._finish_lane(comp.name, done, context['losses'][comp.name], main)
         return context['losses']
 
     def forward(self, context):

@@ -349,14 +349,17 @@ class DeviceScalar:
     reference converts every loss with float() right away (losses.py:25,42,57,73 -- one host sync
     each); with CP.lazy_losses the sync happens once, when the caller formats / adds the value."""
 
-    __slots__ = ('t', '_value')
+    __slots__ = ('t', '_value', 'ready')
 
-    def __init__(self, tensor):
+    def __init__(self, tensor, ready=None):
         self.t = tensor          # 0-d or 1-element float64 tensor
         self._value = None
+        self.ready = ready       # event of the stream that writes the slot, when that is not the reader's stream
 
     def __float__(self):
         if self._value is None:
+            if self.ready is not None:
+                self.ready.synchronize()
             self._value = float(self.t.item())
         return self._value
 
