@@ -1,4 +1,4 @@
-"""Parity at the sizes BASELINE.json names (configs[0..2]); the small oracle-vs-HIP cases live in
+"""Parity at the sizes BASELINE.json names (configs[0..2] and the geometry of configs[4]); the small oracle-vs-HIP cases live in
 test_gpu_ops / test_gpu_models, here the FULL sizes:
 
   configs[0]  my_model forward on one 64x64 glyph            -> HIP vs oracle, f32 and f64
@@ -127,3 +127,36 @@ def test_config2_full_size_properties(cin, cout, ks, st, pd):
     # 4. a column of the full-size result against the oracle (one image, exact reference arithmetic)
     ref = O.conv2d_fwd(CP.asnumpy(x)[:1].astype(np.float64), CP.asnumpy(wt).astype(np.float64), np.zeros(cout), st, pd)
     assert rel_linf(CP.asnumpy(y)[:1], ref) <= 1e-5
+
+
+def test_config4_high_res_pages_fused_equals_layer_by_layer():
+    """configs[4] geometry (1024x2048 full-page scans; float32 here -- the float16 storage mode is not built):
+    the multi-layer kernels (conv pair, upsample+conv on the low-res tensor, loss with the folded Sigmoid)
+    against the layer-by-layer kernels on the same weights and pages at full resolution: losses of two train
+    steps and the weights after them.  Covers the 64-bit offsets of 2-page batches of 2M-pixel images
+    (the unfused Monochrome activation alone is 268 MB)."""
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    from univer_ocr_amd.my_model.trainer import PageTrainer
+    from univer_ocr_amd.nn import CP
+    CP.use_gpu(0)
+    CP.set_dtype('float32')
+    layers = make_page_batch(2, 1024, 2048, 64, seed=21)
+    results = []
+    for fuse in (True, False):
+        trainer = PageTrainer(2, 1024, 2048, 64, optimizer='sgd', lr=0.0015, seed=9, fuse=fuse,
+                              nets=('Monochrome', 'Paragraph', 'Line'))
+        context = trainer.make_context(layers)
+        rows = []
+        for _ in range(2):
+            losses = trainer.step(context)
+            rows.append([float(v) for name in ('Monochrome', 'Paragraph', 'Line') for v in losses[name]['output_losses']])
+        weights = {n: p.value.numpy() for m in trainer.models.values() for n, p in m.params().items()}
+        results.append((np.array(rows), weights))
+        used = {name: (len(m._pairs_used), len(m._ups_used)) for name, m in trainer.models.items()}
+        assert used == ({'Monochrome': (1, 0), 'Paragraph': (0, 2), 'Line': (0, 2)} if fuse else
+                        {'Monochrome': (0, 0), 'Paragraph': (0, 0), 'Line': (0, 0)})
+        del trainer, context
+    assert np.all(np.isfinite(results[0][0]))
+    assert rel_linf(results[0][0], results[1][0]) <= 1e-5
+    for name, w in results[0][1].items():
+        assert rel_linf(w, results[1][1][name]) <= 5e-5, name
