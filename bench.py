@@ -162,11 +162,20 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit('--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
         args.gpus = world
+    # UOCR_BENCH_REHEARSAL=1: several ranks on ONE card with the gloo backend (gradients staged through the
+    # host, parallel.DataParallel) -- exercises this file's multi-rank path where RCCL would refuse two ranks
+    # on one device; never a measurement
+    rehearsal = os.environ.get('UOCR_BENCH_REHEARSAL') == '1'
+    if rehearsal:
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if rehearsal:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
 
     from univer_ocr_amd.my_model.synthetic import make_page_batch
     from univer_ocr_amd.my_model.trainer import PageTrainer
@@ -263,7 +272,8 @@ def main():
                             f'({args.batch},32,{args.char_width},1) line strips per GPU',
                 'batch_per_gpu': args.batch, 'global_batch': args.batch * world,
                 'page': [args.height, args.width], 'optimizer': args.optimizer,
-                'parallelism': f'dp{world}', 'grad_allreduce': 'rccl, 1 flat buffer per net' if world > 1 else None,
+                'parallelism': f'dp{world}',
+                'grad_allreduce': ('gloo (REHEARSAL on one card)' if rehearsal else 'rccl, 1 flat buffer per net') if world > 1 else None,
                 'final_losses': final,
                 'h2d_inclusive': bool(args.h2d), 'input_grads': not args.skip_input_grads, 'hip_graphs': bool(args.graphs), 'pipelined_lanes': not args.no_pipeline,
             },

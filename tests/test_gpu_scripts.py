@@ -55,3 +55,29 @@ def test_page_feeder_uint8_pipeline_matches_direct_copy():
             expect = batch[tag].astype(np.float32) * np.float32(scale)
             got = CP.asnumpy(ctx[label])
             assert got.dtype == np.float32 and np.allclose(got, expect, rtol=1e-6, atol=0), label
+
+
+def test_bench_two_rank_rehearsal_prints_one_valid_line():
+    """`bench.py --gpus 2` launched the way the driver does (torch.distributed.run, one process per rank), with
+    UOCR_BENCH_REHEARSAL=1 so that both ranks share the one card through gloo: rendezvous, data-parallel
+    trainer, barrier / max-over-ranks timing and the rank-0 JSON line of the multi-rank path."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, UOCR_BENCH_REHEARSAL='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3',
+           '--warmup', '2', '--batch', '4', '--height', '64', '--width', '128']
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [line for line in out.stdout.splitlines() if line.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['config']['global_batch'] == 8
+    assert rec['scaling'] == 'weak' and rec['value'] > 0 and 'cpu_baseline' not in rec
+    assert all(np.isfinite(v).all() for v in map(np.array, rec['config']['final_losses'].values()))
