@@ -50,6 +50,22 @@ def _worker(rank, world, port, results):
         dp.wait(char)
         out['char_grad'] = float(char.pack.grad.t[0].item())              # (10 + 20) / 2 = 15
         out['drained'] = id(char) not in dp._pending
+        # 3b. bucketed all-reduce inside the Char net: the dense layers' gradients (the tail of the flat
+        # buffer) go out when dense_1 has run its backward, the conv block's with the final sync
+        trigger, lo, hi = dp._plans[id(char)]
+        out['bucket'] = (trigger, lo > 0, hi == char.pack.total, (hi - lo) * 4 >= (1 << 20))
+        out['no_bucket_for_mono'] = id(mono) not in dp._plans and mono.bucket_hook is None
+        char.pack.grad.t.fill_(float(rank + 1))
+        char.bucket_hook(char, 'Char/dense_block/dense_2')           # not the trigger: nothing happens
+        out['early_idle'] = id(char) not in dp._early
+        char.bucket_hook(char, trigger)
+        out['early_sent'] = id(char) in dp._early
+        char.pack.grad.t[:lo].fill_(float(100 * (rank + 1)))         # the head changes after the tail left
+        char.grad_sync(char)
+        dp.wait(char)
+        out['bucket_head'] = float(char.pack.grad.t[0].item())        # (100 + 200) / 2
+        out['bucket_tail'] = float(char.pack.grad.t[-1].item())       # (1 + 2) / 2
+        out['early_drained'] = id(char) not in dp._early
         # 4. a diverged replica is detected
         if rank == 1:
             mono.pack.value.t[0] += 1.0
@@ -73,4 +89,7 @@ def test_flat_gradient_allreduce_world2():
         assert out['mono_grad'] == 3.0
         assert out['pending'] and out['drained']
         assert out['char_grad'] == 15.0
+        assert out['bucket'] == ('Char/dense_block/dense_1', True, True, True) and out['no_bucket_for_mono']
+        assert out['early_idle'] and out['early_sent'] and out['early_drained']
+        assert out['bucket_head'] == 150.0 and out['bucket_tail'] == 1.5
         assert out['sync1'] is False

@@ -208,6 +208,7 @@ class PageTrainer:
             if comp.name in self.eager_nets:
                 continue
             sync, model.grad_sync = model.grad_sync, None         # collectives are not captured
+            hook, model.bucket_hook = model.bucket_hook, None     # (replays reduce the whole buffer at once)
             comp.selector(context)
             labels = (comp.selector.X_label, comp.selector.y_label)
             X, y = (self._static_input(label, context[label]) for label in labels)
@@ -229,6 +230,7 @@ class PageTrainer:
                          prediction=context.get(comp.selector.pred_label))
             model.grad_sync = sync
             captured[comp.name] = entry
+            del hook                                              # stays off: the backward now lives in the graph
         self._captured = captured
         self._events = {comp.name: torch.cuda.Event() for comp in self.model_system.components}
         self._start = torch.cuda.Event()

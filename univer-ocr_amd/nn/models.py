@@ -111,6 +111,7 @@ class Model(BaseModel):
         self.grad_sync = None            # set by parallel.DataParallel
         self.defer_grad_sync = False     # True: the all-reduce is waited for in train_finish()
         self._pending_losses = None
+        self.bucket_hook = None
         self._receptive_fields = {}
         self.layers, self.relations = None, None
         self.unravel_model()
@@ -291,6 +292,8 @@ class Model(BaseModel):
                     input_activation=None if in_act is None else self.layers[in_act]))
             else:
                 grads_mem[node] = make_list_if_not(self.layers[node].backward(incoming(node)))
+            if self.bucket_hook is not None:          # data parallel: part of the gradient may be final now
+                self.bucket_hook(self, node)
         if self._skipped_input_grads:
             self.input_grads = {}
             return []
