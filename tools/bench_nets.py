@@ -18,6 +18,8 @@ def main():
     ap.add_argument('--option', action='append', default=[], help='ctx option key=value (applied to every lane)')
     ap.add_argument('--only', default='', help='comma-separated nets: time just this combination')
     args = ap.parse_args()
+    if args.pipelined:                          # one hardware queue per net stream (see bench.py)
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     import torch
     from univer_ocr_amd.my_model.synthetic import make_page_batch
     from univer_ocr_amd.my_model.trainer import PageTrainer

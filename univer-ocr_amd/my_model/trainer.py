@@ -53,7 +53,9 @@ class PageTrainer:
         self.graphs = bool(graphs) and self.lanes is not None
         # pipelined: step() does not end with the main stream waiting for every lane, so a lane starts its
         # next step as soon as ITS previous step is done instead of when the slowest net is; results are
-        # the same, losses / outputs are read after their lane's event (DeviceScalar.ready) or join()
+        # the same, losses / outputs are read after their lane's event (DeviceScalar.ready) or join().
+        # Works best with one hardware queue per stream: GPU_MAX_HW_QUEUES=8 in the environment before the
+        # first GPU call (bench.py sets it; ROCm's default 4 makes two nets share a queue)
         self.pipelined = bool(pipelined) and self.lanes is not None
         self._lane_done = {}
         self.eager_nets = tuple(eager_nets)          # nets kept out of the graphs (e.g. to time one kernel)
