@@ -97,7 +97,10 @@ class ProgressTracker(BaseProgressTracker):
 def _tracked(func, tracker_of, name_of, phase):
     @functools.wraps(func)
     def wrapper(*args, **kwargs):
-        tracker, name = tracker_of(args), name_of(args)
+        tracker = tracker_of(args)
+        if type(tracker) is BaseProgressTracker:      # the do-nothing default: no bookkeeping on the hot path
+            return func(*args, **kwargs)
+        name = name_of(args)
         tracker.start_tracking(name, phase)
         try:
             return func(*args, **kwargs)
