@@ -159,3 +159,21 @@ def test_conv2d_entry_points_stay_inside_their_buffers(case, rt):
     runtime.call('uocr_conv2d_bwd_weight', hiplib.F32, x.ptr, g.ptr, dw.ptr, db.ptr, *dims, 0.0, 1, 0)
     dw.check('conv dw')
     db.check('conv db')
+
+
+@pytest.mark.parametrize('shape', [(2, 6, 8, 4), (1, 2, 2, 4), (3, 10, 14, 8)])
+def test_vector_maxpool_stays_inside_its_buffers(shape, rt):
+    from univer_ocr_amd.hip import lib as hiplib
+    CP, runtime = rt
+    n, h, w, c = shape
+    x = CP.copy(np.random.default_rng(6).integers(0, 3, shape).astype(np.float64))
+    y = Guarded(CP, n * (h // 2) * (w // 2) * c)
+    mask = Guarded(CP, n * h * w * c // 4)              # uint8 mask, counted in 4-byte words
+    args = (n, h, w, c, 2, 2, 2, 2, 0, 0, h // 2, w // 2)
+    runtime.call('uocr_maxpool2d_fwd', hiplib.F32, x.ptr, y.ptr, mask.ptr, *args)
+    y.check('maxpool y')
+    mask.check('maxpool mask')
+    g = CP.copy(np.random.default_rng(7).standard_normal((n, h // 2, w // 2, c)))
+    dx = Guarded(CP, n * h * w * c)
+    runtime.call('uocr_maxpool2d_bwd', hiplib.F32, g.ptr, mask.ptr, dx.ptr, *args)
+    dx.check('maxpool dx')

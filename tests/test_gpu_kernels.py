@@ -324,3 +324,22 @@ def test_seg_loss_with_folded_output_sigmoid(kind, shape, f32):
     check(grad2, ref_grad * p32 * (1 - p32), 1e-5, 'grad through sigmoid')
     loss3, none = ops.seg_loss(kind, pd, gd, False)
     assert none is None and float(loss3) == float(loss)
+
+
+@pytest.mark.parametrize('shape', [(2, 6, 8, 4), (3, 10, 14, 8), (1, 2, 2, 4), (2, 64, 96, 16)])
+def test_maxpool2_vector_kernels_match_generic(shape, f32):
+    """2x2 / stride 2 max pooling with c % 4 == 0 (16-byte kernels) == the oracle, with ties inside windows
+    (values drawn from a 3-value set) so the mask and the dy / ties split are exercised; the mask must equal
+    the generic kernel's byte for byte."""
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    rng = np.random.default_rng(sum(shape))
+    X = rng.integers(0, 3, shape).astype(np.float64) - 1.0
+    ref_y, ref_mask = O.maxpool2d_fwd(X, (2, 2), (2, 2), (0, 0))
+    y, mask = ops.maxpool2d_fwd(CP.copy(X), (2, 2), (2, 2), (0, 0))
+    assert np.array_equal(CP.asnumpy(y), ref_y.astype(np.float32))
+    assert np.array_equal(CP.asnumpy(mask), ref_mask.astype(np.uint8))
+    g = rng.standard_normal(ref_y.shape)
+    dx = ops.maxpool2d_bwd(CP.copy(g), mask, X.shape, (2, 2), (2, 2), (0, 0))
+    check(dx, O.maxpool2d_bwd(g, ref_mask, X.shape, (2, 2), (2, 2), (0, 0)), 1e-6, 'dx')
+    CP.runtime().set_option('fast_paths', 1)

@@ -41,6 +41,37 @@ def main():
         us = timed(fn)
         print(f'{name:32s} {us:8.1f} us  {passes * nbytes / us / 1e3:8.0f} GB/s')
 
+    # pooling / activation / loss / optimizer kernels at my_model-like shapes: algorithmic bytes / time
+    import numpy as np
+    rng = np.random.default_rng(0)
+    x4 = CP.copy(rng.standard_normal((32, 256, 512, 4)).astype(np.float32))
+    g4 = CP.copy(rng.standard_normal((32, 256, 512, 4)).astype(np.float32))
+    lo4 = CP.copy(rng.standard_normal((32, 128, 256, 4)).astype(np.float32))
+    y4, mask = ops.maxpool2d_fwd(x4, (2, 2), (2, 2), (0, 0))
+    gy4 = CP.copy(rng.standard_normal(y4.shape).astype(np.float32))
+    p1 = CP.copy(rng.random((32, 256, 512, 1)).astype(np.float32))
+    t1 = CP.copy((rng.random((32, 256, 512, 1)) > 0.5).astype(np.float32))
+    logits = CP.copy(rng.standard_normal((2048, 162)).astype(np.float32))
+    onehot = CP.copy(np.eye(162, dtype=np.float32)[rng.integers(0, 162, 2048)])
+    wbuf, gbuf, vbuf = CP.zeros((1 << 22,)), CP.zeros((1 << 22,)), CP.zeros((1 << 22,))
+    mb = lambda *arrs: sum(a.nbytes for a in arrs)
+    rows = (
+        ('maxpool 2x2 fwd (x -> y + u8 mask)', lambda: ops.maxpool2d_fwd(x4, (2, 2), (2, 2), (0, 0)), mb(x4, y4, mask)),
+        ('maxpool 2x2 bwd (dy, mask -> dx)', lambda: ops.maxpool2d_bwd(gy4, mask, x4.shape, (2, 2), (2, 2), (0, 0)),
+         mb(gy4, mask, x4)),
+        ('upsample 2x fwd (4 ch, vector)', lambda: ops.upsample2d_fwd(lo4, (2, 2)), mb(lo4, x4)),
+        ('upsample 2x bwd (4 ch, vector)', lambda: ops.upsample2d_bwd(g4, lo4.shape, (2, 2)), mb(lo4, x4)),
+        ('leaky bwd from output', lambda: ops.act_bwd_from_output('leaky', x4, g4, 0.01), mb(x4, g4, x4)),
+        ('sigmoid fwd', lambda: rt.call('uocr_act_fwd', x4.code, 3, 0.0, x4.ptr, g4.ptr, x4.size), mb(x4, g4)),
+        ('dice loss + grad (1 ch, folded sigmoid)', lambda: ops.seg_loss('dice', p1, t1, True, out_act='sigmoid'),
+         mb(p1, t1) + mb(p1, t1, p1)),
+        ('softmax CE + grad (2048 x 162)', lambda: ops.softmax_ce(logits, onehot, True), mb(logits, onehot, logits)),
+        ('SGD step (4M parameters)', lambda: ops.momentum_step(wbuf, gbuf, vbuf, 0.01, 0.0), mb(wbuf, gbuf) + mb(wbuf, vbuf)),
+    )
+    for name, fn, nb in rows:
+        us = timed(fn)
+        print(f'{name:40s} {us:8.1f} us  {nb / 1e6:8.1f} MB  {nb / us / 1e3:8.0f} GB/s')
+
 
 if __name__ == '__main__':
     main()

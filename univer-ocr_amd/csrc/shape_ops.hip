@@ -109,6 +109,83 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
     }
 }
 
+// 2x2 / stride 2 / no padding / even h, w / c % 4 == 0 (float32): the windows tile the image, so the mask
+// has exactly the layout of x (mask[b][2oy+ky][2ox+kx][ch]) and every input pixel belongs to one window.
+// One thread per (window, channel quad): 4 x 16-B loads, one 16-B store of y, four 4-B mask stores;
+// the same comparison chain as maxpool_fwd_kernel (NaN sticks).
+__device__ __forceinline__ float pool_max4(float a, float b, float c, float d) {
+    float best = a;
+    if (best == best && (b > best || b != b)) best = b;
+    if (best == best && (c > best || c != c)) best = c;
+    if (best == best && (d > best || d != d)) best = d;
+    return best;
+}
+
+__device__ __forceinline__ uint32_t pool_mask4(const float4& v, const float4& m) {
+    return (v.x == m.x ? 1u : 0u) | (v.y == m.y ? 0x100u : 0u) | (v.z == m.z ? 0x10000u : 0u) |
+           (v.w == m.w ? 0x1000000u : 0u);
+}
+
+__global__ __launch_bounds__(256) void maxpool2_fwd_vec(const float4* __restrict__ x, float4* __restrict__ y,
+                                                        uint32_t* __restrict__ mask, size_t windows, int ow, int cq) {
+    // windows = n*oh*ow*cq; x / mask rows hold 2*ow*cq quads
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < windows;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % cq);
+        const size_t t = idx / cq;
+        const int ox = (int)(t % ow);
+        const size_t row = t / ow;                      // b*oh + oy
+        const size_t rq = (size_t)2 * ow * cq;          // quads per input row
+        const size_t i00 = (row * 2) * rq + (size_t)(2 * ox) * cq + q;
+        const float4 a = x[i00], b = x[i00 + cq], c = x[i00 + rq], d = x[i00 + rq + cq];
+        float4 m;
+        m.x = pool_max4(a.x, b.x, c.x, d.x);
+        m.y = pool_max4(a.y, b.y, c.y, d.y);
+        m.z = pool_max4(a.z, b.z, c.z, d.z);
+        m.w = pool_max4(a.w, b.w, c.w, d.w);
+        y[idx] = m;
+        mask[i00] = pool_mask4(a, m);
+        mask[i00 + cq] = pool_mask4(b, m);
+        mask[i00 + rq] = pool_mask4(c, m);
+        mask[i00 + rq + cq] = pool_mask4(d, m);
+    }
+}
+
+__device__ __forceinline__ float4 pool_scatter4(uint32_t m, const float4& g) {
+    return make_float4((m & 0xffu) ? g.x : 0.f, (m & 0xff00u) ? g.y : 0.f, (m & 0xff0000u) ? g.z : 0.f,
+                       (m & 0xff000000u) ? g.w : 0.f);
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_vec(const float4* __restrict__ dy, const uint32_t* __restrict__ mask,
+                                                        float4* __restrict__ dx, size_t windows, int ow, int cq) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < windows;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % cq);
+        const size_t t = idx / cq;
+        const int ox = (int)(t % ow);
+        const size_t row = t / ow;
+        const size_t rq = (size_t)2 * ow * cq;
+        const size_t i00 = (row * 2) * rq + (size_t)(2 * ox) * cq + q;
+        const uint32_t ma = mask[i00], mb = mask[i00 + cq], mc = mask[i00 + rq], md = mask[i00 + rq + cq];
+        const uint32_t cnt = ma + mb + mc + md;         // per byte: 1..4 set bits (the max itself is always set)
+        float4 g = dy[idx];
+        g.x /= (float)(cnt & 0xffu);
+        g.y /= (float)((cnt >> 8) & 0xffu);
+        g.z /= (float)((cnt >> 16) & 0xffu);
+        g.w /= (float)(cnt >> 24);
+        dx[i00] = pool_scatter4(ma, g);
+        dx[i00 + cq] = pool_scatter4(mb, g);
+        dx[i00 + rq] = pool_scatter4(mc, g);
+        dx[i00 + rq + cq] = pool_scatter4(md, g);
+    }
+}
+
+bool maxpool2_vec_ok(int dtype, const PoolDims& d, const void* a, const void* b, const void* c) {
+    return dtype == UOCR_F32 && d.kh == 2 && d.kw == 2 && d.sh == 2 && d.sw == 2 && d.ph == 0 && d.pw == 0 &&
+           d.h == 2 * d.oh && d.w == 2 * d.ow && d.c % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 &&
+           ((uintptr_t)c % 4) == 0;
+}
+
 // y[b, Y, X, c] = x[b, Y / sy, X / sx, c]   (upsample.py:21-25)
 template <typename T>
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int h,
@@ -282,6 +359,13 @@ int uocr_maxpool2d_fwd(uocr_ctx* ctx, int dtype, const void* x, void* y, uint8_t
     // every window must start inside the padded extent (true for maxpool.py:204-216 shapes)
     UOCR_REQUIRE(ctx, (oh - 1) * sh < h + 2 * ph && (ow - 1) * sw < wd + 2 * pw);
     const size_t total = (size_t)n * oh * ow * c;
+    if (maxpool2_vec_ok(dtype, d, x, y, mask)) {
+        const size_t windows = total / 4;
+        hipLaunchKernelGGL(maxpool2_fwd_vec, dim3(uocr_blocks_for(windows, 256, UOCR_MAX_GRID * 4)), dim3(256), 0,
+                           ctx->stream, (const float4*)x, (float4*)y, (uint32_t*)mask, windows, ow, c / 4);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
     UOCR_DISPATCH(ctx, dtype, {
         hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4)), dim3(256), 0,
                            ctx->stream, (const T*)x, (T*)y, mask, d);
@@ -296,6 +380,13 @@ int uocr_maxpool2d_bwd(uocr_ctx* ctx, int dtype, const void* dy, const uint8_t* 
     const PoolDims d{n, h, wd, c, kh, kw, sh, sw, ph, pw, oh, ow};
     UOCR_REQUIRE(ctx, dy && dx && mask && pool_dims_ok(d));
     const size_t total = (size_t)n * h * wd * c;
+    if (maxpool2_vec_ok(dtype, d, dy, dx, mask)) {
+        const size_t windows = (size_t)n * oh * ow * c / 4;
+        hipLaunchKernelGGL(maxpool2_bwd_vec, dim3(uocr_blocks_for(windows, 256, UOCR_MAX_GRID * 4)), dim3(256), 0,
+                           ctx->stream, (const float4*)dy, (const uint32_t*)mask, (float4*)dx, windows, ow, c / 4);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
     UOCR_DISPATCH(ctx, dtype, {
         hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4)), dim3(256), 0,
                            ctx->stream, (const T*)dy, mask, (T*)dx, d);
