@@ -23,6 +23,7 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->opt_fast = 1;
     ctx->opt_tiled = 1;
     ctx->opt_split = 1024;
+    ctx->opt_split_min = 3;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return UOCR_ERR_HIP;
@@ -70,6 +71,7 @@ int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "fast_paths")) ctx->opt_fast = value;
     else if (!strcmp(key, "tiled")) ctx->opt_tiled = value;
     else if (!strcmp(key, "split_blocks")) ctx->opt_split = value;
+    else if (!strcmp(key, "split_min")) ctx->opt_split_min = value;
     else UOCR_FAIL(ctx, UOCR_ERR_ARG, "unknown option '%s'", key);
     return UOCR_OK;
 }

@@ -456,6 +456,7 @@ int launch_mfma(uocr_ctx* ctx, const ALoader& A, const BRowMajor& B, const Epilo
         const size_t per = (size_t)M * N * sizeof(float);
         if ((size_t)nsplit * per > ws_half(ctx)) nsplit = (int)(ws_half(ctx) / per);
         if (nsplit < 1) nsplit = 1;
+        if (nsplit < ctx->opt_split_min) nsplit = 1;
     }
     const int tps = (ntiles + nsplit - 1) / nsplit;
     nsplit = (ntiles + tps - 1) / tps;

@@ -18,6 +18,7 @@ struct uocr_ctx {
     int opt_fast;        // 0 = generic kernels only, 1 = shape-specialised fast paths (default)
     int opt_tiled;       // 0 = no LDS-tiled conv kernels, 1 = use them where instantiated (default)
     int opt_split;       // MFMA GEMMs split their depth until there are about this many blocks (0 = never)
+    int opt_split_min;   // ... but only when that takes at least this many slabs (a 2-way split rarely pays its reduce)
     char err[512];
 };
 
