@@ -152,12 +152,11 @@ def main():
                          'device (PCIe-inclusive rate; flagged in metric and config, never the headline value)')
     args = ap.parse_args()
 
-    # Pipelined lanes: give every net stream its own hardware queue (ROCm's default is 4 queues per process
-    # for main + 4 nets + RCCL/copy streams, so two nets share one and run one after the other: 1.25 ->
-    # 1.13 ms/step).  Read by the HIP runtime when it starts, hence set before torch touches the GPU.  Not for
-    # the joined mode: with more queues than 4 its per-step cross-queue event waits cost 1.3 ms/step.
-    if not args.no_pipeline and not args.h2d:          # (the upload pipeline waits across streams every step)
-        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+    # One hardware queue per stream: ROCm's default is 4 queues per process for main + 3 net lanes + copy /
+    # RCCL streams, so two of them share a queue and run one after the other (1.25 -> 1.10 ms/step).  The GPU
+    # keeps 4 queues running at a time, which is why PageTrainer uses 3 lanes, not 4.  Read by the HIP runtime
+    # when it starts, hence set before torch touches the GPU.
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
     import torch
     import torch.distributed as dist

@@ -15,6 +15,7 @@ def main():
     ap.add_argument('--skip-input-grads', action='store_true')
     ap.add_argument('--graphs', action='store_true')
     ap.add_argument('--pipelined', action='store_true')
+    ap.add_argument('--lanes4', action='store_true', help='one lane per net instead of the 3 balanced lanes')
     ap.add_argument('--option', action='append', default=[], help='ctx option key=value (applied to every lane)')
     ap.add_argument('--only', default='', help='comma-separated nets: time just this combination')
     args = ap.parse_args()
@@ -32,7 +33,8 @@ def main():
     combos = [tuple(args.only.split(','))] if args.only else [(n,) for n in all_nets] + [all_nets]
     for nets in combos:
         trainer = PageTrainer(args.batch, 256, 512, 64, nets=nets, input_grads=not args.skip_input_grads,
-                              graphs=args.graphs, pipelined=args.pipelined)
+                              graphs=args.graphs, pipelined=args.pipelined,
+                              **({'lane_groups': None} if args.lanes4 else {}))
         for opt in args.option:
             k, v = opt.split('=')
             CP.runtime().set_option(k, int(v))

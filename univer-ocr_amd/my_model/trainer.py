@@ -27,7 +27,8 @@ def make_optimizer(name, lr):
 class PageTrainer:
     def __init__(self, batch, height=256, width=512, char_width=64, optimizer='sgd', lr=0.0015, seed=0,
                  nets=('Monochrome', 'Paragraph', 'Line', 'Char'), data_parallel=None, overlap=True,
-                 init='kaiming_normal', fuse=True, lanes=True, input_grads=True, graphs=False, eager_nets=(), pipelined=False):
+                 init='kaiming_normal', fuse=True, lanes=True, input_grads=True, graphs=False, eager_nets=(), pipelined=False,
+                 lane_groups=(('Monochrome', 'Paragraph'), ('Line',), ('Char',))):
         np.random.seed(seed)                        # kaiming_uniform draws from the NumPy global RNG
         self.batch = batch
         self.optimizer = make_optimizer(optimizer, lr)
@@ -47,7 +48,19 @@ class PageTrainer:
         if lanes and CP.has_device() and len(self.models) > 1:
             rt = CP.runtime()
             # (high-priority streams for the latency-bound nets were tried: 1.44 -> 2.54 ms/step)
-            self.lanes = {name: rt.add_lane() for name in self.models}
+            # Nets of one group share a lane and run one after the other in it.  Default: 3 lanes of about
+            # equal length (Monochrome + Paragraph ~ Line ~ Char): the GPU keeps 4 hardware queues running at
+            # a time, and with 4 lanes the 5th stream that has work (main in the joined mode, RCCL's stream
+            # under data parallelism) gets time-sliced against them (1.3 -> 2.6 ms/step measured)
+            self.lanes = {}
+            for group in lane_groups or [(name,) for name in self.models]:
+                members = [name for name in group if name in self.models]
+                if members:
+                    lane = rt.add_lane()
+                    self.lanes.update({name: lane for name in members})
+            for name in self.models:                   # nets not named in any group: a lane each
+                if name not in self.lanes:
+                    self.lanes[name] = rt.add_lane()
         # HIP graphs: each net's forward+loss+backward and its L2+optimizer tail are captured once and
         # replayed (two hipGraphLaunch per net and step instead of ~40 launches); needs lanes
         self.graphs = bool(graphs) and self.lanes is not None

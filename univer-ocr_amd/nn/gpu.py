@@ -15,6 +15,11 @@ bucketing logic are testable; any kernel call then fails loudly.
 import os
 
 import numpy as np
+# One hardware queue per stream (main, the PageTrainer lanes, copy / RCCL streams): ROCm's default of 4 per
+# process makes streams share queues and run one after the other.  Read by the HIP runtime when it starts,
+# i.e. at the first torch.cuda call after this import; an explicit setting in the environment wins.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 import torch
 
 from ..hip import lib as hiplib
