@@ -230,12 +230,12 @@ class PageTrainer:
             entry = {}
             with rt.lane(self.lanes[comp.name]) as stream:
                 begin = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(begin, stream=stream):
+                with torch.cuda.graph(begin, stream=stream, capture_error_mode='thread_local'):
                     model.train_begin(X, y)
                     comp._publish()
                 pending = model._pending_losses
                 finish = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(finish, stream=stream):
+                with torch.cuda.graph(finish, stream=stream, capture_error_mode='thread_local'):
                     losses = model.train_finish()
             for value in pending + [losses['regularization_loss']]:
                 if not isinstance(value, DeviceScalar):
