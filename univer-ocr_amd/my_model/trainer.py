@@ -146,9 +146,14 @@ class PageTrainer:
         return context['losses']
 
     def _lane_order(self):
-        """Enqueue order of the lanes: the nets that are long chains of short kernels first (their chain is
-        the critical path of the concurrent step), the nets of few long kernels last."""
-        rank = {'Char': 0, 'Paragraph': 1, 'Line': 2, 'Monochrome': 3}
+        """Enqueue order of the nets.  One process: the nets that are long chains of short kernels first
+        (their chain is the critical path of the concurrent step), the nets of few long kernels last.
+        Data parallel: shortest net first -- all gradient all-reduces share RCCL's one in-order stream, so a
+        collective issued behind the Char net's would wait for Char's backward and couple the lanes."""
+        if self.dp is not None:
+            rank = {'Paragraph': 0, 'Monochrome': 1, 'Line': 2, 'Char': 3}
+        else:
+            rank = {'Char': 0, 'Paragraph': 1, 'Line': 2, 'Monochrome': 3}
         return sorted(self.model_system.components, key=lambda comp: rank.get(comp.name, 9))
 
     def _step_lanes(self, context):
