@@ -339,3 +339,19 @@ def test_pipelined_lanes_match_joined_steps(graphs):
     assert np.array_equal(results[0][1], results[1][1])
     for name, w in results[0][2].items():
         assert np.array_equal(np.asarray(w), np.asarray(results[1][2][name])), name
+
+
+def test_get_weights_single_transfer_equals_per_parameter_lists():
+    """Model.get_weights(): one D2H copy of the flat ParamPack, sliced on the host == layer.get_weights()
+    (one tolist() per parameter, layers.py:120-121); JSON layout unchanged."""
+    from univer_ocr_amd.my_model.model import NET_MAKERS
+    from univer_ocr_amd.nn import CP
+    from univer_ocr_amd.nn.optimizers import Momentum
+    CP.use_gpu(0)
+    CP.set_dtype('float32')
+    model = NET_MAKERS['Line']((1, 32, 64, 1), Momentum(lr=0.01, momentum=0))
+    assert model.pack is not None
+    packed = model.get_weights()
+    per_layer = {name: layer.get_weights() for name, layer in model.layers.items() if layer.params()}
+    assert packed == per_layer and 'Line/end/conv_1' in packed
+    assert np.array(packed['Line/end/conv_1']['w']).shape == (5, 5, 4, 2)

@@ -563,6 +563,21 @@ class Model(BaseModel):
         return self._reg_ranges
 
     def get_weights(self):
+        """models.py:455-459 / layers.py:120-121: {layer: {param: nested lists}}.  With a ParamPack the whole
+        model comes down in ONE device-to-host copy of the flat buffer (the reference does one `tolist()`
+        = one transfer per parameter)."""
+        if self._pack is not None:
+            host = self._pack.value.numpy()
+            where = {id(p): (off, size) for p, off, size in self._pack.entries}
+            weights = {}
+            for name, layer in self.layers.items():
+                params = layer.params()
+                if params and all(id(p) in where for p in params.values()):
+                    weights[name] = {pname: host[where[id(p)][0]:where[id(p)][0] + where[id(p)][1]]
+                                     .reshape(p.value.shape).tolist() for pname, p in params.items()}
+                elif params:
+                    weights[name] = layer.get_weights()
+            return weights
         weights = {name: layer.get_weights() for name, layer in self.layers.items()}
         return {name: w for name, w in weights.items() if w != {}}
 
