@@ -31,7 +31,7 @@ def _slice(layers, lo, hi, cw):
     return out
 
 
-def _worker(rank, world, port, results, graphs, steps):
+def _worker(rank, world, port, results, graphs, steps, pipelined):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -44,12 +44,14 @@ def _worker(rank, world, port, results, graphs, steps):
         CP.set_dtype('float64')
         CP.lazy_losses = graphs
         per = BATCH // world
-        trainer = PageTrainer(per, H, W, CW, optimizer='sgd', lr=0.01, seed=5 + rank, overlap=True, graphs=graphs)
+        trainer = PageTrainer(per, H, W, CW, optimizer='sgd', lr=0.01, seed=5 + rank, overlap=True, graphs=graphs,
+                              pipelined=pipelined)
         assert trainer.dp is not None
         layers = make_page_batch(BATCH, H, W, CW, seed=77)
         context = trainer.make_context(_slice(layers, rank * per, (rank + 1) * per, CW))
         for _ in range(steps):
             trainer.step(context)
+        trainer.join()
         assert (trainer._captured is not None) == graphs
         ok = all(trainer.dp.replicas_in_sync(m) for m in trainer.models.values())
         weights = {n: p.value.numpy() for m in trainer.models.values() for n, p in m.params().items()}
@@ -58,15 +60,16 @@ def _worker(rank, world, port, results, graphs, steps):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('graphs,steps', [(False, 2), (True, 5)])
-def test_two_ranks_equal_one_process_on_the_whole_batch(graphs, steps):
-    """graphs=True: steps 3-5 replay the per-net HIP graphs with the all-reduce issued between them."""
+@pytest.mark.parametrize('graphs,steps,pipelined', [(False, 2, False), (True, 5, False), (False, 4, True)])
+def test_two_ranks_equal_one_process_on_the_whole_batch(graphs, steps, pipelined):
+    """graphs=True: steps 3-5 replay the per-net HIP graphs with the all-reduce issued between them;
+    pipelined=True: no per-step join of the lanes (the bench default)."""
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     with ctx.Manager() as manager:
         results = manager.dict()
-        mp.spawn(_worker, args=(world, port, results, graphs, steps), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, results, graphs, steps, pipelined), nprocs=world, join=True)
         results = dict(results)
     assert results[0][0] and results[1][0], 'replicas diverged'
     for name in results[0][1]:
