@@ -235,10 +235,16 @@ def main():
         feeder = PageFeeder(layers_u8)
         feeder.stage(layers_u8)
 
+    statics = {}
+
     def one_step():
         if feeder is None:
             return trainer.step(context)
-        ctx = feeder.context()          # batch i (uploaded while step i-1 ran)
+        if statics:                     # graph replay: convert straight into the arrays the graphs read
+            trainer.join()              # ... once the lanes are done with the previous batch
+            ctx = feeder.context(into=statics)
+        else:
+            ctx = feeder.context()      # batch i (uploaded while step i-1 ran)
         feeder.stage(layers_u8)         # start the upload of batch i+1
         return trainer.step(ctx)
 
@@ -250,6 +256,8 @@ def main():
                   file=sys.stderr, flush=True)
             trainer.graphs, trainer._captured, args.graphs = False, None, False
             torch.cuda.synchronize()
+        if feeder is not None and args.graphs:
+            statics.update(trainer.static_inputs())
     for _ in range(args.warmup):
         losses = one_step()
     barrier()

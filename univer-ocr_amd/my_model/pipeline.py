@@ -56,16 +56,20 @@ class PageFeeder:
             slot['ready'].record(self.copy_stream)
         self._staged.append(slot)
 
-    def context(self):
-        """Device float context of the oldest staged batch; the compute stream waits for its upload only."""
+    def context(self, into=None):
+        """Device float context of the oldest staged batch; the compute stream waits for its upload only.
+        `into` = {label: DeviceArray}: convert into these arrays (the static inputs of a graph-replaying
+        trainer, `PageTrainer.static_inputs()`) instead of allocating; the caller makes sure nothing still
+        reads them (`PageTrainer.join()`)."""
         slot = self._staged.pop(0)
         compute = torch.cuda.current_stream()
         compute.wait_event(slot['ready'])
         made, context = {}, {}
         for label, (tag, scale) in self.feeds.items():
-            key = (tag, scale)
+            target = None if into is None else into.get(label)      # labels of eager nets: a fresh array
+            key = (tag, scale) if target is None else (tag, scale, id(target))
             if key not in made:
-                made[key] = ops.u8_to_float(DeviceArray(slot['dev'][tag]), scale)
+                made[key] = ops.u8_to_float(DeviceArray(slot['dev'][tag]), scale, out=target)
             context[label] = made[key]
         slot['free'].record(compute)
         return context

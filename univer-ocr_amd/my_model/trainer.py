@@ -263,6 +263,11 @@ class PageTrainer:
             self.step(context)
         return self
 
+    def static_inputs(self):
+        """{context label: the array the captured graphs read}, or None before capture.  Filling these in
+        place (after join()) and passing them to step() avoids the copy into the statics."""
+        return dict(self._statics) if self._captured is not None else None
+
     def _static_input(self, label, array):
         """The array the graphs read for `label`: the trainer's own input buffer if the caller uses
         make_context(), otherwise a private clone (a foreign array is never written to)."""

@@ -302,8 +302,11 @@ def zero_(x):
     _rt().call('uocr_memset_zero', x.ptr, x.nbytes)
 
 
-def u8_to_float(src_u8, scale=1.0 / 255.0, dtype=None):
-    out = CP.empty(src_u8.shape, CP.dtype if dtype is None else dtype)
+def u8_to_float(src_u8, scale=1.0 / 255.0, dtype=None, out=None):
+    if out is None:
+        out = CP.empty(src_u8.shape, CP.dtype if dtype is None else dtype)
+    elif out.shape != src_u8.shape:
+        raise AssertionError(f'u8_to_float: out {out.shape} != source {src_u8.shape}')
     _rt().call('uocr_u8_to_float', out.code, src_u8.ptr, out.ptr, float(scale), out.size)
     return out
 
