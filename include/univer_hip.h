@@ -213,6 +213,13 @@ int uocr_adam_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* v, vo
 int uocr_momentum_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* v, size_t count,
                        double lr, double momentum);
 /* a=rho*a+(1-rho)g^2; w-=lr/(sqrt(a)+eps)*g  (:92-95) */
+/* The tail of a train step in one pass over the flat parameter buffer: for up to 4 index ranges [lo, hi)
+ * grad += dR/dw (kind 1 = L1, 2 = L2: regularizations.py:15-26 as applied in layers.py:147-155), then the
+ * Momentum update (optimizers.py:75-78), then grad = 0 when zero_grad (Param.clear_grad, layers.py:20-21);
+ * *reg_loss_out = sum_r strength_r * R_r (float64 device slot).  lo / hi / kind / strength are HOST arrays. */
+int uocr_momentum_step_fused(uocr_ctx* ctx, int dtype, void* w, void* g, void* v, size_t count, double lr,
+                             double momentum, int nranges, const long long* lo, const long long* hi,
+                             const int* kind, const double* strength, double* reg_loss_out, int zero_grad);
 int uocr_rmsprop_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* a, size_t count,
                       double lr, double rho, double eps);
 /* *flag_out (int32, device) = 1 if any element is NaN else 0  (nan_weights, layers.py:139-140) */

@@ -343,3 +343,38 @@ def test_maxpool2_vector_kernels_match_generic(shape, f32):
     dx = ops.maxpool2d_bwd(CP.copy(g), mask, X.shape, (2, 2), (2, 2), (0, 0))
     check(dx, O.maxpool2d_bwd(g, ref_mask, X.shape, (2, 2), (2, 2), (0, 0)), 1e-6, 'dx')
     CP.runtime().set_option('fast_paths', 1)
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+def test_fused_momentum_tail_matches_separate_calls(dtype):
+    """uocr_momentum_step_fused (regularisers of up to 4 ranges + Momentum update + gradient reset) == the three
+    separate entry points in the same order, to one rounding (the compiler contracts multiply-adds differently
+    when the regularised gradient stays in a register) and to 1e-14 for the loss."""
+    from univer_ocr_amd.nn import CP, ops
+    CP.set_dtype(dtype)
+    try:
+        rng = np.random.default_rng(3)
+        n = 5000
+        w0, g0, v0 = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n) * 0.1
+        ranges = [(('l2', 0.01), 0, 1024), (('l1', 0.02), 2048, 3000), (('l2', 0.005), 4096, 5000)]
+        w, g, v = CP.copy(w0), CP.copy(g0), CP.copy(v0)
+        slot = CP.zeros((1,), np.float64)
+        for (kind, strength), lo, hi in ranges:
+            ops.regularize(kind, type(w)(w.t[lo:hi]), type(g)(g.t[lo:hi]), strength, slot, True)
+        ops.momentum_step(w, g, v, 0.05, 0.9)
+        ref_loss = float(slot.t.item())
+        w2, g2, v2 = CP.copy(w0), CP.copy(g0), CP.copy(v0)
+        loss = ops.momentum_step_fused(w2, g2, v2, 0.05, 0.9, ranges)
+        eps = 4 * float(np.finfo(np.dtype(dtype)).eps)
+        assert rel_linf(CP.asnumpy(w2), CP.asnumpy(w).astype(np.float64)) <= eps
+        assert rel_linf(CP.asnumpy(v2), CP.asnumpy(v).astype(np.float64)) <= eps
+        assert not np.any(CP.asnumpy(g2))
+        assert abs(float(loss) - ref_loss) <= 1e-14 * max(1.0, abs(ref_loss))
+        # no ranges: plain momentum + reset
+        w3, g3, v3 = CP.copy(w0), CP.copy(g0), CP.copy(v0)
+        assert ops.momentum_step_fused(w3, g3, v3, 0.05, 0.9, []) == 0
+        w4, g4, v4 = CP.copy(w0), CP.copy(g0), CP.copy(v0)
+        ops.momentum_step(w4, g4, v4, 0.05, 0.9)
+        assert rel_linf(CP.asnumpy(w3), CP.asnumpy(w4).astype(np.float64)) <= eps and not np.any(CP.asnumpy(g3))
+    finally:
+        CP.set_dtype('float32')

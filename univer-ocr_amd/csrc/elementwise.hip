@@ -255,6 +255,68 @@ __global__ __launch_bounds__(256) void momentum_kernel(T* w, const T* g, T* v, s
     }
 }
 
+// Momentum step with the regulariser gradients and the gradient reset folded in (the tail of a train step:
+// layers.py:147-155 regularize, optimizers.py:75-78 update, layers.py:20-21 clear_grad = 4 launches -> 2).
+// Same float operations in the same order as reg_kernel followed by momentum_kernel.
+struct RegRanges {
+    long long lo[4], hi[4];
+    int kind[4];          // 1 = L1, 2 = L2
+    double strength[4];
+    int n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void momentum_fused_kernel(T* w, T* g, T* v, size_t n, T lr, T mu, RegRanges rr,
+                                                             double* partial /* [grid][4] */, int zero_grad) {
+    __shared__ double smem[16];
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (size_t i = tid; i < n; i += stride) {
+        const T wi = w[i];
+        T gi = g[i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r < rr.n && (long long)i >= rr.lo[r] && (long long)i < rr.hi[r]) {
+                const T strength = (T)rr.strength[r];
+                if (rr.kind[r] == 2) {
+                    gi += strength * T(2) * wi;
+                    acc[r] += (double)wi * (double)wi;
+                } else {
+                    const T s = wi > T(0) ? T(1) : (wi < T(0) ? T(-1) : (wi == T(0) ? T(0) : wi));
+                    gi += strength * s;
+                    acc[r] += (double)(wi < T(0) ? -wi : wi);
+                }
+            }
+        }
+        const T vi = mu * v[i] - lr * gi;
+        v[i] = vi;
+        w[i] = wi + vi;
+        g[i] = zero_grad ? T(0) : gi;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double t = block_reduce_sum(acc[r], smem);
+        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * 4 + r] = t;
+        __syncthreads();
+    }
+}
+
+// out = sum_r strength_r * sum_blocks partial[block][r]   (one block)
+__global__ __launch_bounds__(256) void fused_reg_finish_kernel(const double* partial, int nblocks, RegRanges rr,
+                                                               double* out) {
+    __shared__ double smem[16];
+    double total = 0.0;
+    for (int r = 0; r < rr.n; ++r) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < nblocks; i += blockDim.x) acc += partial[(size_t)i * 4 + r];
+        acc = block_reduce_sum(acc, smem);
+        __syncthreads();
+        total += rr.strength[r] * acc;
+    }
+    if (threadIdx.x == 0) *out = total;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void rmsprop_kernel(T* w, const T* g, T* a, size_t n, T lr, T rho, T eps) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -478,6 +540,40 @@ int uocr_momentum_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* v
                            ctx->stream, (T*)w, (const T*)g, (T*)v, count, (T)lr, (T)momentum);
         UOCR_LAUNCH_CHECK(ctx);
     });
+    return UOCR_OK;
+}
+
+int uocr_momentum_step_fused(uocr_ctx* ctx, int dtype, void* w, void* g, void* v, size_t count, double lr,
+                             double momentum, int nranges, const long long* lo, const long long* hi, const int* kind,
+                             const double* strength, double* reg_loss_out, int zero_grad) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, nranges >= 0 && nranges <= 4 && (nranges == 0 || (lo && hi && kind && strength)));
+    UOCR_REQUIRE(ctx, nranges == 0 || reg_loss_out);
+    if (!count) return UOCR_OK;
+    UOCR_REQUIRE(ctx, w && g && v);
+    RegRanges rr{};
+    rr.n = nranges;
+    for (int r = 0; r < nranges; ++r) {
+        UOCR_REQUIRE(ctx, (kind[r] == 1 || kind[r] == 2) && lo[r] >= 0 && lo[r] <= hi[r] && (size_t)hi[r] <= count);
+        rr.lo[r] = lo[r];
+        rr.hi[r] = hi[r];
+        rr.kind[r] = kind[r];
+        rr.strength[r] = strength[r];
+    }
+    const unsigned grid = uocr_blocks_for(count, 256, 512);
+    int rc = uocr_need_workspace(ctx, (size_t)grid * 4 * sizeof(double));
+    if (rc) return rc;
+    double* partial = (double*)ctx->workspace;
+    UOCR_DISPATCH(ctx, dtype, {
+        hipLaunchKernelGGL((momentum_fused_kernel<T>), dim3(grid), dim3(256), 0, ctx->stream, (T*)w, (T*)g, (T*)v, count,
+                           (T)lr, (T)momentum, rr, partial, zero_grad);
+        UOCR_LAUNCH_CHECK(ctx);
+    });
+    if (nranges > 0) {
+        hipLaunchKernelGGL(fused_reg_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)partial, (int)grid,
+                           rr, reg_loss_out);
+        UOCR_LAUNCH_CHECK(ctx);
+    }
     return UOCR_OK;
 }
 

@@ -468,10 +468,9 @@ class Model(BaseModel):
         return {'output_losses': losses, 'regularization_loss': self.regularize()}
 
     def train(self, X, y):
-        losses = self.compute_loss_and_gradients(X, y)
-        self.update_grads()
-        self.clear_grads()
-        return losses
+        """models.py:250-254: compute_loss_and_gradients, update_grads, clear_grads."""
+        self.train_begin(X, y)
+        return self.train_finish()
 
     # two-phase train step: lets a data-parallel driver overlap this model's gradient all-reduce
     # with the next model's forward/backward (parallel.DataParallel, my_model/trainer.py)
@@ -481,11 +480,33 @@ class Model(BaseModel):
     def train_finish(self):
         if self.grad_sync is not None and self.defer_grad_sync:
             self.grad_sync.__self__.wait(self)
+        fused = self._fused_tail()
+        if fused is not None:                         # regularize + update + clear_grads in one pass
+            losses = {'output_losses': self._pending_losses, 'regularization_loss': fused}
+            self._pending_losses = None
+            self.input_grads = {}
+            return losses
         losses = {'output_losses': self._pending_losses, 'regularization_loss': self.regularize()}
         self._pending_losses = None
         self.update_grads()
         self.clear_grads()
         return losses
+
+    def _fused_tail(self):
+        """The three calls that end a train step (models.py:252-254: regularize via compute_loss_and_gradients,
+        update_grads, clear_grads) as ONE kernel over the flat pack when the whole model is trained by one
+        Momentum optimizer and has at most 4 L1/L2 ranges; None = not applicable, run them one by one."""
+        from .optimizers import Momentum
+        pack = self._pack
+        if pack is None or not self.trainable or not all(layer.trainable for layer in self.layers.values()):
+            return None
+        optimizer = pack.same_optimizer()
+        if type(optimizer) is not Momentum:
+            return None
+        ranges = self._regularizer_ranges()
+        if len(ranges) > 4 or any(key[0] not in ('l1', 'l2') for key, _, _ in ranges):
+            return None
+        return optimizer.update_pack_fused(pack, ranges)
 
     def test(self, X, y):
         predicted = self.forward(make_list_if_not(X))

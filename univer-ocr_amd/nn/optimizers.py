@@ -119,6 +119,14 @@ class Momentum(BaseOptimizer):
         f = self._flats(pack)
         ops.momentum_step(pack.value, pack.grad, f['velocity'], self.lr, self.momentum)
 
+    def update_pack_fused(self, pack, reg_ranges):
+        """Regularisers + update + gradient reset in one pass over the pack (Model.train_finish).
+        Returns the regularisation loss."""
+        f = self._flats(pack)
+        loss = ops.momentum_step_fused(pack.value, pack.grad, f['velocity'], self.lr, self.momentum, reg_ranges)
+        pack.grad_dirty = False                     # the kernel left the gradient buffer zeroed
+        return loss
+
 
 class RMSProp(BaseOptimizer):
     state_names = ('accumulated',)
