@@ -220,6 +220,11 @@ int uocr_momentum_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* v
 int uocr_momentum_step_fused(uocr_ctx* ctx, int dtype, void* w, void* g, void* v, size_t count, double lr,
                              double momentum, int nranges, const long long* lo, const long long* hi,
                              const int* kind, const double* strength, double* reg_loss_out, int zero_grad);
+/* the same with the Adam update of optimizers.py:56-61 (no bias correction, as the reference) */
+int uocr_adam_step_fused(uocr_ctx* ctx, int dtype, void* w, void* g, void* v, void* a, size_t count, double lr,
+                         double beta1, double beta2, double eps, int nranges, const long long* lo,
+                         const long long* hi, const int* kind, const double* strength, double* reg_loss_out,
+                         int zero_grad);
 int uocr_rmsprop_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* a, size_t count,
                       double lr, double rho, double eps);
 /* *flag_out (int32, device) = 1 if any element is NaN else 0  (nan_weights, layers.py:139-140) */

@@ -378,3 +378,28 @@ def test_fused_momentum_tail_matches_separate_calls(dtype):
         assert rel_linf(CP.asnumpy(w3), CP.asnumpy(w4).astype(np.float64)) <= eps and not np.any(CP.asnumpy(g3))
     finally:
         CP.set_dtype('float32')
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+def test_fused_adam_tail_matches_separate_calls(dtype):
+    """uocr_adam_step_fused == uocr_l2_reg on the range, then uocr_adam_step, then a zeroed gradient."""
+    from univer_ocr_amd.nn import CP, ops
+    CP.set_dtype(dtype)
+    try:
+        rng = np.random.default_rng(4)
+        n = 4100
+        arrs = [rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n) * 0.1, rng.random(n) * 0.1]
+        ranges = [(('l2', 0.01), 64, 4096)]
+        w, g, v, a = (CP.copy(x) for x in arrs)
+        slot = CP.zeros((1,), np.float64)
+        ops.regularize('l2', type(w)(w.t[64:4096]), type(g)(g.t[64:4096]), 0.01, slot, True)
+        ops.adam_step(w, g, v, a, 0.01, 0.9, 0.999, 1e-8)
+        w2, g2, v2, a2 = (CP.copy(x) for x in arrs)
+        loss = ops.adam_step_fused(w2, g2, v2, a2, 0.01, 0.9, 0.999, 1e-8, ranges)
+        eps = 8 * float(np.finfo(np.dtype(dtype)).eps)
+        for got, ref, what in ((w2, w, 'w'), (v2, v, 'velocity'), (a2, a, 'accumulated')):
+            assert rel_linf(CP.asnumpy(got), CP.asnumpy(ref).astype(np.float64)) <= eps, what
+        assert not np.any(CP.asnumpy(g2))
+        assert abs(float(loss) - float(slot.t.item())) <= 1e-14 * max(1.0, abs(float(loss)))
+    finally:
+        CP.set_dtype('float32')

@@ -265,9 +265,12 @@ struct RegRanges {
     int n;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void momentum_fused_kernel(T* w, T* g, T* v, size_t n, T lr, T mu, RegRanges rr,
-                                                             double* partial /* [grid][4] */, int zero_grad) {
+// OPT 0: Momentum (s1 = velocity; p0 = lr, p1 = momentum); OPT 1: Adam (s1 = velocity, s2 = accumulated;
+// p0 = lr, p1 = beta1, p2 = beta2, p3 = eps) -- the update expressions of momentum_kernel / adam_kernel
+template <typename T, int OPT>
+__global__ __launch_bounds__(256) void opt_fused_kernel(T* w, T* g, T* s1, T* s2, size_t n, T p0, T p1, T p2, T p3,
+                                                        RegRanges rr, double* partial /* [grid][4] */,
+                                                        int zero_grad) {
     __shared__ double smem[16];
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -289,9 +292,17 @@ __global__ __launch_bounds__(256) void momentum_fused_kernel(T* w, T* g, T* v, s
                 }
             }
         }
-        const T vi = mu * v[i] - lr * gi;
-        v[i] = vi;
-        w[i] = wi + vi;
+        if constexpr (OPT == 0) {
+            const T vi = p1 * s1[i] - p0 * gi;
+            s1[i] = vi;
+            w[i] = wi + vi;
+        } else {
+            const T vi = p1 * s1[i] + (T(1) - p1) * gi;
+            const T ai = p2 * s2[i] + (T(1) - p2) * (gi * gi);
+            s1[i] = vi;
+            s2[i] = ai;
+            w[i] = wi - p0 / (dev_sqrt<T>(ai) + p3) * vi;
+        }
         g[i] = zero_grad ? T(0) : gi;
     }
 #pragma unroll
@@ -543,14 +554,14 @@ int uocr_momentum_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* v
     return UOCR_OK;
 }
 
-int uocr_momentum_step_fused(uocr_ctx* ctx, int dtype, void* w, void* g, void* v, size_t count, double lr,
-                             double momentum, int nranges, const long long* lo, const long long* hi, const int* kind,
-                             const double* strength, double* reg_loss_out, int zero_grad) {
-    UOCR_CHECK_CTX(ctx);
+static int launch_opt_fused(uocr_ctx* ctx, int dtype, int opt, void* w, void* g, void* s1, void* s2, size_t count,
+                            double p0, double p1, double p2, double p3, int nranges, const long long* lo,
+                            const long long* hi, const int* kind, const double* strength, double* reg_loss_out,
+                            int zero_grad) {
     UOCR_REQUIRE(ctx, nranges >= 0 && nranges <= 4 && (nranges == 0 || (lo && hi && kind && strength)));
     UOCR_REQUIRE(ctx, nranges == 0 || reg_loss_out);
     if (!count) return UOCR_OK;
-    UOCR_REQUIRE(ctx, w && g && v);
+    UOCR_REQUIRE(ctx, w && g && s1 && (opt == 0 || s2));
     RegRanges rr{};
     rr.n = nranges;
     for (int r = 0; r < nranges; ++r) {
@@ -565,8 +576,12 @@ int uocr_momentum_step_fused(uocr_ctx* ctx, int dtype, void* w, void* g, void* v
     if (rc) return rc;
     double* partial = (double*)ctx->workspace;
     UOCR_DISPATCH(ctx, dtype, {
-        hipLaunchKernelGGL((momentum_fused_kernel<T>), dim3(grid), dim3(256), 0, ctx->stream, (T*)w, (T*)g, (T*)v, count,
-                           (T)lr, (T)momentum, rr, partial, zero_grad);
+        if (opt == 0)
+            hipLaunchKernelGGL((opt_fused_kernel<T, 0>), dim3(grid), dim3(256), 0, ctx->stream, (T*)w, (T*)g, (T*)s1,
+                               (T*)s2, count, (T)p0, (T)p1, (T)p2, (T)p3, rr, partial, zero_grad);
+        else
+            hipLaunchKernelGGL((opt_fused_kernel<T, 1>), dim3(grid), dim3(256), 0, ctx->stream, (T*)w, (T*)g, (T*)s1,
+                               (T*)s2, count, (T)p0, (T)p1, (T)p2, (T)p3, rr, partial, zero_grad);
         UOCR_LAUNCH_CHECK(ctx);
     });
     if (nranges > 0) {
@@ -575,6 +590,23 @@ int uocr_momentum_step_fused(uocr_ctx* ctx, int dtype, void* w, void* g, void* v
         UOCR_LAUNCH_CHECK(ctx);
     }
     return UOCR_OK;
+}
+
+int uocr_momentum_step_fused(uocr_ctx* ctx, int dtype, void* w, void* g, void* v, size_t count, double lr,
+                             double momentum, int nranges, const long long* lo, const long long* hi, const int* kind,
+                             const double* strength, double* reg_loss_out, int zero_grad) {
+    UOCR_CHECK_CTX(ctx);
+    return launch_opt_fused(ctx, dtype, 0, w, g, v, nullptr, count, lr, momentum, 0.0, 0.0, nranges, lo, hi, kind,
+                            strength, reg_loss_out, zero_grad);
+}
+
+int uocr_adam_step_fused(uocr_ctx* ctx, int dtype, void* w, void* g, void* v, void* a, size_t count, double lr,
+                         double beta1, double beta2, double eps, int nranges, const long long* lo,
+                         const long long* hi, const int* kind, const double* strength, double* reg_loss_out,
+                         int zero_grad) {
+    UOCR_CHECK_CTX(ctx);
+    return launch_opt_fused(ctx, dtype, 1, w, g, v, a, count, lr, beta1, beta2, eps, nranges, lo, hi, kind, strength,
+                            reg_loss_out, zero_grad);
 }
 
 int uocr_rmsprop_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* a, size_t count, double lr,

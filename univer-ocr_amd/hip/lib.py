@@ -89,6 +89,8 @@ _PROTOS = {
     'uocr_momentum_step': [_ctx, _i, _vp, _vp, _vp, _sz, _d, _d],
     'uocr_momentum_step_fused': [_ctx, _i, _vp, _vp, _vp, _sz, _d, _d, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
                                  C.POINTER(C.c_int), C.POINTER(C.c_double), _vp, _i],
+    'uocr_adam_step_fused': [_ctx, _i, _vp, _vp, _vp, _vp, _sz, _d, _d, _d, _d, _i, C.POINTER(C.c_longlong),
+                             C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_double), _vp, _i],
     'uocr_rmsprop_step': [_ctx, _i, _vp, _vp, _vp, _sz, _d, _d, _d],
     'uocr_has_nan': [_ctx, _i, _vp, _sz, _vp],
 }

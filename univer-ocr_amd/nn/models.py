@@ -495,13 +495,13 @@ class Model(BaseModel):
     def _fused_tail(self):
         """The three calls that end a train step (models.py:252-254: regularize via compute_loss_and_gradients,
         update_grads, clear_grads) as ONE kernel over the flat pack when the whole model is trained by one
-        Momentum optimizer and has at most 4 L1/L2 ranges; None = not applicable, run them one by one."""
-        from .optimizers import Momentum
+        Momentum or Adam optimizer and has at most 4 L1/L2 ranges; None = not applicable, run them one by one."""
+        from .optimizers import Adam, Momentum
         pack = self._pack
         if pack is None or not self.trainable or not all(layer.trainable for layer in self.layers.values()):
             return None
         optimizer = pack.same_optimizer()
-        if type(optimizer) is not Momentum:
+        if type(optimizer) not in (Momentum, Adam):
             return None
         ranges = self._regularizer_ranges()
         if len(ranges) > 4 or any(key[0] not in ('l1', 'l2') for key, _, _ in ranges):

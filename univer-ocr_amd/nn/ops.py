@@ -369,18 +369,32 @@ def adam_step(w, g, v, a, lr, beta1, beta2, eps):
                float(beta1), float(beta2), float(eps))
 
 
-def momentum_step_fused(w, g, v, lr, momentum, ranges, zero_grad=True):
-    """Regularisers of `ranges` = [((kind, strength), lo, hi), ...] (at most 4) + Momentum update + gradient
-    reset in one pass (univer_hip.h: uocr_momentum_step_fused).  Returns the regularisation loss."""
+def _range_args(ranges):
     import ctypes as C
     n = len(ranges)
     lo = (C.c_longlong * max(n, 1))(*[r[1] for r in ranges])
     hi = (C.c_longlong * max(n, 1))(*[r[2] for r in ranges])
     kind = (C.c_int * max(n, 1))(*[{'l1': 1, 'l2': 2, 1: 1, 2: 2}[r[0][0]] for r in ranges])
     strength = (C.c_double * max(n, 1))(*[float(r[0][1]) for r in ranges])
+    return n, lo, hi, kind, strength
+
+
+def momentum_step_fused(w, g, v, lr, momentum, ranges, zero_grad=True):
+    """Regularisers of `ranges` = [((kind, strength), lo, hi), ...] (at most 4) + Momentum update + gradient
+    reset in one pass (univer_hip.h: uocr_momentum_step_fused).  Returns the regularisation loss."""
+    n, lo, hi, kind, strength = _range_args(ranges)
     slot = _loss_slot() if n else None
     _rt().call('uocr_momentum_step_fused', _same_dtype(w, g, v), w.ptr, g.ptr, v.ptr, w.size, float(lr), float(momentum),
                n, lo, hi, kind, strength, slot.ptr if n else None, int(bool(zero_grad)))
+    return _finish_loss(slot) if n else 0
+
+
+def adam_step_fused(w, g, v, a, lr, beta1, beta2, eps, ranges, zero_grad=True):
+    n, lo, hi, kind, strength = _range_args(ranges)
+    slot = _loss_slot() if n else None
+    _rt().call('uocr_adam_step_fused', _same_dtype(w, g, v, a), w.ptr, g.ptr, v.ptr, a.ptr, w.size, float(lr),
+               float(beta1), float(beta2), float(eps), n, lo, hi, kind, strength, slot.ptr if n else None,
+               int(bool(zero_grad)))
     return _finish_loss(slot) if n else 0
 
 

@@ -101,6 +101,14 @@ class Adam(BaseOptimizer):
         f = self._flats(pack)
         ops.adam_step(pack.value, pack.grad, f['velocity'], f['accumulated'], self.lr, self.beta1, self.beta2, EPS)
 
+    def update_pack_fused(self, pack, reg_ranges):
+        """Regularisers + update + gradient reset in one pass over the pack (Model.train_finish)."""
+        f = self._flats(pack)
+        loss = ops.adam_step_fused(pack.value, pack.grad, f['velocity'], f['accumulated'], self.lr, self.beta1,
+                                   self.beta2, EPS, reg_ranges)
+        pack.grad_dirty = False
+        return loss
+
 
 class Momentum(BaseOptimizer):
     state_names = ('velocity',)
