@@ -124,8 +124,8 @@ def cpu_baseline(height, width, char_width, optimizer, lr, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=32, help='pages per GPU per step')
     ap.add_argument('--height', type=int, default=256)
     ap.add_argument('--width', type=int, default=512)
