@@ -143,9 +143,22 @@ __global__ __launch_bounds__(256) void conv_pair_fwd_kernel(const float* __restr
     }
 }
 
-// Same walk for the backward.  DX: the tile owns the inner 14 x 30 positions of the region (d_a1 is needed
-// on a halo of 1 for dx); otherwise all 16 x 32.  Per block one reduction of the two 16 x 16 accumulator
-// tiles (4 VGPRs each) and of db1 / db2; partial[blk][q][NA] in the layout conv_pair_bwd_finish sums.
+// Same walk for the backward; a tile owns all 16 x 32 positions of its region.  Per block one reduction of the
+// two 16 x 16 accumulator tiles (4 VGPRs each) and of db1 / db2; partial[blk][q][NA] in the layout
+// conv_pair_bwd_finish sums.
+// DX: dx[p] = sum_s U[p - s + 1, s] needs U of the 8 neighbours of p, one ring beyond the tile.  Instead of
+// recomputing d_a1 on a halo (x1.22 work, 14 x 30 tiles), the tile scatters its own U over its 18 x 34
+// extended area: the inside goes to dx (edge pixels still incomplete), the ring -- what this tile contributes
+// to pixels of its 8 neighbours -- to border[tile][100]; conv_pair_dx_border then adds, per edge pixel and in
+// a fixed order, the ring entries of the neighbouring tiles.  No atomics: every float is written once.
+constexpr int RING = 2 * XW + 2 * RH;      // top row, bottom row (XW each, corners included), left, right column
+
+__device__ __forceinline__ int ring_index(int er, int ec) {      // (er, ec) in tile coordinates, on the ring
+    if (er == -1) return ec + 1;
+    if (er == RH) return XW + ec + 1;
+    if (ec == -1) return 2 * XW + er;
+    return 2 * XW + RH + er;
+}
 template <bool DX>
 __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restrict__ x, const float* __restrict__ yout,
                                                             const float* __restrict__ dy,
@@ -153,10 +166,11 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restr
                                                             const float* __restrict__ b1,
                                                             const float* __restrict__ w2,
                                                             float* __restrict__ partial, float* __restrict__ dx,
-                                                            int h, int wd, int rows_per_block, float pad1,
-                                                            int use_b1, float alpha, int act2) {
-    constexpr int OFF = DX ? 1 : 0;
-    constexpr int TH = RH - 2 * OFF, TW = RW - 2 * OFF;
+                                                            float* __restrict__ border, int h, int wd,
+                                                            int rows_per_block, float pad1, int use_b1, float alpha,
+                                                            int act2) {
+    constexpr int OFF = 0;
+    constexpr int TH = RH, TW = RW;
     __shared__ float xs[XH * XW];
     __shared__ float gs[XH * XW];
     __shared__ float us[DX ? RH * RW * 9 : 1];           // U[pos][tap]
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restr
             }
         __syncthreads();
         if (y0 + TH < row_end) prefetch(y0 + TH);
-        const int ry = y0 - OFF, rx = x0 - OFF;          // region origin; xs / gs origin one further out
+        const int ry = y0, rx = x0;                      // region origin; xs / gs origin one further out
 #pragma unroll 2
         for (int k = 0; k < 8; ++k) {
             const int gi = wv * 8 + k, r = gi >> 1, c0 = (gi & 1) * 16;
@@ -230,13 +244,13 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restr
             }
             // results: channel n at positions (r, c0 + 4kq + i)
             const int ay = ry + r;
-            const bool row_in = ay >= 0 && ay < h, row_own = row_in && (!DX || (r >= 1 && r <= TH)) && ay < row_end;
+            const bool row_in = ay >= 0 && ay < h, row_own = row_in && ay < row_end;
             float a[4], d[4], dn[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c = c0 + 4 * kq + i, ax = rx + c;
                 const bool inside = row_in && ax >= 0 && ax < wd;
-                const bool owned = row_own && ax >= 0 && ax < wd && (!DX || (c >= 1 && c <= TW));
+                const bool owned = row_own && ax >= 0 && ax < wd;
                 const float slope = z[i] >= 0.f ? 1.f : alpha;
                 a[i] = owned ? z[i] * slope : 0.f;
                 d[i] = inside ? s[i] * slope : 0.f;
@@ -264,20 +278,28 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restr
                 }
             }
         }
-        if constexpr (DX) __syncthreads();
         for (int p = tid; p < TH * TW; p += 256) {
             const int pr = p / TW, pc = p - pr * TW;
-            const int gy = y0 + pr, gx = x0 + pc;
-            if (gy >= row_end || gx >= wd) continue;
-            db2acc += gs[(pr + OFF + 1) * XW + pc + OFF + 1];
-            if constexpr (DX) {
+            if (y0 + pr < row_end && x0 + pc < wd) db2acc += gs[(pr + 1) * XW + pc + 1];
+        }
+        if constexpr (DX) {
+            __syncthreads();
+            const int tiles_y = (h + RH - 1) / RH;
+            const size_t tile_id = ((size_t)blockIdx.z * tiles_y + y0 / RH) * gridDim.x + blockIdx.x;
+            for (int e = tid; e < XH * XW; e += 256) {   // the tile and the ring around it
+                const int er = e / XW - 1, ec = e - (er + 1) * XW - 1;
                 float v = 0.f;
 #pragma unroll
                 for (int sy = 0; sy < 3; ++sy)
 #pragma unroll
-                    for (int sx = 0; sx < 3; ++sx)
-                        v += us[((pr + 2 - sy) * RW + pc + 2 - sx) * 9 + sy * 3 + sx];
-                dx[img + (size_t)gy * wd + gx] = v;
+                    for (int sx = 0; sx < 3; ++sx) {
+                        const int qr = er + 1 - sy, qc = ec + 1 - sx;      // q = e - s + 1
+                        if (qr >= 0 && qr < RH && qc >= 0 && qc < RW) v += us[(qr * RW + qc) * 9 + sy * 3 + sx];
+                    }
+                const int gy = y0 + er, gx = x0 + ec;
+                if (gy < 0 || gy >= h || gx < 0 || gx >= wd) continue;
+                if (er >= 0 && er < RH && ec >= 0 && ec < RW) dx[img + (size_t)gy * wd + gx] = v;
+                else border[tile_id * RING + ring_index(er, ec)] = v;
             }
         }
     }
@@ -339,8 +361,41 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_finish(const float* __restr
     *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
 
+// dx of the tile-edge pixels += what the 8 neighbouring tiles wrote on their rings (fixed order: N, S, W, E,
+// NW, NE, SW, SE).  One thread per (tile, edge pixel): 2 * RW + 2 * (RH - 2) = 92 per tile.
+__global__ __launch_bounds__(256) void conv_pair_dx_border(const float* __restrict__ border, float* __restrict__ dx,
+                                                           int n, int h, int wd, int tiles_y, int tiles_x) {
+    constexpr int EDGE = 2 * RW + 2 * (RH - 2);
+    const size_t total = (size_t)n * tiles_y * tiles_x * EDGE;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % EDGE);
+        const size_t tile = idx / EDGE;
+        const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y), b = (int)(tile / ((size_t)tiles_x * tiles_y));
+        int pr, pc;
+        if (k < RW) { pr = 0; pc = k; }
+        else if (k < 2 * RW) { pr = RH - 1; pc = k - RW; }
+        else if (k < 2 * RW + RH - 2) { pr = k - 2 * RW + 1; pc = 0; }
+        else { pr = k - 2 * RW - (RH - 2) + 1; pc = RW - 1; }
+        const int gy = ty * RH + pr, gx = tx * RW + pc;
+        if (gy >= h || gx >= wd) continue;
+        const int dys[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, dxs[8] = {0, 0, -1, 1, -1, 1, -1, 1};
+        float add = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ny = ty + dys[j], nx = tx + dxs[j];
+            if (ny < 0 || ny >= tiles_y || nx < 0 || nx >= tiles_x) continue;
+            const int er = pr - RH * dys[j], ec = pc - RW * dxs[j];          // this pixel seen from tile (ny, nx)
+            if (er < -1 || er > RH || ec < -1 || ec > RW) continue;
+            if (er >= 0 && er < RH && ec >= 0 && ec < RW) continue;          // (cannot happen for a neighbour)
+            add += border[(((size_t)b * tiles_y + ny) * tiles_x + nx) * RING + ring_index(er, ec)];
+        }
+        dx[((size_t)b * h + gy) * wd + gx] += add;
+    }
+}
+
 // rows per block = a multiple of the tile height th giving at most max_blocks blocks (measured at
-// 32 x 256 x 512: forward / backward with dx 4096 blocks = 4 rounds of resident blocks, backward without dx 2048)
+// 32 x 256 x 512: forward 4096 blocks, backward with dx 1024, without dx 2048)
 int pair_rows_per_block(int strips, int h, int n, int th, unsigned max_blocks) {
     int rows = th;
     while (rows < h && (size_t)strips * ((h + rows - 1) / rows) * n > max_blocks) rows += th;
@@ -383,26 +438,34 @@ extern "C" int uocr_conv_pair_bwd(uocr_ctx* ctx, int dtype, const void* x, const
     UOCR_REQUIRE(ctx, x && y && dy && w1 && b1 && w2 && dw1 && db1 && dw2 && db2);
     int rc = check_pair(ctx, dtype, n, h, w, cmid, act2);
     if (rc != UOCR_OK) return rc;
-    const int tw = dx ? RW - 2 : RW, th = dx ? RH - 2 : RH;
-    const int strips = (w + tw - 1) / tw;
-    const int rows_per_block = pair_rows_per_block(strips, h, n, th, dx ? 4096u : 2048u);
+    const int strips = (w + RW - 1) / RW, tiles_y = (h + RH - 1) / RH;
+    const int rows_per_block = pair_rows_per_block(strips, h, n, RH, dx ? 1024u : 2048u);
     const int bands = (h + rows_per_block - 1) / rows_per_block;
     const int nblocks = strips * bands * n;
-    rc = uocr_need_workspace(ctx, (size_t)nblocks * 4 * NA * sizeof(float));
+    const size_t partial_bytes = (size_t)nblocks * 4 * NA * sizeof(float);
+    const size_t border_bytes = dx ? (size_t)n * tiles_y * strips * RING * sizeof(float) : 0;
+    rc = uocr_need_workspace(ctx, partial_bytes + border_bytes);
     if (rc != UOCR_OK) return rc;
     float* partial = (float*)ctx->workspace;
+    float* border = (float*)((char*)ctx->workspace + partial_bytes);
     const dim3 grid(strips, bands, n);
     if (dx)
         hipLaunchKernelGGL((conv_pair_bwd_kernel<true>), grid, dim3(256), 0, ctx->stream, (const float*)x,
                            (const float*)y, (const float*)dy, (const float*)w1, (const float*)b1, (const float*)w2,
-                           partial, (float*)dx, h, w, rows_per_block, (float)pad_value1, use_bias1, (float)alpha1,
-                           act2);
+                           partial, (float*)dx, border, h, w, rows_per_block, (float)pad_value1, use_bias1,
+                           (float)alpha1, act2);
     else
         hipLaunchKernelGGL((conv_pair_bwd_kernel<false>), grid, dim3(256), 0, ctx->stream, (const float*)x,
                            (const float*)y, (const float*)dy, (const float*)w1, (const float*)b1, (const float*)w2,
-                           partial, (float*)nullptr, h, w, rows_per_block, (float)pad_value1, use_bias1,
-                           (float)alpha1, act2);
+                           partial, (float*)nullptr, (float*)nullptr, h, w, rows_per_block, (float)pad_value1,
+                           use_bias1, (float)alpha1, act2);
     UOCR_LAUNCH_CHECK(ctx);
+    if (dx) {
+        const size_t edge_px = (size_t)n * tiles_y * strips * (2 * RW + 2 * (RH - 2));
+        hipLaunchKernelGGL(conv_pair_dx_border, dim3(uocr_blocks_for(edge_px, 256, UOCR_MAX_GRID)), dim3(256), 0,
+                           ctx->stream, (const float*)border, (float*)dx, n, h, w, tiles_y, strips);
+        UOCR_LAUNCH_CHECK(ctx);
+    }
     hipLaunchKernelGGL(conv_pair_bwd_finish, dim3(NA, 4), dim3(256), 0, ctx->stream, (const float*)partial,
                        (float*)dw1, (float*)db1, (float*)dw2, (float*)db2, nblocks, use_bias1, use_bias2, accumulate);
     UOCR_LAUNCH_CHECK(ctx);
