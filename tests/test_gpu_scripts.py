@@ -81,3 +81,45 @@ def test_bench_two_rank_rehearsal_prints_one_valid_line():
     assert rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['config']['global_batch'] == 8
     assert rec['scaling'] == 'weak' and rec['value'] > 0 and 'cpu_baseline' not in rec
     assert all(np.isfinite(v).all() for v in map(np.array, rec['config']['final_losses'].values()))
+
+
+def test_page_feeder_into_static_graph_inputs():
+    """The upload pipeline converting straight into the arrays the HIP graphs read
+    (PageFeeder.context(into=PageTrainer.static_inputs())) trains exactly like make_context() on the same
+    uint8-quantised pages."""
+    from univer_ocr_amd.my_model.pipeline import PageFeeder, to_uint8_layers
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    from univer_ocr_amd.my_model.trainer import PageTrainer
+    from univer_ocr_amd.nn import CP
+    CP.use_gpu(0)
+    CP.set_dtype('float32')
+    lazy, CP.lazy_losses = CP.lazy_losses, True
+    try:
+        raw = [make_page_batch(2, 32, 64, 16, seed=s) for s in (21, 22, 23)]
+        u8 = [to_uint8_layers(b) for b in raw]
+        quantised = [{t: a.astype(np.float32) * (np.float32(1 / 255) if t in ('image', 'char_lines') else np.float32(1))
+                      for t, a in b.items()} for b in u8]
+        results = []
+        for use_feeder in (False, True):
+            trainer = PageTrainer(2, 32, 64, 16, optimizer='sgd', lr=0.01, seed=8, graphs=True, pipelined=True)
+            trainer.capture(trainer.make_context(quantised[0]))
+            rows = []
+            if use_feeder:
+                statics = trainer.static_inputs()
+                feeder = PageFeeder(u8[0])
+                feeder.stage(u8[0])
+                for i in range(5):
+                    trainer.join()
+                    ctx = feeder.context(into=statics)
+                    feeder.stage(u8[(i + 1) % 3])
+                    losses = trainer.step(ctx)
+                    rows.append({n: float(l['output_losses'][0]) for n, l in losses.items()})
+            else:
+                for i in range(5):
+                    losses = trainer.step(trainer.make_context(quantised[i % 3]))
+                    rows.append({n: float(l['output_losses'][0]) for n, l in losses.items()})
+            trainer.join()
+            results.append(rows)
+        assert results[0] == results[1]
+    finally:
+        CP.lazy_losses = lazy
