@@ -59,7 +59,7 @@ class Runtime:
         self._lanes = [(self.ctx, self.stream)]      # lane 0 = the main stream
 
     # -- lanes: extra (context, stream) pairs so independent models run concurrently ---------------
-    def add_lane(self, workspace_mb=64, priority=0):
+    def add_lane(self, workspace_mb=256, priority=0):
         """A further HIP context of the library with its own stream and workspace.  The four my_model
         nets are independent, so each trains on its own lane: the latency-bound kernels of the small
         nets run under the bandwidth-bound kernels of the large ones."""
