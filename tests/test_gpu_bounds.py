@@ -177,3 +177,64 @@ def test_vector_maxpool_stays_inside_its_buffers(shape, rt):
     dx = Guarded(CP, n * h * w * c)
     runtime.call('uocr_maxpool2d_bwd', hiplib.F32, g.ptr, mask.ptr, dx.ptr, *args)
     dx.check('maxpool dx')
+
+
+@pytest.mark.parametrize('m,n_in,n_out', [(70, 36, 50), (2048, 512, 1024), (300, 1024, 128), (129, 129, 162)])
+def test_dense_entry_points_stay_inside_their_buffers(m, n_in, n_out, rt):
+    """FullyConnected forward / backward (MFMA GEMM with split depth and the generic GEMM for the small shape)."""
+    from univer_ocr_amd.hip import lib as hiplib
+    CP, runtime = rt
+    rng = np.random.default_rng(m + n_in)
+    x = CP.copy(rng.standard_normal((m, n_in)))
+    w = CP.copy(rng.standard_normal((n_in + 1, n_out)) * 0.1)
+    y = Guarded(CP, m * n_out)
+    runtime.call('uocr_dense_fwd', hiplib.F32, x.ptr, w.ptr, y.ptr, m, n_in, n_out)
+    y.check('dense y')
+    g = CP.copy(rng.standard_normal((m, n_out)))
+    dx, dw = Guarded(CP, m * n_in), Guarded(CP, (n_in + 1) * n_out)
+    runtime.call('uocr_dense_bwd', hiplib.F32, x.ptr, w.ptr, g.ptr, dx.ptr, dw.ptr, m, n_in, n_out, 0)
+    dx.check('dense dx')
+    dw.check('dense dw')
+
+
+@pytest.mark.parametrize('shape', [(3, 1, 70, 64), (2, 2, 16, 4)])
+def test_fixed_width_and_softmax_stay_inside_their_buffers(shape, rt):
+    from univer_ocr_amd.hip import lib as hiplib
+    CP, runtime = rt
+    n, h, w, c = shape
+    rng = np.random.default_rng(w)
+    x = CP.copy(rng.standard_normal(shape))
+    y = Guarded(CP, n * w * h * 8 * c)
+    runtime.call('uocr_fixed_width_fwd', hiplib.F32, x.ptr, y.ptr, n, h, w, c, 8)
+    y.check('fixed width y')
+    g = CP.copy(rng.standard_normal((n * w, h, 8, c)))
+    dx = Guarded(CP, n * h * w * c)
+    runtime.call('uocr_fixed_width_bwd', hiplib.F32, g.ptr, dx.ptr, n, h, w, c, 8)
+    dx.check('fixed width dx')
+    rows, classes = n * w, 162
+    logits = CP.copy(rng.standard_normal((rows, classes)))
+    onehot = CP.copy(np.eye(classes)[rng.integers(0, classes, rows)])
+    grad = Guarded(CP, rows * classes)
+    slot = CP.empty((1,), np.float64)
+    runtime.call('uocr_softmax_ce', hiplib.F32, logits.ptr, onehot.ptr, grad.ptr, slot.ptr, rows, classes)
+    grad.check('softmax grad')
+
+
+def test_fused_optimizer_tail_stays_inside_its_buffers(rt):
+    import ctypes as C
+    from univer_ocr_amd.hip import lib as hiplib
+    CP, runtime = rt
+    n = 5003
+    bufs = {k: Guarded(CP, n, fill=SENTINEL) for k in ('w', 'g', 'v', 'a')}
+    for b in bufs.values():                      # payload: small numbers; the borders keep the sentinel
+        b.buf.t[GUARD:GUARD + n] = 0.5
+    lo, hi = (C.c_longlong * 1)(64), (C.c_longlong * 1)(4096)
+    kind, strength = (C.c_int * 1)(2), (C.c_double * 1)(0.01)
+    slot = CP.empty((1,), np.float64)
+    runtime.call('uocr_momentum_step_fused', hiplib.F32, bufs['w'].ptr, bufs['g'].ptr, bufs['v'].ptr, n, 0.01, 0.9, 1, lo,
+                 hi, kind, strength, slot.ptr, 1)
+    runtime.call('uocr_adam_step_fused', hiplib.F32, bufs['w'].ptr, bufs['g'].ptr, bufs['v'].ptr, bufs['a'].ptr, n, 0.01,
+                 0.9, 0.999, 1e-8, 1, lo, hi, kind, strength, slot.ptr, 1)
+    for name, b in bufs.items():
+        b.check(name, expect_written=False)
+    assert not np.any(bufs['g'].check('g', expect_written=False))
