@@ -24,6 +24,8 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->opt_tiled = 1;
     ctx->opt_split = 1024;
     ctx->opt_split_min = 3;
+    ctx->opt_bm = 0;
+    ctx->opt_xcd = 1;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return UOCR_ERR_HIP;
@@ -72,6 +74,8 @@ int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "tiled")) ctx->opt_tiled = value;
     else if (!strcmp(key, "split_blocks")) ctx->opt_split = value;
     else if (!strcmp(key, "split_min")) ctx->opt_split_min = value;
+    else if (!strcmp(key, "gemm_bm")) ctx->opt_bm = value;
+    else if (!strcmp(key, "xcd_remap")) ctx->opt_xcd = value;
     else UOCR_FAIL(ctx, UOCR_ERR_ARG, "unknown option '%s'", key);
     return UOCR_OK;
 }

@@ -6,9 +6,10 @@
 // Block tile BM x 64 (BM = 128: 4 waves of 32x64; BM = 64: 2x2 waves of 32x32), depth tile 32,
 // 256 threads.  A and B tiles are staged global -> registers -> LDS (double buffered, one barrier
 // per depth tile): the loads of tile t+1 are issued before the MFMAs of tile t and written to LDS
-// after them.  A is m-major in LDS with a row stride of 33 floats (conflict-free ds_read_b32 for
-// the 32x32x2 A fragment: lane l reads A[l&31][k + (l>>5)]), B is depth-major with 64-float rows
-// (lane l reads B[k + (l>>5)][l&31]).  B is ALWAYS a row-major [D][N] matrix in memory (weights
+// after them.  A loaded along the depth is m-major in LDS with a row stride of 33 floats
+// (conflict-free ds_read_b32 for the 32x32x2 A fragment: lane l reads A[l&31][k + (l>>5)]); A
+// loaded along M (the dw forms) is depth-major with BM-float rows, stored as the float4s it was
+// loaded as; B is depth-major with 64-float rows (lane l reads B[k + (l>>5)][l&31]).  B is ALWAYS a row-major [D][N] matrix in memory (weights
 // that are needed transposed are transposed once per call into the workspace -- they are <= 2 MB);
 // A is produced by a loader functor, which is where the im2col / transposed-conv / bias-column
 // logic lives -- nothing is materialised in HBM.
@@ -33,6 +34,41 @@ struct alignas(16) F4 {
 
 __device__ __forceinline__ F4 f4_zero() { return F4{{0.f, 0.f, 0.f, 0.f}}; }
 __device__ __forceinline__ F4 f4_fill(float x) { return F4{{x, x, x, x}}; }
+
+// The vector loaders never branch around a global load: an element group that lies outside the operand is
+// loaded from the operand's base address instead and tagged, and the tag is resolved when the registers are
+// written to LDS, AFTER the MFMAs of the current tile.  (With `cond ? load : constant` the compiler merges
+// the two values in the destination registers right after the load -- an s_waitcnt vmcnt(0) in front of the
+// MFMA loop, which serialises every depth tile's global latency with its MFMAs.)
+enum : int { LD_KEEP = 0, LD_ZERO = 1, LD_E0 = 2, LD_PAD = 3 };   // E0 = (1, 0, 0, 0): the ones row / column
+
+__device__ __forceinline__ F4 ld_resolve(F4 v, int code, float pad) {
+    const float first = code == LD_PAD ? pad : (code == LD_E0 ? 1.f : 0.f);
+    const float rest = code == LD_PAD ? pad : 0.f;
+    F4 r;
+    r.v[0] = code == LD_KEEP ? v.v[0] : first;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) r.v[q] = code == LD_KEEP ? v.v[q] : rest;
+    return r;
+}
+
+// n / d for 0 <= n < 2^31 as one mulhi + shift (d fixed per launch): a runtime 32-bit division is ~40 VALU
+// instructions, and the dw loader needs two per 16-byte load.
+struct FastDiv {
+    unsigned mul, shift;
+    int d;
+    FastDiv() = default;
+    explicit FastDiv(int divisor) : mul(0), shift(0), d(divisor) {
+        if (divisor > 1) {
+            int lg = 0;
+            while ((1ll << lg) < divisor) ++lg;                    // ceil(log2 d)
+            const int p = 31 + lg;
+            mul = (unsigned)(((1ull << p) + (unsigned)divisor - 1) / (unsigned)divisor);
+            shift = (unsigned)(p - 32);
+        }
+    }
+    __device__ __forceinline__ int div(int n) const { return d == 1 ? n : (int)(__umulhi((unsigned)n, mul) >> shift); }
+};
 
 // ---------------------------------------------------------------------------------------------
 // epilogue
@@ -77,8 +113,13 @@ struct BRowMajor {
     const float* b;
     long ld;
     int rows, n;       // valid extent
-    int vec_ok;        // rows 16-byte aligned (ld % 4 == 0, base aligned)
-    __device__ __forceinline__ F4 load(int d, int j) const {
+    int vec_ok;        // rows 16-byte aligned (ld % 4 == 0, base aligned) and n % 4 == 0: no partial groups
+    __device__ __forceinline__ F4 load(int d, int j, int& code) const {
+        const bool in = d < rows && j < n;
+        code = in ? LD_KEEP : LD_ZERO;
+        return *reinterpret_cast<const F4*>(in ? b + (long)d * ld + j : b);
+    }
+    __device__ __forceinline__ F4 load_slow(int d, int j) const {
         if (d >= rows || j >= n) return f4_zero();
         const float* p = b + (long)d * ld + j;
         if (vec_ok && j + 3 < n) return *reinterpret_cast<const F4*>(p);
@@ -100,13 +141,21 @@ struct ARowMajor {
     long ld;
     int m, stored;     // stored = number of stored columns; column `stored` is the ones column
     int ones_col;
-    int vec_ok;
+    int vec_ok;        // rows 16-byte aligned and stored % 4 == 0
+    static constexpr bool HAS_SLOW = true;
     struct Row {
         const float* p;
         bool ok;
     };
+    __device__ __forceinline__ float fill() const { return 0.f; }
     __device__ __forceinline__ Row prep(int i) const { return Row{a + (long)i * ld, i < m}; }
-    __device__ __forceinline__ F4 load(const Row& r, int tile, int kq) const {
+    __device__ __forceinline__ F4 load(const Row& r, int tile, int kq, int& code) const {
+        const int d0 = tile * BD + kq * 4;
+        const bool in = r.ok && d0 < stored;
+        code = in ? LD_KEEP : ((r.ok && ones_col && d0 == stored) ? LD_E0 : LD_ZERO);
+        return *reinterpret_cast<const F4*>(in ? r.p + d0 : a);
+    }
+    __device__ __forceinline__ F4 load_slow(const Row& r, int tile, int kq) const {
         const int d0 = tile * BD + kq * 4;
         if (!r.ok) return f4_zero();
         if (vec_ok && d0 + 3 < stored) return *reinterpret_cast<const F4*>(r.p + d0);
@@ -129,12 +178,19 @@ struct AColMajor {
     int stored_rows;   // rows i < stored_rows are stored; row `stored_rows` is the ones row
     int ones_row;
     int depth;
-    int vec_ok;
+    int vec_ok;        // rows 16-byte aligned and stored_rows % 4 == 0
+    static constexpr bool HAS_SLOW = true;
     struct Row {
         int i0;
     };
+    __device__ __forceinline__ float fill() const { return 0.f; }
     __device__ __forceinline__ Row prep(int i0) const { return Row{i0}; }
-    __device__ __forceinline__ F4 load(const Row& r, int d) const {
+    __device__ __forceinline__ F4 load(const Row& r, int d, int& code) const {
+        const bool in = d < depth && r.i0 < stored_rows;
+        code = in ? LD_KEEP : ((d < depth && ones_row && r.i0 == stored_rows) ? LD_E0 : LD_ZERO);
+        return *reinterpret_cast<const F4*>(in ? a + (long)d * ld + r.i0 : a);
+    }
+    __device__ __forceinline__ F4 load_slow(const Row& r, int d) const {
         if (d >= depth) return f4_zero();
         const float* p = a + (long)d * ld + r.i0;
         if (vec_ok && r.i0 + 3 < stored_rows) return *reinterpret_cast<const F4*>(p);
@@ -173,14 +229,16 @@ struct AConvFwd {
         r.base = (((long)b * d.h + r.iy0) * d.w + r.ix0) * d.cin;
         return r;
     }
-    __device__ __forceinline__ F4 load(const Row& r, int tile, int kq) const {
+    static constexpr bool HAS_SLOW = false;
+    __device__ __forceinline__ float fill() const { return pad; }
+    __device__ __forceinline__ F4 load(const Row& r, int tile, int kq, int& code) const {
         const int cpt = d.cin / BD;
         const int kk = tile / cpt, c0 = (tile - kk * cpt) * BD + kq * 4;
         const int ky = kk / d.kw, kx = kk - ky * d.kw;
-        if (!r.ok) return f4_zero();
         const int iy = r.iy0 + ky, ix = r.ix0 + kx;
-        if (iy < 0 || iy >= d.h || ix < 0 || ix >= d.w) return f4_fill(pad);
-        return *reinterpret_cast<const F4*>(x + r.base + ((long)ky * d.w + kx) * d.cin + c0);
+        const bool inside = iy >= 0 && iy < d.h && ix >= 0 && ix < d.w;
+        code = !r.ok ? LD_ZERO : (inside ? LD_KEEP : LD_PAD);
+        return *reinterpret_cast<const F4*>(code == LD_KEEP ? x + r.base + ((long)ky * d.w + kx) * d.cin + c0 : x);
     }
 };
 
@@ -204,16 +262,17 @@ struct AConvDgrad {
         r.b = t / d.h;
         return r;
     }
-    __device__ __forceinline__ F4 load(const Row& r, int tile, int kq) const {
+    static constexpr bool HAS_SLOW = false;
+    __device__ __forceinline__ float fill() const { return 0.f; }
+    __device__ __forceinline__ F4 load(const Row& r, int tile, int kq, int& code) const {
         const int cpt = d.cout / BD;
         const int kk = tile / cpt, c0 = (tile - kk * cpt) * BD + kq * 4;
         const int ky = kk / d.kw, kx = kk - ky * d.kw;
-        if (!r.ok) return f4_zero();
         const int ty = r.y + d.ph - ky, tx = r.x + d.pw - kx;
-        if (ty < 0 || tx < 0) return f4_zero();
-        const int gy = ty / d.sh, gx = tx / d.sw;
-        if (gy * d.sh != ty || gx * d.sw != tx || gy >= d.oh || gx >= d.ow) return f4_zero();
-        return *reinterpret_cast<const F4*>(dy + (((long)r.b * d.oh + gy) * d.ow + gx) * d.cout + c0);
+        const int gy = ty / d.sh, gx = tx / d.sw;     // (truncation for negative ty / tx is caught by ty >= 0)
+        const bool hit = r.ok && ty >= 0 && tx >= 0 && gy * d.sh == ty && gx * d.sw == tx && gy < d.oh && gx < d.ow;
+        code = hit ? LD_KEEP : LD_ZERO;
+        return *reinterpret_cast<const F4*>(hit ? dy + (((long)r.b * d.oh + gy) * d.ow + gx) * d.cout + c0 : dy);
     }
     // A strided transposed conv multiplies structural zeros: input row y only receives tap rows ky with
     // (y + ph - ky) divisible by the stride and inside the output.  When the BM rows of a block lie in ONE
@@ -242,6 +301,7 @@ struct AConvWgrad {
     int K;             // kh*kw*cin
     int use_bias;
     int depth;         // n*oh*ow
+    FastDiv by_ow, by_oh;
     struct Row {
         int ky, kx, ic0;
         int kind;      // 0 = weights rows, 1 = bias row group, 2 = beyond
@@ -260,15 +320,16 @@ struct AConvWgrad {
         }
         return r;
     }
-    __device__ __forceinline__ F4 load(const Row& r, int p) const {
-        if (p >= depth || r.kind == 2) return f4_zero();
-        if (r.kind == 1) return F4{{1.f, 0.f, 0.f, 0.f}};
-        const int ox = p % d.ow;
-        const int t = p / d.ow;
-        const int oy = t % d.oh, b = t / d.oh;
+    static constexpr bool HAS_SLOW = false;
+    __device__ __forceinline__ float fill() const { return pad; }
+    __device__ __forceinline__ F4 load(const Row& r, int p, int& code) const {
+        const bool live = p < depth;
+        const int t = by_ow.div(live ? p : 0), ox = (live ? p : 0) - t * d.ow;
+        const int b = by_oh.div(t), oy = t - b * d.oh;
         const int iy = oy * d.sh - d.ph + r.ky, ix = ox * d.sw - d.pw + r.kx;
-        if (iy < 0 || iy >= d.h || ix < 0 || ix >= d.w) return f4_fill(pad);
-        return *reinterpret_cast<const F4*>(x + (((long)b * d.h + iy) * d.w + ix) * d.cin + r.ic0);
+        const bool inside = iy >= 0 && iy < d.h && ix >= 0 && ix < d.w;
+        code = (!live || r.kind == 2) ? LD_ZERO : (r.kind == 1 ? LD_E0 : (inside ? LD_KEEP : LD_PAD));
+        return *reinterpret_cast<const F4*>(code == LD_KEEP ? x + (((long)b * d.h + iy) * d.w + ix) * d.cin + r.ic0 : x);
     }
 };
 
@@ -277,7 +338,8 @@ struct AConvWgrad {
 // ---------------------------------------------------------------------------------------------
 template <int BM, typename ALoader>
 __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, Epilogue ep, int M, int N,
-                                                        int ntiles, int tiles_per_split, float* slabs) {
+                                                        int ntiles, int tiles_per_split, float* slabs,
+                                                        int xcd_remap) {
     constexpr int WM = BM / 32;            // waves along M: 4 or 2
     constexpr int WN = 4 / WM;             // waves along N: 1 or 2
     constexpr int NB = (BN / WN) / 32;     // 32x32 blocks per wave along N: 2 or 1
@@ -287,12 +349,26 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, 
     constexpr int AM_PASSES = BD / AM_ROWS;    // 4 or 2
     constexpr int A_REGS = ALoader::DEPTH_CONTIG ? A_PASSES : AM_PASSES;
 
-    __shared__ float As[2][BM * LDA];
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BD * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int t_begin = blockIdx.z * tiles_per_split;
+    // Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Blocks that share
+    // operand rows (the M tiles of one depth slab in dw; neighbouring pixel tiles, which share halo rows, in a
+    // conv forward) should share an L2: XCD c takes the c-th contiguous eighth of the logical block ids.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (xcd_remap) {
+        const int total = gridDim.x * gridDim.y * gridDim.z;
+        const int lin = bx + gridDim.x * (by + gridDim.y * bz);
+        const int c = lin & 7, q = total >> 3, r = total & 7;
+        const int logical = c * q + min(c, r) + (lin >> 3);
+        bx = logical % gridDim.x;
+        const int rest = logical / gridDim.x;
+        by = rest % gridDim.y;
+        bz = rest / gridDim.y;
+    }
+    const int m0 = bx * BM, n0 = by * BN;
+    const int t_begin = bz * tiles_per_split;
     const int t_end = min(ntiles, t_begin + tiles_per_split);
 
     // ---- staging assignment ----
@@ -311,19 +387,41 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, 
     const int b_nq = tid & 15, b_kr = tid >> 4;
 
     F4 areg[A_REGS], breg[2];
+    int acode[A_REGS], bcode[2];
+    bool a_slow = false;
+    if constexpr (ALoader::HAS_SLOW) a_slow = !A.vec_ok;
     auto load_tile = [&](int t) {
-        if constexpr (ALoader::DEPTH_CONTIG) {
+        if (a_slow) {             // unaligned rows or ragged groups: element loads (block-uniform choice)
+            if constexpr (ALoader::HAS_SLOW) {
 #pragma unroll
-            for (int s = 0; s < A_PASSES; ++s) areg[s] = A.load(rows[s], t, a_kq);
+                for (int s = 0; s < A_REGS; ++s) {
+                    if constexpr (ALoader::DEPTH_CONTIG) areg[s] = A.load_slow(rows[s], t, a_kq);
+                    else areg[s] = A.load_slow(rows[0], t * BD + a_pr + AM_ROWS * s);
+                    acode[s] = LD_KEEP;
+                }
+            }
+        } else if constexpr (ALoader::DEPTH_CONTIG) {
+#pragma unroll
+            for (int s = 0; s < A_PASSES; ++s) areg[s] = A.load(rows[s], t, a_kq, acode[s]);
         } else {
 #pragma unroll
-            for (int s = 0; s < AM_PASSES; ++s) areg[s] = A.load(rows[0], t * BD + a_pr + AM_ROWS * s);
+            for (int s = 0; s < AM_PASSES; ++s) areg[s] = A.load(rows[0], t * BD + a_pr + AM_ROWS * s, acode[s]);
         }
-        breg[0] = B.load(t * BD + b_kr, n0 + b_nq * 4);
-        breg[1] = B.load(t * BD + b_kr + 16, n0 + b_nq * 4);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (B.vec_ok) breg[s] = B.load(t * BD + b_kr + 16 * s, n0 + b_nq * 4, bcode[s]);
+            else {
+                breg[s] = B.load_slow(t * BD + b_kr + 16 * s, n0 + b_nq * 4);
+                bcode[s] = LD_KEEP;
+            }
+        }
     };
     auto store_tile = [&](int buf) {
         float* as = As[buf];
+#pragma unroll
+        for (int s = 0; s < A_REGS; ++s) areg[s] = ld_resolve(areg[s], acode[s], A.fill());
+#pragma unroll
+        for (int s = 0; s < 2; ++s) breg[s] = ld_resolve(breg[s], bcode[s], 0.f);
         if constexpr (ALoader::DEPTH_CONTIG) {
 #pragma unroll
             for (int s = 0; s < A_PASSES; ++s)
@@ -331,9 +429,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, 
                 for (int q = 0; q < 4; ++q) as[(a_r + 32 * s) * LDA + a_kq * 4 + q] = areg[s].v[q];
         } else {
 #pragma unroll
-            for (int s = 0; s < AM_PASSES; ++s)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) as[(a_iq * 4 + q) * LDA + a_pr + AM_ROWS * s] = areg[s].v[q];
+            for (int s = 0; s < AM_PASSES; ++s)      // depth-major [BD][BM]: the float4 goes in as it was loaded
+                *reinterpret_cast<F4*>(&as[(a_pr + AM_ROWS * s) * BM + a_iq * 4]) = areg[s];
         }
         *reinterpret_cast<F4*>(&Bs[buf][b_kr * BN + b_nq * 4]) = breg[0];
         *reinterpret_cast<F4*>(&Bs[buf][(b_kr + 16) * BN + b_nq * 4]) = breg[1];
@@ -349,6 +446,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, 
     const int fi = wm * 32 + (lane & 31);        // A fragment row of this lane
     const int fk = lane >> 5;                    // depth offset inside a 2-deep MFMA step
     const int fj = wn * (BN / WN) + (lane & 31); // B fragment column (first 32x32 block)
+    const bool band_live = m0 + wm * 32 < M;     // a wave whose 32 rows lie beyond M only helps with the staging
 
     // depth tiles that are zero for the whole block (block-uniform) are stepped over
     auto next_tile = [&](int t) {
@@ -369,9 +467,10 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, 
         if (more) load_tile(tn);
         const float* as = As[buf];
         const float* bs = Bs[buf];
+        if (band_live)
 #pragma unroll
         for (int k = 0; k < BD; k += 2) {
-            const float a = as[fi * LDA + k + fk];
+            const float a = ALoader::DEPTH_CONTIG ? as[fi * LDA + k + fk] : as[(k + fk) * BM + fi];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const float b = bs[(k + fk) * BN + fj + nb * 32];
@@ -391,7 +490,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, 
         for (int r = 0; r < 16; ++r) {
             const int i = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (i < M && j < N) {
-                if (slabs) slabs[((long)blockIdx.z * M + i) * N + j] = acc[nb][r];
+                if (slabs) slabs[((long)bz * M + i) * N + j] = acc[nb][r];
                 else epilogue_store(ep, i, j, acc[nb][r]);
             }
         }
@@ -442,7 +541,12 @@ template <typename ALoader>
 int launch_mfma(uocr_ctx* ctx, const ALoader& A, const BRowMajor& B, const Epilogue& ep, int M, int N, int depth,
                 bool allow_split) {
     const int ntiles = (depth + BD - 1) / BD;
-    const int bm = ((long)((M + 127) / 128) * ((N + BN - 1) / BN) >= 512) ? 128 : 64;
+    // 128-row tiles (two MFMAs per A fragment read) when they still fill the chip: on their own, or -- very deep
+    // GEMMs, dw of a wide conv -- together with the depth split
+    const long tiles128 = (long)((M + 127) / 128) * ((N + BN - 1) / BN);
+    const long deep = (allow_split && ctx->opt_split > 0) ? min(256, ntiles / 32) : 1;
+    int bm = (tiles128 >= 512 || tiles128 * deep >= 512) ? 128 : 64;
+    if (ctx->opt_bm == 64 || ctx->opt_bm == 128) bm = ctx->opt_bm;
     const int gm = (M + bm - 1) / bm, gn = (N + BN - 1) / BN;
     int nsplit = 1;
     // Small GEMMs are latency-bound per block (a depth tile is ~1k MFMA cycles against a 1-2 us global
@@ -452,9 +556,10 @@ int launch_mfma(uocr_ctx* ctx, const ALoader& A, const BRowMajor& B, const Epilo
     const int target = ctx->opt_split;
     if (allow_split && target > 0 && gm * gn < target && ntiles >= 4) {
         nsplit = (target + gm * gn - 1) / (gm * gn);
-        // at most 32 slabs of >= 2 depth tiles, or up to 128 when every slab still has >= 32 tiles (very deep
-        // GEMMs with few output tiles: dw of a wide conv, 9 tiles x 131072 depth tiles: 36 -> 51 TF/s)
-        const int cap = max(min(32, ntiles / 2), min(128, ntiles / 32));
+        // at most 32 slabs of >= 2 depth tiles, or up to 256 when every slab still has >= 32 tiles (very deep
+        // GEMMs with few output tiles: dw of a wide conv, 5 tiles x 131072 depth tiles -- ~4 blocks per CU
+        // keep the CUs evenly loaded where 2.5 would not)
+        const int cap = max(min(32, ntiles / 2), min(256, ntiles / 32));
         if (nsplit > cap) nsplit = cap;
         const size_t per = (size_t)M * N * sizeof(float);
         if ((size_t)nsplit * per > ws_half(ctx)) nsplit = (int)(ws_half(ctx) / per);
@@ -467,10 +572,10 @@ int launch_mfma(uocr_ctx* ctx, const ALoader& A, const BRowMajor& B, const Epilo
     const dim3 grid(gm, gn, nsplit), block(256);
     if (bm == 128)
         hipLaunchKernelGGL((mfma_gemm_kernel<128, ALoader>), grid, block, 0, ctx->stream, A, B, ep, M, N, ntiles, tps,
-                           slabs);
+                           slabs, ctx->opt_xcd);
     else
         hipLaunchKernelGGL((mfma_gemm_kernel<64, ALoader>), grid, block, 0, ctx->stream, A, B, ep, M, N, ntiles, tps,
-                           slabs);
+                           slabs, ctx->opt_xcd);
     UOCR_LAUNCH_CHECK(ctx);
     if (nsplit > 1) {
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(uocr_blocks_for((size_t)M * N, 256, 1024)), dim3(256), 0,
@@ -503,7 +608,7 @@ int uocr_gemm_mfma(uocr_ctx* ctx, const GemmArgs& g) {
     // B must be row-major [depth][n]; a transposed B (dense dx: w[:-1]^T) is transposed into the workspace
     BRowMajor B;
     if (g.b_cs == 1) {
-        B = BRowMajor{(const float*)g.b, g.b_rs, g.depth, g.n, (g.b_rs % 4 == 0 && aligned16(g.b)) ? 1 : 0};
+        B = BRowMajor{(const float*)g.b, g.b_rs, g.depth, g.n, (g.b_rs % 4 == 0 && g.n % 4 == 0 && aligned16(g.b)) ? 1 : 0};
     } else {
         float* bt = ws_aux(ctx);     // B(p,j) = b[p + j*b_cs]: stored as [n][b_cs]; take its transpose
         // in[r = j][c = p] with cols = b_cs (only the first `depth` columns are used) -> out[p*n + j]
@@ -511,16 +616,18 @@ int uocr_gemm_mfma(uocr_ctx* ctx, const GemmArgs& g) {
                            ctx->stream, (const float*)g.b, bt, g.n, (int)g.b_cs);
         UOCR_LAUNCH_CHECK(ctx);
         // transpose_kernel wrote out[c*rows + r] for c < cols = b_cs; rows = n  => out[p*n + j]
-        B = BRowMajor{bt, g.n, g.depth, g.n, (g.n % 4 == 0) ? 1 : 0};
+        B = BRowMajor{bt, g.n, g.depth, g.n, (g.n % 4 == 0 && aligned16(bt)) ? 1 : 0};
     }
     const Epilogue ep = plain_epilogue((float*)g.c, g.ldc, g.accumulate);
     if (g.a_cs == 1) {
         const int stored = g.a_ones_col ? g.depth - 1 : g.depth;
-        ARowMajor A{(const float*)g.a, g.a_rs, g.m, stored, g.a_ones_col, (g.a_rs % 4 == 0 && aligned16(g.a)) ? 1 : 0};
+        ARowMajor A{(const float*)g.a, g.a_rs, g.m, stored, g.a_ones_col,
+                    (g.a_rs % 4 == 0 && stored % 4 == 0 && aligned16(g.a)) ? 1 : 0};
         return launch_mfma(ctx, A, B, ep, g.m, g.n, g.depth, true);
     }
     const int stored_rows = g.a_ones_row ? g.m - 1 : g.m;
-    AColMajor A{(const float*)g.a, g.a_cs, stored_rows, g.a_ones_row, g.depth, (g.a_cs % 4 == 0 && aligned16(g.a)) ? 1 : 0};
+    AColMajor A{(const float*)g.a, g.a_cs, stored_rows, g.a_ones_row, g.depth,
+                (g.a_cs % 4 == 0 && stored_rows % 4 == 0 && aligned16(g.a)) ? 1 : 0};
     return launch_mfma(ctx, A, B, ep, g.m, g.n, g.depth, true);
 }
 
@@ -552,7 +659,7 @@ int uocr_conv_dgrad_mfma(uocr_ctx* ctx, const void* dy, const void* w, void* dx,
                        0, ctx->stream, (const float*)w, wt, d.kh * d.kw, d.cin, d.cout);
     UOCR_LAUNCH_CHECK(ctx);
     AConvDgrad A{(const float*)dy, d, M};
-    BRowMajor B{wt, d.cin, D, d.cin, 1};
+    BRowMajor B{wt, d.cin, D, d.cin, aligned16(wt) ? 1 : 0};
     Epilogue ep = plain_epilogue((float*)dx, d.cin, 0);
     ep.mask_y = (const float*)mask.y;
     ep.mask_act = mask.act;
@@ -564,7 +671,7 @@ int uocr_conv_wgrad_mfma(uocr_ctx* ctx, const void* x, const void* dy, void* dw,
                          double pad_value, int use_bias, int accumulate) {
     const int K = d.kh * d.kw * d.cin, P = d.n * d.oh * d.ow;
     const int M = K + (use_bias ? 1 : 0);
-    AConvWgrad A{(const float*)x, d, (float)pad_value, K, use_bias, P};
+    AConvWgrad A{(const float*)x, d, (float)pad_value, K, use_bias, P, FastDiv(d.ow), FastDiv(d.oh)};
     BRowMajor B{(const float*)dy, d.cout, P, d.cout, aligned16(dy) ? 1 : 0};
     Epilogue ep{(float*)dw, d.cout, nullptr, UOCR_ACT_NONE, 0.f, accumulate, use_bias ? K : -1, (float*)db,
                 nullptr,    UOCR_ACT_NONE, 0.f};

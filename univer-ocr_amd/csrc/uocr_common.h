@@ -19,6 +19,8 @@ struct uocr_ctx {
     int opt_tiled;       // 0 = no LDS-tiled conv kernels, 1 = use them where instantiated (default)
     int opt_split;       // MFMA GEMMs split their depth until there are about this many blocks (0 = never)
     int opt_split_min;   // ... but only when that takes at least this many slabs (a 2-way split rarely pays its reduce)
+    int opt_xcd;         // 1 = MFMA GEMM blocks are renumbered so that neighbours share an XCD (L2)
+    int opt_bm;          // 0 = choose the MFMA GEMM row tile automatically, 64 / 128 = force it (experiments)
     char err[512];
 };
 
