@@ -21,6 +21,8 @@
 // The f32 MFMA rate equals the f32 vector rate (157 TF), but one MFMA replaces 16 v_fma plus their
 // operand moves, and it runs beside the VALU work (masks, LDS addressing): the quad-lane VALU version of
 // these kernels was issue-bound at 4 cycles per vector instruction (97 / 241 us; this one: see DESIGN.md).
+// hipcc-flags: -mllvm -amdgpu-mfma-vgpr-form=1
+// (MFMA accumulators in VGPRs: no v_accvgpr copies between the MFMAs and the VALU code that consumes them)
 #include "uocr_common.h"
 
 namespace {

@@ -20,6 +20,8 @@
 //             dy window from an LDS tile, optional LeakyReLU' epilogue (ActMask as in conv_dims.h)
 // Sums of weights first / different summation order: results agree with the layer-by-layer path to
 // float32 rounding (tests: 1e-5 normalised), not bit for bit.
+// hipcc-flags: -mllvm -amdgpu-mfma-vgpr-form=1
+// (MFMA accumulators in VGPRs: no v_accvgpr copies between the MFMAs and the VALU code that consumes them)
 #include "conv_dims.h"
 
 namespace {

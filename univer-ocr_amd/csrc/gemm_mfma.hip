@@ -17,6 +17,9 @@
 // Split-D: when M x N has too few tiles to fill 256 CUs (dw of the 64-channel convs: 15 tiles),
 // gridDim.z blocks each sum a slice of D into a float32 slab in the workspace and a second kernel
 // adds the slabs in a fixed order (deterministic) and applies the epilogue.
+// hipcc-flags: -mllvm -amdgpu-mfma-vgpr-form=1
+// (accumulators stay in VGPRs: with the AGPR form the compiler copies all 32 of them in and out of the
+// AGPRs around every depth tile -- 64 v_accvgpr moves against 32 MFMAs)
 #include "conv_dims.h"
 #include "gemm.h"
 
@@ -467,14 +470,27 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, 
         if (more) load_tile(tn);
         const float* as = As[buf];
         const float* bs = Bs[buf];
-        if (band_live)
+        if (band_live) {
+            // fragments of depth step k+2 are read from LDS while the MFMAs of step k run
+            auto frag_a = [&](int k) { return ALoader::DEPTH_CONTIG ? as[fi * LDA + k + fk] : as[(k + fk) * BM + fi]; };
+            float a = frag_a(0), b[NB];
 #pragma unroll
-        for (int k = 0; k < BD; k += 2) {
-            const float a = ALoader::DEPTH_CONTIG ? as[fi * LDA + k + fk] : as[(k + fk) * BM + fi];
+            for (int nb = 0; nb < NB; ++nb) b[nb] = bs[fk * BN + fj + nb * 32];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const float b = bs[(k + fk) * BN + fj + nb * 32];
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nb], 0, 0, 0);
+            for (int k = 0; k < BD; k += 2) {
+                float an = 0.f, bn[NB];
+                if (k + 2 < BD) {
+                    an = frag_a(k + 2);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) bn[nb] = bs[(k + 2 + fk) * BN + fj + nb * 32];
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[nb], acc[nb], 0, 0, 0);
+                if (k + 2 < BD) {
+                    a = an;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) b[nb] = bn[nb];
+                }
             }
         }
         if (more) store_tile(buf ^ 1);
