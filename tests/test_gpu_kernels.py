@@ -134,6 +134,8 @@ FAST_SHAPES = [
     ((2, 41, 77, 4), (5, 5), 2, (1, 1), (2, 2)),
     ((3, 32, 70, 1), (5, 3), 64, (2, 1), (0, 1)),
     ((5, 64, 130, 16), (3, 3), 1, (1, 1), (1, 1)),     # more rows than one band per image
+    ((2, 40, 76, 1), (5, 5), 1, (2, 2), (2, 2)),       # even sizes: the stride-2 dx kernel stores pixel pairs
+    ((2, 40, 140, 1), (5, 5), 4, (2, 2), (2, 2)),
 ]
 
 

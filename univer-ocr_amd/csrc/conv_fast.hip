@@ -244,6 +244,75 @@ __global__ __launch_bounds__(256) void conv_dgrad_fast(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward data of the 5x5 / stride 2 / pad 2 encoder convs (Paragraph down_1/2, Line down_1/2).  A thread
+// owns the 2x2 block of dx pixels (2j + py, 2i + px): pixel parity selects the taps (ky = py, py + 2, ..)
+// and all four pixels read the same 3x3 neighbourhood of dy, so the 25 taps are spread over the four pixels
+// without a single predicated tap (conv_dgrad_fast tests every tap against the stride phase of its lane:
+// three quarters of the lanes idle in each of the 25 iterations).
+//   y = 2j:     ky = 0, 2, 4 -> dy rows j+1, j, j-1          y = 2j+1:  ky = 1, 3 -> dy rows j+1, j
+// ---------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_dgrad_s2(const float* __restrict__ dy, const float* __restrict__ w,
+                                                     float* __restrict__ dx, FastDims d,
+                                                     const float* __restrict__ mask_y, int mask_act,
+                                                     float mask_alpha) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
+    if (2 * i >= d.w || 2 * j >= d.h) return;
+    const float* gb = dy + (size_t)b * d.oh * d.ow * COUT;
+    float g[3][3][COUT];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int gy = j - 1 + r;
+        const bool row_ok = gy >= 0 && gy < d.oh;
+        const int gyc = min(max(gy, 0), d.oh - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int gx = i - 1 + c;
+            load_vec<COUT>(gb + ((size_t)gyc * d.ow + min(max(gx, 0), d.ow - 1)) * COUT, g[r][c]);
+            if (!(row_ok && gx >= 0 && gx < d.ow)) {
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) g[r][c][o] = 0.f;
+            }
+        }
+    }
+    float out[2][2][CIN];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) out[q >> 1][q & 1][ci] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+            const int py = ky & 1, px = kx & 1;
+            const int r = (py ? (3 - ky) / 2 : 1 - ky / 2) + 1, c = (px ? (3 - kx) / 2 : 1 - kx / 2) + 1;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int o = 0; o < COUT; ++o)
+                    out[py][px][ci] += g[r][c][o] * w[((ky * 5 + kx) * CIN + ci) * COUT + o];
+        }
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+        const int y = 2 * j + py;
+        if (y >= d.h) break;
+        const size_t off = (((size_t)b * d.h + y) * d.w + 2 * i) * CIN;
+        if (CIN == 1 && (d.w & 1) == 0) {                // even width: the pixel pair is one aligned 8-byte store
+            float v[2] = {out[py][0][0], out[py][1][0]};
+            apply_mask<2>(v, mask_y, off, mask_act, mask_alpha);
+            store_vec<2>(dx + off, v);
+        } else {
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                if (2 * i + px >= d.w) break;
+                apply_mask<CIN>(out[py][px], mask_y, off + px * CIN, mask_act, mask_alpha);
+                store_vec<CIN>(dx + off + px * CIN, out[py][px]);
+            }
+        }
+    }
+}
+
 // One-channel row segment seg[j] = row[first + j], j < N, as aligned float4 loads: `first` = 4*a - OFFS
 // with OFFS compile-time, the row start 16-byte aligned and width % 4 == 0, so every float4 is either
 // fully inside or fully outside the row (outside -> fill).  8-11 dword loads at a 16 B lane stride
@@ -995,6 +1064,20 @@ int uocr_conv_dgrad_fast(uocr_ctx* ctx, const void* dy, const void* w, void* dx,
         hipLaunchKernelGGL((conv_c16_reduce<3, 3, PY, true>), grid, block, 0, ctx->stream, (const float*)dy,
                            (const float*)w, (const float*)nullptr, (float*)dx, d.n, d.h, d.w, d.ph, d.pw, 0.f, 0,
                            (int)UOCR_ACT_NONE, 0.f, (const float*)mask.y, mask.act, (float)mask.alpha);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
+    if (d.kh == 5 && d.kw == 5 && d.sh == 2 && d.sw == 2 && d.ph == 2 && d.pw == 2 &&
+        ((d.cin == 1 && (d.cout == 1 || d.cout == 4)) || (d.cin == 4 && d.cout == 4))) {
+        const dim3 grid(((d.w + 1) / 2 + 63) / 64, ((d.h + 1) / 2 + 3) / 4, d.n), block(64, 4);
+        const FastDims fd{d.n, d.h, d.w, d.oh, d.ow, d.ph, d.pw};
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, (const float*)dy, (const float*)w, (float*)dx, fd,
+                               (const float*)mask.y, mask.act, (float)mask.alpha);
+        };
+        if (d.cin == 4) launch(conv_dgrad_s2<4, 4>);
+        else if (d.cout == 1) launch(conv_dgrad_s2<1, 1>);
+        else launch(conv_dgrad_s2<1, 4>);
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }

@@ -161,7 +161,7 @@ __device__ __forceinline__ int ring_index(int er, int ec) {      // (er, ec) in 
     if (ec == -1) return 2 * XW + er;
     return 2 * XW + RH + er;
 }
-template <bool DX>
+template <bool DX, bool SIG>
 __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restrict__ x, const float* __restrict__ yout,
                                                             const float* __restrict__ dy,
                                                             const float* __restrict__ w1,
@@ -169,8 +169,7 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restr
                                                             const float* __restrict__ w2,
                                                             float* __restrict__ partial, float* __restrict__ dx,
                                                             float* __restrict__ border, int h, int wd,
-                                                            int rows_per_block, float pad1, int use_b1, float alpha,
-                                                            int act2) {
+                                                            int rows_per_block, float pad1, int use_b1, float alpha) {
     constexpr int OFF = 0;
     constexpr int TH = RH, TW = RW;
     __shared__ float xs[XH * XW];
@@ -208,17 +207,16 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restr
     float db1acc = 0.f, db2acc = 0.f;
 
     Stage st;
-    float px[NPF], pg[NPF];
+    // the loads of the next tile are only issued here; their values are first touched at the LDS write after
+    // the MFMAs (the sigmoid derivative included), so nothing in between waits for global memory
+    float px[NPF], pg[NPF], py[SIG ? NPF : 1];
     auto prefetch = [&](int y0) {
         st.locate(tid, y0 - OFF - 1, x0 - OFF - 1, h, wd);
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             px[k] = xb[st.off[k]];
             pg[k] = gb[st.off[k]];
-            if (act2 == UOCR_ACT_SIGMOID) {
-                const float yv = yb[st.off[k]];
-                pg[k] *= yv * (1.f - yv);
-            }
+            if constexpr (SIG) py[k] = yb[st.off[k]];
         }
     };
     prefetch(row_begin);
@@ -227,8 +225,10 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restr
 #pragma unroll
         for (int k = 0; k < NPF; ++k)
             if (tid + k * 256 < XH * XW) {
+                float g = pg[k];
+                if constexpr (SIG) g *= py[k] * (1.f - py[k]);
                 xs[tid + k * 256] = st.in[k] ? px[k] : pad1;
-                gs[tid + k * 256] = st.in[k] ? pg[k] : 0.f;
+                gs[tid + k * 256] = st.in[k] ? g : 0.f;
             }
         __syncthreads();
         if (y0 + TH < row_end) prefetch(y0 + TH);
@@ -451,16 +451,17 @@ extern "C" int uocr_conv_pair_bwd(uocr_ctx* ctx, int dtype, const void* x, const
     float* partial = (float*)ctx->workspace;
     float* border = (float*)((char*)ctx->workspace + partial_bytes);
     const dim3 grid(strips, bands, n);
-    if (dx)
-        hipLaunchKernelGGL((conv_pair_bwd_kernel<true>), grid, dim3(256), 0, ctx->stream, (const float*)x,
-                           (const float*)y, (const float*)dy, (const float*)w1, (const float*)b1, (const float*)w2,
-                           partial, (float*)dx, border, h, w, rows_per_block, (float)pad_value1, use_bias1,
-                           (float)alpha1, act2);
-    else
-        hipLaunchKernelGGL((conv_pair_bwd_kernel<false>), grid, dim3(256), 0, ctx->stream, (const float*)x,
-                           (const float*)y, (const float*)dy, (const float*)w1, (const float*)b1, (const float*)w2,
-                           partial, (float*)nullptr, (float*)nullptr, h, w, rows_per_block, (float)pad_value1,
-                           use_bias1, (float)alpha1, act2);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, ctx->stream, (const float*)x, (const float*)y, (const float*)dy,
+                           (const float*)w1, (const float*)b1, (const float*)w2, partial, (float*)dx,
+                           dx ? border : (float*)nullptr, h, w, rows_per_block, (float)pad_value1, use_bias1,
+                           (float)alpha1);
+    };
+    const bool sig = act2 == UOCR_ACT_SIGMOID;
+    if (dx && sig) launch(conv_pair_bwd_kernel<true, true>);
+    else if (dx) launch(conv_pair_bwd_kernel<true, false>);
+    else if (sig) launch(conv_pair_bwd_kernel<false, true>);
+    else launch(conv_pair_bwd_kernel<false, false>);
     UOCR_LAUNCH_CHECK(ctx);
     if (dx) {
         const size_t edge_px = (size_t)n * tiles_y * strips * (2 * RW + 2 * (RH - 2));
