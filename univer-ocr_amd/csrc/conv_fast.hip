@@ -912,6 +912,110 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_finish(const float* __res
     *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// dw / db of the Line output conv (5x5, 4 -> 2, stride 1, pad 2) from an LDS tile.  conv_wgrad_fast gives
+// each of the 5 tap rows its own block, so x and dy cross the L2 five times (0.5 GB at 256x512x32: the
+// kernel ran at L2 speed); here a block of FIVE waves stages a 16x64 tile of dy and its 20x68 window of x
+// once and wave k owns tap row k: 40 accumulators per lane, 4 adjacent pixels per lane per trip (8 window
+// vectors feed 160 FMAs).  Window columns are stored 4-way interleaved (column c at (c % 4) * 17 + c / 4)
+// so that the 16 lanes of a row, which read columns 4 apart, touch consecutive 16-byte LDS words.
+// ---------------------------------------------------------------------------------------------
+namespace t542 {
+constexpr int TH = 16, TW = 64, WH = TH + 4, WW = TW + 4, NACC = 42, NP = 64;   // 40 dw of a tap row + db
+__device__ __forceinline__ int swz(int row, int c) { return row * WW + (c & 3) * (WW / 4) + (c >> 2); }
+}  // namespace t542
+
+__global__ __launch_bounds__(320) void conv_wgrad_t542(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ partial, int h, int wd, float pad,
+                                                       int tiles_per_block) {
+    using namespace t542;
+    __shared__ float4 xs[WH * WW];
+    __shared__ float2 gs[TH * TW];
+    const int tid = threadIdx.x, lane = tid & 63, ky = tid >> 6;
+    const int x0 = blockIdx.x * TW, b = blockIdx.z;
+    const int tile0 = blockIdx.y * tiles_per_block, tiles_y = (h + TH - 1) / TH;
+    const float4* xb = reinterpret_cast<const float4*>(x) + (size_t)b * h * wd;
+    const float2* gb = reinterpret_cast<const float2*>(dy) + (size_t)b * h * wd;
+    float acc[NP];
+#pragma unroll
+    for (int a = 0; a < NP; ++a) acc[a] = 0.f;
+    const int cg = lane & 15, rsub = lane >> 4;
+    const int t_end = min(tiles_y, tile0 + tiles_per_block);
+    for (int t = tile0; t < t_end; ++t) {
+        const int y0 = t * TH;
+        __syncthreads();                                   // the previous tile's reads are over
+        // (rolled staging loops on purpose: with the loads batched in registers, or prefetched across tiles,
+        // the kernel needs 160+ VGPRs and loses more in occupancy than the overlap gains: 57 -> 60-64 us)
+        for (int e = tid; e < WH * WW; e += 320) {
+            const int r = e / WW, c = e - r * WW;
+            const int gy = y0 - 2 + r, gx = x0 - 2 + c;
+            float4 v = xb[(size_t)min(max(gy, 0), h - 1) * wd + min(max(gx, 0), wd - 1)];
+            if (gy < 0 || gy >= h || gx < 0 || gx >= wd) v = make_float4(pad, pad, pad, pad);
+            xs[swz(r, c)] = v;
+        }
+        for (int e = tid; e < TH * TW; e += 320) {
+            const int r = e / TW, c = e - r * TW;
+            const int gy = y0 + r, gx = x0 + c;
+            float2 v = gb[(size_t)min(gy, h - 1) * wd + min(gx, wd - 1)];
+            if (gy >= h || gx >= wd) v = make_float2(0.f, 0.f);
+            gs[e] = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int it = 0; it < TH / 4; ++it) {
+            const int r = it * 4 + rsub;
+            float g[4][2];
+            {
+                const float4* gp = reinterpret_cast<const float4*>(gs + r * TW + 4 * cg);
+                const float4 g01 = gp[0], g23 = gp[1];
+                g[0][0] = g01.x, g[0][1] = g01.y, g[1][0] = g01.z, g[1][1] = g01.w;
+                g[2][0] = g23.x, g[2][1] = g23.y, g[3][0] = g23.z, g[3][1] = g23.w;
+            }
+            float xv[8][4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 v = xs[swz(r + ky, 4 * cg + j)];
+                xv[j][0] = v.x, xv[j][1] = v.y, xv[j][2] = v.z, xv[j][3] = v.w;
+            }
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                    for (int co = 0; co < 2; ++co)
+#pragma unroll
+                        for (int px = 0; px < 4; ++px) acc[(kx * 4 + ci) * 2 + co] += xv[px + kx][ci] * g[px][co];
+            if (ky == 0) {
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    acc[40] += g[px][0];
+                    acc[41] += g[px][1];
+                }
+            }
+        }
+    }
+    lane_reduce_scatter<NP>(acc, lane);                    // lane L now holds the wave's sum of accumulator L
+    const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (lane < NACC) partial[(blk * 5 + ky) * NACC + lane] = acc[0];
+}
+
+// block a < 200: dw[a] (= tap row a / 40, accumulator a % 40); a = 200, 201: db (from tap row 0's waves)
+__global__ __launch_bounds__(256) void conv_wgrad_t542_finish(const float* __restrict__ partial, float* __restrict__ dw,
+                                                              float* __restrict__ db, int nblocks, int use_bias,
+                                                              int accumulate) {
+    using namespace t542;
+    __shared__ double smem[16];
+    const int a = blockIdx.x;
+    const int ky = a < 200 ? a / 40 : 0, idx = a < 200 ? a % 40 : 40 + (a - 200);
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += (double)partial[((size_t)i * 5 + ky) * NACC + idx];
+    s = block_reduce_sum(s, smem);
+    if (threadIdx.x != 0) return;
+    float* dst = a < 200 ? dw + a : db + (a - 200);
+    if (a >= 200 && !use_bias) s = 0.0;
+    *dst = accumulate ? (float)((double)*dst + s) : (float)s;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <int KH, int KW, int CIN, int COUT, int SH, int SW, int COB, int PY, int DPY, int KYR, int WCOB, int WPY, int FPX,
@@ -1105,6 +1209,24 @@ int uocr_conv_wgrad_fast(uocr_ctx* ctx, const void* x, const void* dy, void* dw,
         UOCR_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL((conv_c16_wgrad_finish<3, 3>), dim3(NA, 4), dim3(256), 0, ctx->stream,
                            (const float*)partial, (float*)dw, (float*)db, nblocks, use_bias, accumulate);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
+    if (d.kh == 5 && d.kw == 5 && d.cin == 4 && d.cout == 2 && d.sh == 1 && d.sw == 1 && d.ph == 2 && d.pw == 2) {
+        const int tiles_x = (d.w + t542::TW - 1) / t542::TW, tiles_y = (d.h + t542::TH - 1) / t542::TH;
+        int per_block = 1;                                  // ~1024 blocks: a few tiles of one column strip each
+        // (measured at 32 x 256 x 512: 512 blocks 58 us, 1024 57, 2048 65, 4096 74)
+        while (per_block < tiles_y && (size_t)tiles_x * ((tiles_y + per_block - 1) / per_block) * d.n > 1024) ++per_block;
+        const dim3 grid(tiles_x, (tiles_y + per_block - 1) / per_block, d.n);
+        const int nblocks = (int)(grid.x * grid.y * grid.z);
+        int rc = uocr_need_workspace(ctx, (size_t)nblocks * 5 * t542::NACC * sizeof(float));
+        if (rc) return rc;
+        float* partial = (float*)ctx->workspace;
+        hipLaunchKernelGGL(conv_wgrad_t542, grid, dim3(320), 0, ctx->stream, (const float*)x, (const float*)dy, partial,
+                           d.h, d.w, (float)pad_value, per_block);
+        UOCR_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(conv_wgrad_t542_finish, dim3(202), dim3(256), 0, ctx->stream, (const float*)partial,
+                           (float*)dw, (float*)db, nblocks, use_bias, accumulate);
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }

@@ -268,19 +268,12 @@ struct RegRanges {
 // OPT 0: Momentum (s1 = velocity; p0 = lr, p1 = momentum); OPT 1: Adam (s1 = velocity, s2 = accumulated;
 // p0 = lr, p1 = beta1, p2 = beta2, p3 = eps) -- the update expressions of momentum_kernel / adam_kernel
 template <typename T, int OPT>
-__global__ __launch_bounds__(256) void opt_fused_kernel(T* w, T* g, T* s1, T* s2, size_t n, T p0, T p1, T p2, T p3,
-                                                        RegRanges rr, double* partial /* [grid][4] */,
-                                                        int zero_grad) {
-    __shared__ double smem[16];
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (size_t i = tid; i < n; i += stride) {
-        const T wi = w[i];
-        T gi = g[i];
+__device__ __forceinline__ void opt_fused_one(T& wi, T& gi, T& vi, T& ai, long long i, const RegRanges& rr,
+                                              bool near_range, double (&acc)[4], T p0, T p1, T p2, T p3) {
+    if (near_range) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (r < rr.n && (long long)i >= rr.lo[r] && (long long)i < rr.hi[r]) {
+            if (r < rr.n && i >= rr.lo[r] && i < rr.hi[r]) {
                 const T strength = (T)rr.strength[r];
                 if (rr.kind[r] == 2) {
                     gi += strength * T(2) * wi;
@@ -292,25 +285,75 @@ __global__ __launch_bounds__(256) void opt_fused_kernel(T* w, T* g, T* s1, T* s2
                 }
             }
         }
-        if constexpr (OPT == 0) {
-            const T vi = p1 * s1[i] - p0 * gi;
-            s1[i] = vi;
-            w[i] = wi + vi;
-        } else {
-            const T vi = p1 * s1[i] + (T(1) - p1) * gi;
-            const T ai = p2 * s2[i] + (T(1) - p2) * (gi * gi);
-            s1[i] = vi;
-            s2[i] = ai;
-            w[i] = wi - p0 / (dev_sqrt<T>(ai) + p3) * vi;
-        }
-        g[i] = zero_grad ? T(0) : gi;
     }
+    if constexpr (OPT == 0) {
+        vi = p1 * vi - p0 * gi;
+        wi = wi + vi;
+    } else {
+        vi = p1 * vi + (T(1) - p1) * gi;
+        ai = p2 * ai + (T(1) - p2) * (gi * gi);
+        wi = wi - p0 / (dev_sqrt<T>(ai) + p3) * vi;
+    }
+}
+
+// VEC = 4: every thread moves 4 consecutive parameters per trip as one vector per array (the arrays are
+// 4-element aligned: the launcher checks); VEC = 1 is the fallback for unaligned views.  The regulariser
+// ranges are tested once per vector, element by element only where a range is touched.
+template <typename T, int OPT, int VEC>
+__global__ __launch_bounds__(256) void opt_fused_kernel(T* __restrict__ w, T* __restrict__ g, T* __restrict__ s1,
+                                                        T* __restrict__ s2, size_t n, T p0, T p1, T p2, T p3,
+                                                        RegRanges rr, double* __restrict__ partial /* [grid][4] */,
+                                                        int zero_grad) {
+    struct alignas(sizeof(T) * VEC) Vec {
+        T v[VEC];
+    };
+    __shared__ double smem[4][4];
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t groups = n / VEC;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (size_t q = tid; q < groups; q += stride) {
+        const long long i0 = (long long)(q * VEC);
+        Vec wv = *reinterpret_cast<const Vec*>(w + i0);
+        Vec gv = *reinterpret_cast<const Vec*>(g + i0);
+        Vec sv = *reinterpret_cast<const Vec*>(s1 + i0);
+        Vec av = sv;
+        if constexpr (OPT == 1) av = *reinterpret_cast<const Vec*>(s2 + i0);
+        bool near_range = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) near_range |= r < rr.n && i0 < rr.hi[r] && i0 + VEC > rr.lo[r];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+            opt_fused_one<T, OPT>(wv.v[k], gv.v[k], sv.v[k], av.v[k], i0 + k, rr, near_range, acc, p0, p1, p2, p3);
+        if (zero_grad) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) gv.v[k] = T(0);
+        }
+        *reinterpret_cast<Vec*>(w + i0) = wv;
+        *reinterpret_cast<Vec*>(g + i0) = gv;
+        *reinterpret_cast<Vec*>(s1 + i0) = sv;
+        if constexpr (OPT == 1) *reinterpret_cast<Vec*>(s2 + i0) = av;
+    }
+    for (size_t i = groups * VEC + tid; i < n; i += stride) {      // the n % VEC trailing parameters
+        T wi = w[i], gi = g[i], vi = s1[i], ai = OPT == 1 ? s2[i] : T(0);
+        opt_fused_one<T, OPT>(wi, gi, vi, ai, (long long)i, rr, rr.n > 0, acc, p0, p1, p2, p3);
+        w[i] = wi;
+        g[i] = zero_grad ? T(0) : gi;
+        s1[i] = vi;
+        if constexpr (OPT == 1) s2[i] = ai;
+    }
+    if (rr.n == 0) return;
+    // one block reduction for all ranges: waves through shuffles, the four waves through LDS (fixed order)
+    const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const double t = block_reduce_sum(acc[r], smem);
-        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * 4 + r] = t;
-        __syncthreads();
+        const double t = r < rr.n ? wave_reduce_sum(acc[r]) : 0.0;
+        if (lane == 0) smem[wv_id][r] = t;
     }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        partial[(size_t)blockIdx.x * 4 + threadIdx.x] =
+            smem[0][threadIdx.x] + smem[1][threadIdx.x] + smem[2][threadIdx.x] + smem[3][threadIdx.x];
 }
 
 // out = sum_r strength_r * sum_blocks partial[block][r]   (one block)
@@ -571,17 +614,24 @@ static int launch_opt_fused(uocr_ctx* ctx, int dtype, int opt, void* w, void* g,
         rr.kind[r] = kind[r];
         rr.strength[r] = strength[r];
     }
-    const unsigned grid = uocr_blocks_for(count, 256, 512);
+    // 4 parameters per thread per trip when the arrays allow vector access
+    const auto aligned = [](const void* p, size_t to) { return (reinterpret_cast<uintptr_t>(p) % to) == 0; };
+    const size_t vec_bytes = 4 * (dtype == UOCR_F64 ? 8 : 4);
+    const bool vec = aligned(w, vec_bytes) && aligned(g, vec_bytes) && aligned(s1, vec_bytes) &&
+                     (opt == 0 || aligned(s2, vec_bytes));
+    const unsigned grid = uocr_blocks_for(vec ? (count + 3) / 4 : count, 256, 1024);
     int rc = uocr_need_workspace(ctx, (size_t)grid * 4 * sizeof(double));
     if (rc) return rc;
     double* partial = (double*)ctx->workspace;
     UOCR_DISPATCH(ctx, dtype, {
-        if (opt == 0)
-            hipLaunchKernelGGL((opt_fused_kernel<T, 0>), dim3(grid), dim3(256), 0, ctx->stream, (T*)w, (T*)g, (T*)s1,
-                               (T*)s2, count, (T)p0, (T)p1, (T)p2, (T)p3, rr, partial, zero_grad);
-        else
-            hipLaunchKernelGGL((opt_fused_kernel<T, 1>), dim3(grid), dim3(256), 0, ctx->stream, (T*)w, (T*)g, (T*)s1,
-                               (T*)s2, count, (T)p0, (T)p1, (T)p2, (T)p3, rr, partial, zero_grad);
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, ctx->stream, (T*)w, (T*)g, (T*)s1, (T*)s2, count, (T)p0,
+                               (T)p1, (T)p2, (T)p3, rr, partial, zero_grad);
+        };
+        if (opt == 0 && vec) launch(opt_fused_kernel<T, 0, 4>);
+        else if (opt == 0) launch(opt_fused_kernel<T, 0, 1>);
+        else if (vec) launch(opt_fused_kernel<T, 1, 4>);
+        else launch(opt_fused_kernel<T, 1, 1>);
         UOCR_LAUNCH_CHECK(ctx);
     });
     if (nranges > 0) {
