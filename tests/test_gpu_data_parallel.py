@@ -60,10 +60,10 @@ def _worker(rank, world, port, results, graphs, steps, pipelined):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('graphs,steps,pipelined', [(False, 2, False), (True, 5, False), (False, 4, True)])
+@pytest.mark.parametrize('graphs,steps,pipelined', [(False, 2, False), (True, 5, False), (False, 4, True), (True, 6, True)])
 def test_two_ranks_equal_one_process_on_the_whole_batch(graphs, steps, pipelined):
     """graphs=True: steps 3-5 replay the per-net HIP graphs with the all-reduce issued between them;
-    pipelined=True: no per-step join of the lanes (the bench default)."""
+    pipelined=True: no per-step join of the lanes (the bench default); both: graph replay on free-running lanes."""
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
