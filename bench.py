@@ -138,12 +138,16 @@ def main():
                     help='end every step with the main stream waiting for all four net streams (default: a net starts '
                          'its next step as soon as ITS previous step is done; the timed region still ends with a full '
                          'device synchronisation)')
-    ap.add_argument('--no-graphs', action='store_true', help='eager launches on one GPU too (default: HIP graphs at N = 1)')
+    ap.add_argument('--dp-side-stream', action='store_true',
+                    help='N > 1: all-reduce with async_op=True on torch\'s internal NCCL stream (+ early bucket) instead of '
+                         'synchronously inside each net\'s lane (the default; the side stream is one hardware queue too many)')
+    ap.add_argument('--no-graphs', action='store_true', help='eager launches (default: HIP graphs)')
     ap.add_argument('--graphs', action='store_true',
-                    help='replay Paragraph, Line and Char as HIP graphs (PageTrainer(graphs=True)); Monochrome stays eager '
-                         'so that the HIP events around the dominant kernel keep working.  Default at N = 1 (host '
-                         'enqueue 1.1 -> 0.3 ms/step); at N > 1 the default is eager launches (graphs next to RCCL '
-                         'could not be rehearsed on the one-GPU box)')
+                    help='(the default) replay Paragraph, Line and Char as HIP graphs (PageTrainer(graphs=True)); '
+                         'Monochrome stays eager so that the HIP events around the dominant kernel keep working.  Host '
+                         'enqueue 1.1 -> 0.3 ms/step; under data parallelism the all-reduce is issued eagerly between a '
+                         'net\'s two graphs, from its lane (one-rank RCCL rehearsal, UOCR_BENCH_FORCE_DP=1: 0.98 ms/step '
+                         'with graphs, 1.26 ms eager -- the eager step is bound by the host)')
     ap.add_argument('--skip-input-grads', action='store_true',
                     help='DIAGNOSTIC: do not compute the gradient w.r.t. the page inputs (unused by training; the '
                          'reference computes it, and so does the default run)')
@@ -154,6 +158,12 @@ def main():
                     help='upload every batch as uint8 from pinned host memory on a copy stream and convert on the '
                          'device (PCIe-inclusive rate; flagged in metric and config, never the headline value)')
     args = ap.parse_args()
+
+    # The contract is ONE line on stdout.  Libraries write there too (RCCL prints a version banner when the
+    # communicator is created): everything but the final JSON line goes to stderr, at the descriptor level.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
 
     # One hardware queue per stream: ROCm's default is 4 queues per process for main + 3 net lanes + copy /
     # RCCL streams, so two of them share a queue and run one after the other (1.25 -> 1.10 ms/step).  The GPU
@@ -171,7 +181,7 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit('--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
         args.gpus = world
-    args.graphs = (args.graphs or world == 1) and not args.no_graphs
+    args.graphs = not args.no_graphs
     # UOCR_BENCH_REHEARSAL=1: several ranks on ONE card with the gloo backend (gradients staged through the
     # host, parallel.DataParallel) -- exercises this file's multi-rank path where RCCL would refuse two ranks
     # on one device; never a measurement
@@ -179,8 +189,13 @@ def main():
     if rehearsal:
         local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # UOCR_BENCH_FORCE_DP=1: a ONE-rank RCCL process group with the data-parallel machinery switched on
+    # (flat gradient buffers, all-reduce between the graphs, waits on the lanes) -- the closest a one-GPU box
+    # gets to the N > 1 code path with the real backend; never a measurement either
+    force_dp = world == 1 and os.environ.get('UOCR_BENCH_FORCE_DP') == '1'
+    if world > 1 or force_dp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         if rehearsal:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
@@ -199,7 +214,8 @@ def main():
     trainer = PageTrainer(args.batch, args.height, args.width, args.char_width, args.optimizer, args.lr,
                           seed=0, overlap=not args.no_overlap, input_grads=not args.skip_input_grads,
                           graphs=args.graphs, eager_nets=('Monochrome',),    # probed kernel stays eager
-                          pipelined=not args.no_pipeline)
+                          pipelined=not args.no_pipeline, data_parallel=True if force_dp else None,
+                          dp_side_stream=args.dp_side_stream)
     layers = make_page_batch(args.batch, args.height, args.width, args.char_width, seed=1234 + rank)
     context = trainer.make_context(layers)       # inputs resident in HBM before the timed region
 
@@ -297,7 +313,7 @@ def main():
                 'batch_per_gpu': args.batch, 'global_batch': args.batch * world,
                 'page': [args.height, args.width], 'optimizer': args.optimizer,
                 'parallelism': f'dp{world}',
-                'grad_allreduce': ('gloo (REHEARSAL on one card)' if rehearsal else 'rccl, 1 flat buffer per net') if world > 1 else None,
+                'grad_allreduce': ('gloo (REHEARSAL on one card)' if rehearsal else 'rccl, 1 flat buffer per net') if world > 1 else ('rccl, ONE rank (REHEARSAL)' if force_dp else None),
                 'final_losses': final,
                 'h2d_inclusive': bool(args.h2d), 'input_grads': not args.skip_input_grads, 'hip_graphs': bool(args.graphs), 'pipelined_lanes': not args.no_pipeline,
                 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'default (4)'),
@@ -314,8 +330,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.height, args.width, args.char_width, args.optimizer, args.lr)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        print(json.dumps(out), file=json_out, flush=True)
+    if world > 1 or force_dp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, results):
+def _worker(rank, world, port, results, side_stream=True):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -31,7 +31,7 @@ def _worker(rank, world, port, results):
         mono = make_monochrome((2, 8, 8, 1), Momentum(lr=0.1))
         char = make_char((1, 32, 8, 1), Momentum(lr=0.1))
         before = mono.pack.value.t.clone()
-        dp = DataParallel({'Monochrome': mono, 'Char': char}, overlap=True)
+        dp = DataParallel({'Monochrome': mono, 'Char': char}, overlap=True, side_stream=side_stream)
         out = {'rank': rank}
         # 1. replicas start identical (rank 0's weights), and they were different before
         out['sync0'] = dp.replicas_in_sync(mono) and dp.replicas_in_sync(char)
@@ -52,6 +52,7 @@ def _worker(rank, world, port, results):
         out['drained'] = id(char) not in dp._pending
         # 3b. bucketed all-reduce inside the Char net: the dense layers' gradients (the tail of the flat
         # buffer) go out when dense_1 has run its backward, the conv block's with the final sync
+        out['own_groups'] = dp._groups[id(mono)] is not dp._groups[id(char)]
         trigger, lo, hi = dp._plans[id(char)]
         out['bucket'] = (trigger, lo > 0, hi == char.pack.total, (hi - lo) * 4 >= (1 << 20))
         out['no_bucket_for_mono'] = id(mono) not in dp._plans and mono.bucket_hook is None
@@ -75,19 +76,22 @@ def _worker(rank, world, port, results):
         dist.destroy_process_group()
 
 
-def test_flat_gradient_allreduce_world2():
+@pytest.mark.parametrize('side_stream', [True, False])
+def test_flat_gradient_allreduce_world2(side_stream):
+    """side_stream=True: asynchronous collectives on the default group, completed by wait();
+    False (the default on GPUs): synchronous collectives, one process group per net."""
     if torch.cuda.is_available():
         pytest.skip('CPU (gloo) rehearsal of the data-parallel logic')
     world, port = 2, _free_port()
     with mp.Manager() as manager:
         results = manager.dict()
-        mp.spawn(_worker, args=(world, port, results), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, results, side_stream), nprocs=world, join=True)
         results = dict(results)
     assert set(results) == {0, 1}
     for rank, out in results.items():
         assert out['sync0'] and out['changed']
         assert out['mono_grad'] == 3.0
-        assert out['pending'] and out['drained']
+        assert out['pending'] == side_stream and out['drained'] and out['own_groups'] == (not side_stream)
         assert out['char_grad'] == 15.0
         assert out['bucket'] == ('Char/dense_block/dense_1', True, True, True) and out['no_bucket_for_mono']
         assert out['early_idle'] and out['early_sent'] and out['early_drained']

@@ -27,6 +27,7 @@ def make_optimizer(name, lr):
 class PageTrainer:
     def __init__(self, batch, height=256, width=512, char_width=64, optimizer='sgd', lr=0.0015, seed=0,
                  nets=('Monochrome', 'Paragraph', 'Line', 'Char'), data_parallel=None, overlap=True,
+                 dp_side_stream=False,
                  init='kaiming_normal', fuse=True, lanes=True, input_grads=True, graphs=False, eager_nets=(), pipelined=False,
                  lane_groups=(('Monochrome', 'Paragraph'), ('Line',), ('Char',))):
         np.random.seed(seed)                        # kaiming_uniform draws from the NumPy global RNG
@@ -80,7 +81,7 @@ class PageTrainer:
             data_parallel = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if data_parallel:
             from ..parallel import DataParallel
-            self.dp = DataParallel(self.models, overlap=overlap)
+            self.dp = DataParallel(self.models, overlap=overlap, side_stream=dp_side_stream)
             for model in self.models.values():
                 model.defer_grad_sync = overlap
 
