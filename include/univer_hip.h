@@ -58,7 +58,11 @@ int uocr_ctx_set_stream(uocr_ctx* ctx, void* hip_stream);
 void* uocr_ctx_get_stream(uocr_ctx* ctx);
 /* kernel selection knobs (for parity tests and A/B timing): "mfma" = 0 never / 1 auto / 2 whenever
  * eligible; "fast_paths" = 0 generic kernels only / 1 shape-specialised kernels (default);
- * "tiled" = 0 / 1 (default) LDS-tiled conv kernels where instantiated */
+ * "tiled" = 0 / 1 (default) LDS-tiled conv kernels where instantiated; MFMA GEMM tuning:
+ * "split_blocks" (1024: split the depth until about this many blocks exist, 0 = never),
+ * "split_min" (3: smallest number of slabs worth a reduce pass), "gemm_bm" (0 auto / 64 / 128 row
+ * tile), "xcd_remap" (1: neighbouring tiles are numbered onto the same XCD / L2).  Results do not
+ * depend on any of them beyond float32 summation order. */
 int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value);
 int uocr_ctx_reserve_workspace(uocr_ctx* ctx, size_t bytes);   /* synchronises; not capturable */
 const char* uocr_last_error(uocr_ctx* ctx);
