@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void conv_fwd_px(const float* __restrict__ x, 
         const float* wr = w + ky * (KW * CIN * COUT);
         float xv[NXV][CIN];
         bool vec_done = false;
-        if constexpr (CIN == 1 && PX == 4) {
+        if constexpr (CIN == 1 && PX % 4 == 0) {
             constexpr int PWC = KW / 2, OFFS = (4 - PWC % 4) % 4;      // "same" padding: ix0 = 4a*SW - PWC
             if (d.pw == PWC && d.w % 4 == 0) {
                 load_row_c1<NXV, OFFS>(xr, ix0 - OFFS, d.w, row_ok, pad, xv);
@@ -400,12 +400,12 @@ __global__ __launch_bounds__(256) void conv_fwd_px(const float* __restrict__ x, 
                     for (int p = 0; p < PX; ++p) acc[p][o] += xv[p * SW + kx][c] * wv;
                 }
     }
-    if constexpr (COUT == 1 && PX == 4) {
-        if (d.ow % 4 == 0) {          // the 4 pixels of the thread are one aligned float4
-            float out[4];
+    if constexpr (COUT == 1 && PX % 4 == 0) {
+        if (d.ow % PX == 0) {         // the PX pixels of the thread are PX / 4 aligned float4s
+            float out[PX];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) out[p] = act_apply(acc[p][0] + (use_bias ? bias[0] : 0.f), act, alpha);
-            store_vec<4>(y + ((size_t)b * d.oh + oy) * d.ow + ox0, out);
+            for (int p = 0; p < PX; ++p) out[p] = act_apply(acc[p][0] + (use_bias ? bias[0] : 0.f), act, alpha);
+            store_vec<PX>(y + ((size_t)b * d.oh + oy) * d.ow + ox0, out);
             return;
         }
     }
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_px(const float* __restrict__ d
         const float* wr = w + ky * (KW * CIN * COUT);
         float g[NG][COUT];
         bool vec_done = false;
-        if constexpr (COUT == 1 && PX == 4) {
+        if constexpr (COUT == 1 && PX % 4 == 0) {
             constexpr int PWC = KW / 2, OFFS = (((KW - 1 - PWC) % 4) + 4) % 4;   // gx0 = 4a - (KW-1-PWC)
             if (d.pw == PWC && d.ow % 4 == 0) {
                 load_row_c1<NG, OFFS>(gr, gx0 - OFFS, d.ow, row_ok, 0.f, g);
@@ -477,12 +477,14 @@ __global__ __launch_bounds__(256) void conv_dgrad_px(const float* __restrict__ d
                     for (int p = 0; p < PX; ++p) acc[p][c] += g[p + (KW - 1) - kx][o] * wv;
                 }
     }
-    if constexpr (CIN == 1 && PX == 4) {
-        if (d.w % 4 == 0) {
-            float out[4] = {acc[0][0], acc[1][0], acc[2][0], acc[3][0]};
+    if constexpr (CIN == 1 && PX % 4 == 0) {
+        if (d.w % PX == 0) {
+            float out[PX];
+#pragma unroll
+            for (int p = 0; p < PX; ++p) out[p] = acc[p][0];
             const size_t off = ((size_t)b * d.h + iy) * d.w + ix0;
-            apply_mask<4>(out, mask_y, off, mask_act, mask_alpha);
-            store_vec<4>(dx + off, out);
+            apply_mask<PX>(out, mask_y, off, mask_act, mask_alpha);
+            store_vec<PX>(dx + off, out);
             return;
         }
     }
@@ -1095,7 +1097,7 @@ struct FastConv {
     X(3, 3, 1, 16, 1, 1, 4, 2, 4, 3, 16, 1, 0, 4) /* Monochrome conv_1: dgrad re-reads 16-ch dy */ \
     X(3, 3, 16, 1, 1, 1, 1, 4, 1, 1, 1, 1, 4, 2)  /* Monochrome conv_2: fwd/wgrad re-read 16-ch x */ \
     X(5, 5, 1, 1, 2, 2, 1, 1, 1, 5, 1, 4, 4, 0)   /* Paragraph down_1/2 */                         \
-    X(5, 5, 1, 1, 1, 1, 1, 4, 4, 5, 1, 4, 4, 4)   /* Paragraph up_2, up_1, end */                  \
+    X(5, 5, 1, 1, 1, 1, 1, 4, 4, 5, 1, 4, 4, 8)   /* Paragraph up_2, up_1, end (PX 8: fwd 22 -> 24, dx 22 -> 19 us) */                \
     X(5, 5, 1, 4, 2, 2, 4, 1, 1, 5, 4, 1, 4, 0)   /* Line down_1 */                                \
     X(5, 5, 4, 4, 2, 2, 4, 2, 1, 1, 4, 2, 4, 0)   /* Line down_2 */                                \
     X(5, 5, 4, 4, 1, 1, 4, 4, 4, 1, 4, 4, 4, 4)   /* Line up_2, up_1 */                            \
