@@ -149,9 +149,10 @@ class PageTrainer:
     def _lane_order(self):
         """Enqueue order of the nets.  One process: the nets that are long chains of short kernels first
         (their chain is the critical path of the concurrent step), the nets of few long kernels last.
-        Data parallel: shortest net first -- all gradient all-reduces share RCCL's one in-order stream, so a
-        collective issued behind the Char net's would wait for Char's backward and couple the lanes."""
-        if self.dp is not None:
+        Data parallel with the collectives on torch's side stream: shortest net first -- all gradient
+        all-reduces then share that one in-order stream, so a collective issued behind the Char net's would
+        wait for Char's backward and couple the lanes (collectives issued from the lanes do not)."""
+        if self.dp is not None and self.dp.side_stream:
             rank = {'Paragraph': 0, 'Monochrome': 1, 'Line': 2, 'Char': 3}
         else:
             rank = {'Char': 0, 'Paragraph': 1, 'Line': 2, 'Monochrome': 3}
