@@ -405,3 +405,32 @@ def test_fused_adam_tail_matches_separate_calls(dtype):
         assert abs(float(loss) - float(slot.t.item())) <= 1e-14 * max(1.0, abs(float(loss)))
     finally:
         CP.set_dtype('float32')
+
+
+@pytest.mark.parametrize('shape,n_out', [((3, 1, 70, 64), 96), ((2, 2, 19, 32), 64), ((2, 1, 8, 64), 32)])
+@pytest.mark.parametrize('masked', [False, True])
+def test_windows_dense_against_the_three_layers(shape, n_out, masked, f32):
+    """Conv2DToBatchedFixedWidthed(8) + Flatten + FullyConnected as one implicit GEMM (ops.windows_dense_*)
+    against the oracle's three layers, with and without the folded LeakyReLU' of the feature map."""
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    n, h, wd, c = shape
+    rng = np.random.default_rng(n_out + wd)
+    X = rng.standard_normal(shape)
+    w = rng.standard_normal((h * 8 * c + 1, n_out)) * 0.1
+    windows = O.fixed_width_fwd(X, 8)
+    flat = windows.reshape(n * wd, -1)
+    ref_y = O.dense_fwd(flat, w)
+    g = rng.standard_normal(ref_y.shape)
+    ref_dflat, ref_dw = O.dense_bwd(flat, w, g)
+    ref_dx = O.fixed_width_bwd(ref_dflat.reshape(windows.shape), shape, 8)
+    if masked:
+        ref_dx = ref_dx * np.where(X >= 0, 1.0, 0.01)
+    dX, dW = CP.copy(X), CP.copy(w)
+    y = ops.windows_dense_fwd(dX, dW, 8)
+    check(y, ref_y, 1e-5, 'y')
+    dw = CP.copy(np.full(w.shape, 0.5))
+    dx = ops.windows_dense_bwd(dX, dW, CP.copy(g), dw, 8, accumulate=True,
+                               **({'x_act': dX, 'act': 'leaky', 'alpha': 0.01} if masked else {}))
+    check(dx, ref_dx, 1e-5, 'dx')
+    check(dw, ref_dw + 0.5, 2e-5, 'dw')

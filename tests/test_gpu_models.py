@@ -221,6 +221,8 @@ def test_fused_activation_graph_matches_reference(net_name, dt):
     f32 = np.dtype(dt) == np.float32
     assert len(model._pairs_used) == (1 if f32 and net_name == 'Monochrome' else 0)
     assert len(model._ups_used) == (2 if f32 and net_name in ('Line', 'Paragraph') else 0)
+    # Char: windows + flatten + dense_1 as one implicit GEMM on the conv feature map (ops.windows_dense_fwd)
+    assert len(model._wins_used) == (1 if f32 and net_name == 'Char' else 0)
     losses = model.compute_loss_and_gradients(X, y)
     close(losses_row(losses), g['sgd/grad_loss'], PASS_TOL[dt], 'loss')
     close(model.input_grads[0], g['sgd/input_grad'], PASS_TOL[dt] * 2, 'input_grad')

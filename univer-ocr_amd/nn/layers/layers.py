@@ -355,6 +355,28 @@ class FullyConnected(BaseLayer):
     def _backward(self, grad, mem_id=0):
         return ops.dense_bwd(self._mem[mem_id], self.w.value, grad, self.w.grad, accumulate=True)
 
+    # this layer fed by Conv2DToBatchedFixedWidthed + Flatten: one implicit GEMM on the conv feature map
+    # (Model._find_windows; ops.windows_dense_fwd)
+    @track_method('forward')
+    def forward_windows(self, x, width):
+        x = ops.as_device(x)
+        self._mem[0] = x
+        return ops.windows_dense_fwd(x, self.w.value, width)
+
+    @track_method('backward')
+    def backward_windows(self, grads, width, input_activation=None):
+        """Returns the gradient w.r.t. the feature map the windows were cut from; with `input_activation`
+        (the fused activation that produced it) times that activation's derivative."""
+        grad = ops.as_device(make_list_if_not(grads)[0])
+        x = self._mem[0]
+        if input_activation is None:
+            dx = ops.windows_dense_bwd(x, self.w.value, grad, self.w.grad, width, accumulate=True)
+        else:
+            dx = ops.windows_dense_bwd(x, self.w.value, grad, self.w.grad, width, accumulate=True, x_act=x,
+                                       act=input_activation.kind, alpha=input_activation.alpha)
+        self.clear_memory()
+        return dx
+
     def get_output_shapes(self, input_shapes):
         return [(make_list_if_not(input_shapes)[0][0], self.n_output)]
 

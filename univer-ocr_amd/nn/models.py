@@ -199,10 +199,23 @@ class Model(BaseModel):
         pair_first = {first: second for second, (first, _, _) in pairs.items()}
         ups = self._active_ups()
         up_nodes = {up for up, _ in ups.values()}
+        wins = self._active_windows()
+        win_nodes = {n for fw, flat, _ in wins.values() for n in (fw, flat)}
         for node in self._plan:
-            if node in pair_first or node in up_nodes:   # computed inside the kernel of its consumer
+            if node in pair_first or node in up_nodes or node in win_nodes:   # computed inside the kernel of its consumer
                 outputs[node] = None
                 continue
+            if node in wins:                          # windows + flatten + dense on the conv feature map
+                fw = wins[node][0]
+                src = self.relations[fw][0]
+                x = inputs[src] if isinstance(src, int) else outputs[src]
+                if x.shape[3] % 32 == 0:
+                    outputs[node] = self.layers[node].forward_windows(x, self.layers[fw].width)
+                    continue
+                for part in (fw, wins[node][1]):      # channel count the implicit GEMM does not take
+                    out = self.layers[part].forward([x])
+                    x = outputs[part] = out[0] if isinstance(out, list) else out
+                wins = {k: v for k, v in wins.items() if k != node}
             if node in ups:                           # upsample + conv on the low-res tensor
                 src = self.relations[ups[node][0]][0]
                 x_low = inputs[src] if isinstance(src, int) else outputs[src]
@@ -231,6 +244,7 @@ class Model(BaseModel):
         self.layers_outputs = outputs
         self._pairs_used = pairs
         self._ups_used = ups
+        self._wins_used = wins
         return [outputs[k] for k in range(self.outputs_count)]
 
     def _active_pairs(self, inputs):
@@ -259,10 +273,22 @@ class Model(BaseModel):
         pair_first = {first: second for second, (first, _, _) in pairs.items()}
         ups = getattr(self, '_ups_used', {})
         up_nodes = {up for up, _ in ups.values()}
+        wins = getattr(self, '_wins_used', {})
+        win_nodes = {n for fw, flat, _ in wins.values() for n in (fw, flat)}
         for node in reversed(self._plan):
             if node not in self.relations_backward:
                 continue
-            if node in ups:                           # dW, and dX w.r.t. the LOW-RES input, in one go
+            if node in wins:                          # dW and dX w.r.t. the conv feature map in one go
+                fw, flat, act_in = wins[node]
+                dx = self.layers[node].backward_windows(
+                    incoming(node), self.layers[fw].width,
+                    input_activation=None if act_in is None else self.layers[act_in])
+                grads_mem[node] = [None]
+                grads_mem[flat] = [None]
+                grads_mem[fw] = [dx]
+            elif node in win_nodes:
+                grads_mem.setdefault(node, [None])
+            elif node in ups:                           # dW, and dX w.r.t. the LOW-RES input, in one go
                 up_node, act_in = ups[node]
                 act = self.layers[fused_conv[node]] if node in fused_conv else None
                 dx_low = self.layers[node].backward_up(
@@ -330,6 +356,7 @@ class Model(BaseModel):
             self._fusion = ({}, {}, {}, set())
             self._pairs = {}
             self._ups = {}
+            self._wins = {}
             return {}, {}
         if self._fusion is None:
             from .layers import Convolutional2D, LeakyRelu, Sigmoid
@@ -363,7 +390,52 @@ class Model(BaseModel):
             self._fusion = (fused_conv, fused_act, input_of, folded)
             self._pairs = self._find_pairs(fused_conv, input_of) if getattr(self, 'fuse_pairs', True) else {}
             self._ups = self._find_ups(fused_act) if getattr(self, 'fuse_pairs', True) else {}
+            self._wins = self._find_windows(fused_act) if getattr(self, 'fuse_pairs', True) else {}
         return self._fusion[0], self._fusion[1]
+
+    def _find_windows(self, fused_act):
+        """Conv2DToBatchedFixedWidthed feeding only a Flatten feeding only a FullyConnected -- the bridge
+        between the conv block and the dense block of the Char net (my_model/model.py:250-304) -- runs as one
+        implicit GEMM on the conv feature map (ops.windows_dense_fwd): the 8x larger windows tensor and its
+        gradient are never built.  Returns {dense: (windows node, flatten node, fused activation that feeds only
+        the windows layer, or None)}; that activation's backward is folded into the dx epilogue."""
+        from .layers import Conv2DToBatchedFixedWidthed, Flatten, FullyConnected
+
+        def only_consumer(node, kind):
+            consumers = self.relations_backward.get(node, {})
+            if len(consumers) != 1:
+                return None
+            (dst, _), = consumers.items()
+            if isinstance(dst, int) or self.relations[dst] != [node] or not isinstance(self.layers[dst], kind):
+                return None
+            return dst
+
+        wins = {}
+        for node in self._plan:
+            if not isinstance(self.layers[node], Conv2DToBatchedFixedWidthed):
+                continue
+            flat = only_consumer(node, Flatten)
+            dense = only_consumer(flat, FullyConnected) if flat is not None else None
+            if dense is None:
+                continue
+            src = self.relations[node]
+            act_in = None
+            if len(src) == 1 and src[0] in fused_act and len(self.relations_backward.get(src[0], {})) == 1:
+                act_in = src[0]
+            wins[dense] = (node, flat, act_in)
+        return wins
+
+    def _active_windows(self):
+        """float32 with channel counts the MFMA implicit GEMM takes (the generic conv kernels would be slower
+        than the three separate layers)."""
+        wins = getattr(self, '_wins', {})
+        out = {}
+        for dense, v in wins.items():
+            layer = self.layers[dense]
+            if layer.is_initialized and layer.w.value.dtype == np.float32 and layer.n_output % 32 == 0 and \
+                    layer.n_input % (32 * self.layers[v[0]].width) == 0:
+                out[dense] = v
+        return out
 
     def _find_ups(self, fused_act):
         """Upsample2D(2) feeding only a 5x5 / stride 1 / padding 2 Convolutional2D with 4->4 or 1->1 channels -- the
@@ -401,7 +473,8 @@ class Model(BaseModel):
         """Is the backward of this fused activation applied by its consumer (a conv's dx kernel, or the
         loss kernel for an output Sigmoid)?"""
         return act_node in self._fusion[3] or act_node in getattr(self, '_loss_folded', ()) or \
-            any(a == act_node for _, a in getattr(self, '_ups_used', {}).values())
+            any(a == act_node for _, a in getattr(self, '_ups_used', {}).values()) or \
+            any(a == act_node for _, _, a in getattr(self, '_wins_used', {}).values())
 
     def _foldable_output_sigmoid(self, key):
         """Model output `key` = a Sigmoid fused into its conv (not a pair kernel, which applies Sigmoid'

@@ -226,6 +226,47 @@ def dense_bwd(x, w, dy, dw, accumulate=True, need_dx=True):
     return dx
 
 
+# ---- Conv2DToBatchedFixedWidthed + Flatten + FullyConnected as ONE implicit GEMM -------------------------
+# The windows layer (convolutional.py:330-373) copies every `width`-column window of (n, h, W, c) into its own
+# batch entry, Flatten strings it out as (h, j, c) and the dense layer multiplies by w[(h, j, c), n_out]: that is a
+# convolution with a (h, width) kernel, padding (0, width // 2) and the output cut to W columns, whose weights
+# are the dense layer's rows and whose bias is its last row.  Run through the conv entry points (the implicit-GEMM
+# loaders gather the windows on the fly) the 8x larger windows tensor and its gradient never exist.
+def _windows_dims(x_shape, w, width):
+    n, h, wd, c = x_shape
+    n_in = h * width * c
+    if w.shape[0] != n_in + 1:
+        raise AssertionError(f'weights {w.shape} do not fit {width}-column windows of {tuple(x_shape)} (bias row included)')
+    if wd < width:
+        raise AssertionError(f'Input width must be >= than output width, found: {wd} < {width}')
+    dims = (n, h, wd, c, w.shape[1], h, width, 1, 1, 0, width // 2, 1, wd)
+    return dims, n_in * w.shape[1] * w.t.element_size()
+
+
+def windows_dense_fwd(x, w, width):
+    """(n, h, W, c) -> (n * W, n_out): fixed-width windows, flatten and dense in one kernel."""
+    dims, bias_off = _windows_dims(x.shape, w, width)
+    y = CP.empty((dims[0] * dims[2], dims[4]), x.dtype)
+    _rt().call('uocr_conv2d_fwd', _same_dtype(x, w), x.ptr, w.ptr, w.ptr + bias_off, y.ptr, *dims, 0.0, 1,
+               ACT_CODES[None], 0.0)
+    return y
+
+
+def windows_dense_bwd(x, w, dy, dw, width, accumulate=True, x_act=None, act=None, alpha=0.0):
+    """dw (bias row included) and the gradient w.r.t. x (times act'(x) when x is the output of a fused
+    activation, as conv2d_bwd_data)."""
+    dims, bias_off = _windows_dims(x.shape, w, width)
+    code = _same_dtype(x, w, dy, dw)
+    if dy.shape != (dims[0] * dims[2], dims[4]):
+        raise AssertionError(f'grad shape {dy.shape} does not match the layer output')
+    _rt().call('uocr_conv2d_bwd_weight', code, x.ptr, dy.ptr, dw.ptr, dw.ptr + bias_off, *dims, 0.0, 1,
+               int(bool(accumulate)))
+    dx = CP.empty(x.shape, dy.dtype)
+    _rt().call('uocr_conv2d_bwd_data', code, dy.ptr, w.ptr, dx.ptr, *dims, None if x_act is None else x_act.ptr,
+               ACT_CODES[act if x_act is not None else None], float(alpha))
+    return dx
+
+
 # ---- Conv2DToBatchedFixedWidthed -------------------------------------------------------------------
 def fixed_width_fwd(x, width):
     n, h, wd, c = x.shape
