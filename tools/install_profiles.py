@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Copies what tools/refresh_profiles.sh left in gpurun_out/refresh/ into profiles/ (kernel stats + per-step summary,
+the two bench lines, micro-benchmarks, the PMC rows of the dominant kernel and the traffic JSON bench.py reads)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+
+R, P = 'gpurun_out/refresh', 'profiles'
+
+
+def latest(pattern):
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+def part(name):
+    for key, tag in (('conv_pair_bwd_kernel', 'main'), ('conv_pair_dx_border', 'border'), ('conv_pair_bwd_finish', 'finish')):
+        if key in name:
+            return tag
+    return None
+
+
+def main():
+    shutil.copy(latest(f'{R}/stats/*/*_kernel_stats.csv'), f'{P}/r01_rocprofv3_kernel_stats.csv')
+    rows = list(csv.DictReader(open(f'{P}/r01_rocprofv3_kernel_stats.csv')))
+    steps = 25
+    total = sum(float(r['TotalDurationNs']) for r in rows)
+    calls = sum(int(r['Calls']) for r in rows)
+    out = [f'kernel time {total / 1e6 / steps:.3f} ms/step, {calls / steps:.1f} kernels/step']
+    for r in rows[:40]:
+        name = r['Name'].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '')
+        out.append(f"{name[:88]:88s} n/step={int(r['Calls']) / steps:5.1f} avg_us={float(r['AverageNs']) / 1e3:8.1f} "
+                   f"ms/step={float(r['TotalDurationNs']) / 1e6 / steps:7.3f} {float(r['Percentage']):5.1f}%")
+    open(f'{P}/r01_rocprofv3_summary.txt', 'w').write('\n'.join(out) + '\n')
+    shutil.copy(f'{R}/bench_n1.json', f'{P}/r01_bench_n1.json')
+    shutil.copy(f'{R}/bench_under_rocprofv3.json', f'{P}/r01_bench_n1_under_rocprofv3.json')
+    for src, dst in (('conv_microbench.txt', 'r01_conv_microbench.txt'), ('membw.txt', 'r01_membw.txt')):
+        open(f'{P}/{dst}', 'w').write(''.join(line for line in open(f'{R}/{src}') if 'amdgpu.ids' not in line))
+    picked, agg = [], {'FETCH_SIZE': collections.defaultdict(list), 'WRITE_SIZE': collections.defaultdict(list)}
+    for d in ('pmc_fetch', 'pmc_write'):
+        for r in csv.DictReader(open(latest(f'{R}/{d}/*/*counter_collection.csv'))):
+            tag = part(r['Kernel_Name'])
+            if tag is None:
+                continue
+            picked.append((r['Counter_Name'], r['Kernel_Name'], r['Dispatch_Id'], float(r['Counter_Value'])))
+            agg[r['Counter_Name']][tag].append(float(r['Counter_Value']))
+    with open(f'{P}/r01_pmc_dominant_kernel.csv', 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['Counter_Name', 'Kernel_Name', 'Dispatch_Id', 'Counter_Value'])
+        for r in picked:
+            w.writerow([r[0], r[1], r[2], f'{r[3]:.6f}'])
+    traffic = json.load(open(f'{P}/dominant_kernel_traffic.json'))
+    fetch = {k: sum(v) / len(v) for k, v in agg['FETCH_SIZE'].items()}
+    write = {k: sum(v) / len(v) for k, v in agg['WRITE_SIZE'].items()}
+    fb, wb = sum(fetch.values()) * 1024, sum(write.values()) * 1024
+    traffic.update(FETCH_SIZE_KB_avg=fetch, WRITE_SIZE_KB_avg=write, fetch_bytes=fb, write_bytes=wb,
+                   hbm_bytes_per_launch=fb + wb)
+    json.dump(traffic, open(f'{P}/dominant_kernel_traffic.json', 'w'), indent=1)
+    b, u = json.load(open(f'{P}/r01_bench_n1.json')), json.load(open(f'{P}/r01_bench_n1_under_rocprofv3.json'))
+    print('bench', b['value'], b['ms_per_step'], b['roofline']['avg_launch_us'], b['roofline']['frac'],
+          b['cpu_baseline']['value'])
+    print('under rocprofv3', u['value'], u['ms_per_step'], u['roofline']['avg_launch_us'])
+    print('traffic MB', fb / 1e6, wb / 1e6, (fb + wb) / 1e6)
+    for r in rows:
+        if part(r['Name']):
+            print(r['Name'][:70], float(r['AverageNs']) / 1e3)
+    print(out[0])
+
+
+if __name__ == '__main__':
+    main()
