@@ -517,8 +517,18 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
                                                           Epilogue ep) {
     const long total = (long)M * N;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        // eight slabs' loads in flight at a time, added in slab order (the sum is the same fmaf-free chain
+        // z = 0, 1, 2, ... whatever the batching)
         float v = 0.f;
-        for (int z = 0; z < nsplit; ++z) v += slabs[(long)z * total + idx];
+        int z = 0;
+        for (; z + 8 <= nsplit; z += 8) {
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = slabs[(long)(z + k) * total + idx];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += t[k];
+        }
+        for (; z < nsplit; ++z) v += slabs[(long)z * total + idx];
         epilogue_store(ep, (int)(idx / N), (int)(idx % N), v);
     }
 }
