@@ -9,8 +9,8 @@
 // after them.  A loaded along the depth is m-major in LDS with a row stride of 33 floats
 // (conflict-free ds_read_b32 for the 32x32x2 A fragment: lane l reads A[l&31][k + (l>>5)]); A
 // loaded along M (the dw forms) is depth-major with BM-float rows, stored as the float4s it was
-// loaded as; B is depth-major with 64-float rows (lane l reads B[k + (l>>5)][l&31]).  B is ALWAYS a row-major [D][N] matrix in memory (weights
-// that are needed transposed are transposed once per call into the workspace -- they are <= 2 MB);
+// loaded as; B is depth-major with 64-float rows (lane l reads B[k + (l>>5)][l&31]) when it is a row-major [D][N]
+// matrix in memory, n-major with stride 33 when it lies along the depth (BDepthContig: the weights of the dx forms);
 // A is produced by a loader functor, which is where the im2col / transposed-conv / bias-column
 // logic lives -- nothing is materialised in HBM.
 //
@@ -113,6 +113,7 @@ __device__ __forceinline__ void epilogue_store(const Epilogue& e, int i, int j, 
 // B operand: row-major [D][N]
 // ---------------------------------------------------------------------------------------------
 struct BRowMajor {
+    static constexpr bool DEPTH_CONTIG = false;
     const float* b;
     long ld;
     int rows, n;       // valid extent
@@ -130,6 +131,38 @@ struct BRowMajor {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (j + q < n) r.v[q] = p[q];
+        return r;
+    }
+};
+
+// B read along the depth -- the weights of the two dx forms, which are stored with the summed index
+// contiguous: dense dx B(p, j) = w[j * n_out + p] (one segment), conv dx B((kk, oc), ic) =
+// w[(kk * cin + ic) * cout + oc] (one segment of cout per tap).  Staged like a depth-contiguous A: 16-B
+// loads along the depth, n-major LDS tile with stride 33.  (These operands used to be transposed into the
+// workspace by a separate kernel in front of every dx GEMM: five launches per step of the Char net.)
+struct BDepthContig {
+    static constexpr bool DEPTH_CONTIG = true;
+    const float* b;
+    long ld;           // distance between columns j
+    int n, depth;      // valid extent
+    int rows;          // conv: columns per tap (cin); dense: 0
+    FastDiv by_seg;    // depth per segment (conv: cout, dense: depth)
+    int vec_ok;        // 16-byte aligned groups: base aligned, ld % 4 == 0, segment % 4 == 0
+    __device__ __forceinline__ const float* at(int d0, int j) const {
+        const int kk = by_seg.div(d0);
+        return b + ((long)kk * rows + j) * ld + (d0 - kk * by_seg.d);
+    }
+    __device__ __forceinline__ F4 load(int j, int d0, int& code) const {
+        const bool in = j < n && d0 < depth;
+        code = in ? LD_KEEP : LD_ZERO;
+        return *reinterpret_cast<const F4*>(in ? at(d0, j) : b);
+    }
+    __device__ __forceinline__ F4 load_slow(int j, int d0) const {
+        F4 r = f4_zero();
+        if (j >= n) return r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (d0 + q < depth) r.v[q] = *at(d0 + q, j);
         return r;
     }
 };
@@ -339,8 +372,8 @@ struct AConvWgrad {
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
-template <int BM, typename ALoader>
-__global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, Epilogue ep, int M, int N,
+template <int BM, typename ALoader, typename BLoader>
+__global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BLoader B, Epilogue ep, int M, int N,
                                                         int ntiles, int tiles_per_split, float* slabs,
                                                         int xcd_remap) {
     constexpr int WM = BM / 32;            // waves along M: 4 or 2
@@ -353,7 +386,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, 
     constexpr int A_REGS = ALoader::DEPTH_CONTIG ? A_PASSES : AM_PASSES;
 
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BD * BN];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BLoader::DEPTH_CONTIG ? BN * LDA : BD * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Blocks that share
@@ -387,7 +420,8 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, 
         a_pr = tid / AM_GROUPS;
         rows[0] = A.prep(m0 + a_iq * 4);
     }
-    const int b_nq = tid & 15, b_kr = tid >> 4;
+    const int b_nq = tid & 15, b_kr = tid >> 4;       // row-major B: float4 along n at depths b_kr, b_kr + 16
+    const int b_kq = tid & 7, b_r = tid >> 3;         // depth-contiguous B: float4 along the depth, columns b_r, b_r + 32
 
     F4 areg[A_REGS], breg[2];
     int acode[A_REGS], bcode[2];
@@ -412,7 +446,13 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, 
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            if (B.vec_ok) breg[s] = B.load(t * BD + b_kr + 16 * s, n0 + b_nq * 4, bcode[s]);
+            if constexpr (BLoader::DEPTH_CONTIG) {
+                if (B.vec_ok) breg[s] = B.load(n0 + b_r + 32 * s, t * BD + b_kq * 4, bcode[s]);
+                else {
+                    breg[s] = B.load_slow(n0 + b_r + 32 * s, t * BD + b_kq * 4);
+                    bcode[s] = LD_KEEP;
+                }
+            } else if (B.vec_ok) breg[s] = B.load(t * BD + b_kr + 16 * s, n0 + b_nq * 4, bcode[s]);
             else {
                 breg[s] = B.load_slow(t * BD + b_kr + 16 * s, n0 + b_nq * 4);
                 bcode[s] = LD_KEEP;
@@ -435,8 +475,15 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, 
             for (int s = 0; s < AM_PASSES; ++s)      // depth-major [BD][BM]: the float4 goes in as it was loaded
                 *reinterpret_cast<F4*>(&as[(a_pr + AM_ROWS * s) * BM + a_iq * 4]) = areg[s];
         }
-        *reinterpret_cast<F4*>(&Bs[buf][b_kr * BN + b_nq * 4]) = breg[0];
-        *reinterpret_cast<F4*>(&Bs[buf][(b_kr + 16) * BN + b_nq * 4]) = breg[1];
+        if constexpr (BLoader::DEPTH_CONTIG) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Bs[buf][(b_r + 32 * s) * LDA + b_kq * 4 + q] = breg[s].v[q];
+        } else {
+            *reinterpret_cast<F4*>(&Bs[buf][b_kr * BN + b_nq * 4]) = breg[0];
+            *reinterpret_cast<F4*>(&Bs[buf][(b_kr + 16) * BN + b_nq * 4]) = breg[1];
+        }
     };
 
     f32x16 acc[NB];
@@ -473,16 +520,19 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BRowMajor B, 
         if (band_live) {
             // fragments of depth step k+2 are read from LDS while the MFMAs of step k run
             auto frag_a = [&](int k) { return ALoader::DEPTH_CONTIG ? as[fi * LDA + k + fk] : as[(k + fk) * BM + fi]; };
+            auto frag_b = [&](int k, int nb) {
+                return BLoader::DEPTH_CONTIG ? bs[(fj + nb * 32) * LDA + k + fk] : bs[(k + fk) * BN + fj + nb * 32];
+            };
             float a = frag_a(0), b[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) b[nb] = bs[fk * BN + fj + nb * 32];
+            for (int nb = 0; nb < NB; ++nb) b[nb] = frag_b(0, nb);
 #pragma unroll
             for (int k = 0; k < BD; k += 2) {
                 float an = 0.f, bn[NB];
                 if (k + 2 < BD) {
                     an = frag_a(k + 2);
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) bn[nb] = bs[(k + 2 + fk) * BN + fj + nb * 32];
+                    for (int nb = 0; nb < NB; ++nb) bn[nb] = frag_b(k + 2, nb);
                 }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[nb], acc[nb], 0, 0, 0);
@@ -543,19 +593,6 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
-// wt[(kk*cout + oc)*cin + ic] = w[(kk*cin + ic)*cout + oc]
-__global__ __launch_bounds__(256) void conv_weight_transpose_kernel(const float* __restrict__ w,
-                                                                    float* __restrict__ wt, int kk_count, int cin,
-                                                                    int cout) {
-    const long total = (long)kk_count * cin * cout;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int ic = (int)(idx % cin);
-        const long t = idx / cin;
-        const int oc = (int)(t % cout), kk = (int)(t / cout);
-        wt[idx] = w[((long)kk * cin + ic) * cout + oc];
-    }
-}
-
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // workspace layout for this file: [0, half) split-D slabs, [half, end) transposed weights
@@ -563,8 +600,8 @@ inline float* ws_slabs(uocr_ctx* ctx) { return (float*)ctx->workspace; }
 inline float* ws_aux(uocr_ctx* ctx) { return (float*)((char*)ctx->workspace + ctx->workspace_bytes / 2); }
 inline size_t ws_half(uocr_ctx* ctx) { return ctx->workspace_bytes / 2; }
 
-template <typename ALoader>
-int launch_mfma(uocr_ctx* ctx, const ALoader& A, const BRowMajor& B, const Epilogue& ep, int M, int N, int depth,
+template <typename ALoader, typename BLoader>
+int launch_mfma(uocr_ctx* ctx, const ALoader& A, const BLoader& B, const Epilogue& ep, int M, int N, int depth,
                 bool allow_split) {
     const int ntiles = (depth + BD - 1) / BD;
     // 128-row tiles (two MFMAs per A fragment read) when they still fill the chip: on their own, or -- very deep
@@ -597,10 +634,10 @@ int launch_mfma(uocr_ctx* ctx, const ALoader& A, const BRowMajor& B, const Epilo
     float* slabs = nsplit > 1 ? ws_slabs(ctx) : nullptr;
     const dim3 grid(gm, gn, nsplit), block(256);
     if (bm == 128)
-        hipLaunchKernelGGL((mfma_gemm_kernel<128, ALoader>), grid, block, 0, ctx->stream, A, B, ep, M, N, ntiles, tps,
+        hipLaunchKernelGGL((mfma_gemm_kernel<128, ALoader, BLoader>), grid, block, 0, ctx->stream, A, B, ep, M, N, ntiles, tps,
                            slabs, ctx->opt_xcd);
     else
-        hipLaunchKernelGGL((mfma_gemm_kernel<64, ALoader>), grid, block, 0, ctx->stream, A, B, ep, M, N, ntiles, tps,
+        hipLaunchKernelGGL((mfma_gemm_kernel<64, ALoader, BLoader>), grid, block, 0, ctx->stream, A, B, ep, M, N, ntiles, tps,
                            slabs, ctx->opt_xcd);
     UOCR_LAUNCH_CHECK(ctx);
     if (nsplit > 1) {
@@ -631,7 +668,17 @@ bool uocr_gemm_mfma_eligible(uocr_ctx* ctx, int dtype, const GemmArgs& g) {
 }
 
 int uocr_gemm_mfma(uocr_ctx* ctx, const GemmArgs& g) {
-    // B must be row-major [depth][n]; a transposed B (dense dx: w[:-1]^T) is transposed into the workspace
+    const Epilogue ep0 = plain_epilogue((float*)g.c, g.ldc, g.accumulate);
+    if (g.b_cs != 1 && g.b_rs == 1 && g.a_cs == 1) {
+        // dense dx: B(p, j) = w[j * n_out + p] is read along the depth as it lies in memory
+        const int stored = g.a_ones_col ? g.depth - 1 : g.depth;
+        ARowMajor A{(const float*)g.a, g.a_rs, g.m, stored, g.a_ones_col,
+                    (g.a_rs % 4 == 0 && stored % 4 == 0 && aligned16(g.a)) ? 1 : 0};
+        BDepthContig B{(const float*)g.b, g.b_cs, g.n, g.depth, 0, FastDiv(g.depth),
+                       (g.b_cs % 4 == 0 && g.depth % 4 == 0 && aligned16(g.b)) ? 1 : 0};
+        return launch_mfma(ctx, A, B, ep0, g.m, g.n, g.depth, true);
+    }
+    // otherwise B must be row-major [depth][n]; a transposed B is transposed into the workspace
     BRowMajor B;
     if (g.b_cs == 1) {
         B = BRowMajor{(const float*)g.b, g.b_rs, g.depth, g.n, (g.b_rs % 4 == 0 && g.n % 4 == 0 && aligned16(g.b)) ? 1 : 0};
@@ -680,12 +727,9 @@ int uocr_conv_fwd_mfma(uocr_ctx* ctx, const void* x, const void* w, const void* 
 int uocr_conv_dgrad_mfma(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d,
                          const ActMask& mask) {
     const int M = d.n * d.h * d.w, D = d.kh * d.kw * d.cout;
-    float* wt = ws_aux(ctx);
-    hipLaunchKernelGGL(conv_weight_transpose_kernel, dim3(uocr_blocks_for((size_t)D * d.cin, 256, 1024)), dim3(256),
-                       0, ctx->stream, (const float*)w, wt, d.kh * d.kw, d.cin, d.cout);
-    UOCR_LAUNCH_CHECK(ctx);
+    // B((kk, oc), ic) = w[(kk * cin + ic) * cout + oc]: the weights as they lie in memory, read along oc
     AConvDgrad A{(const float*)dy, d, M};
-    BRowMajor B{wt, d.cin, D, d.cin, aligned16(wt) ? 1 : 0};
+    BDepthContig B{(const float*)w, d.cout, d.cin, D, d.cin, FastDiv(d.cout), aligned16(w) ? 1 : 0};
     Epilogue ep = plain_epilogue((float*)dx, d.cin, 0);
     ep.mask_y = (const float*)mask.y;
     ep.mask_act = mask.act;

@@ -8,6 +8,8 @@
                   passes, lr decay, NaN rollback to the last (then best) weights, best-weights
                   callback.  Host orchestration only.
 """
+import os
+
 import numpy as np
 import torch.distributed as dist
 
@@ -42,7 +44,7 @@ class PageTrainer:
         self.model_system.components = keep
         self.models = {n: m for n, m in self.models.items() if n in nets}
         for model in self.models.values():
-            model.enable_fusion(fuse)            # conv + LeakyReLU / Sigmoid as one forward kernel
+            model.enable_fusion(fuse, windows=os.environ.get('UOCR_WINDOWS_FUSION', '1') != '0')   # conv + LeakyReLU / Sigmoid as one forward kernel
             model.skip_input_grads(not input_grads)   # False: drop the page-input gradient nobody reads
         # one stream (lane) per net: the nets are independent until the optimizer step
         self.lanes = None

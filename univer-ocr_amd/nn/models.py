@@ -341,13 +341,14 @@ class Model(BaseModel):
         return self
 
     # -- conv + activation fusion (graph level; reference: none -- every layer is its own pass) -----
-    def enable_fusion(self, on=True, pairs=True):
+    def enable_fusion(self, on=True, pairs=True, windows=True):
         """Run every Convolutional2D whose ONLY consumer is a LeakyRelu(alpha > 0) / Sigmoid as one
         kernel with the activation in the epilogue.  Results are the same tensors the unfused graph
         produces for the activation layers; the conv's pre-activation output is not materialised
         (layers_outputs[conv] then aliases the activation output)."""
         self.fuse_activations = bool(on)
         self.fuse_pairs = bool(pairs)        # also run conv(1->16)+LeakyReLU+conv(16->1) blocks as one kernel
+        self.fuse_windows = bool(windows)    # and windows + flatten + dense as one implicit GEMM
         self._fusion = None
         return self
 
@@ -390,7 +391,7 @@ class Model(BaseModel):
             self._fusion = (fused_conv, fused_act, input_of, folded)
             self._pairs = self._find_pairs(fused_conv, input_of) if getattr(self, 'fuse_pairs', True) else {}
             self._ups = self._find_ups(fused_act) if getattr(self, 'fuse_pairs', True) else {}
-            self._wins = self._find_windows(fused_act) if getattr(self, 'fuse_pairs', True) else {}
+            self._wins = self._find_windows(fused_act) if getattr(self, 'fuse_windows', True) else {}
         return self._fusion[0], self._fusion[1]
 
     def _find_windows(self, fused_act):
