@@ -172,6 +172,14 @@ int uocr_dense_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, void*
 /* dx = dy . w[:-1]^T ; dw (+)= [x,1]^T . dy ; dx may be NULL to skip it */
 int uocr_dense_bwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* dy,
                    void* dx, void* dw, int m, int n_in, int n_out, int accumulate);
+/* FullyConnected followed by LeakyRelu / Sigmoid (my_model/model.py:250-304: dense_1, dense_2) as one
+ * GEMM: y = act([x,1] . w) (layers.py:335-339 + :377-418); and the backward of a layer whose input x IS such an
+ * activation's output: dx = (dy . w[:-1]^T) * act'(x), act' taken from the output as in uocr_act_bwd_from_output */
+int uocr_dense_fwd_act(uocr_ctx* ctx, int dtype, const void* x, const void* w, void* y,
+                       int m, int n_in, int n_out, int act, double act_alpha);
+int uocr_dense_bwd_act(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* dy,
+                       void* dx, void* dw, int m, int n_in, int n_out, int accumulate,
+                       int x_act, double x_act_alpha);
 
 /* ---- Conv2DToBatchedFixedWidthed (layers/convolutional.py:330-373) ------------------------ */
 int uocr_fixed_width_fwd(uocr_ctx* ctx, int dtype, const void* x, void* y,

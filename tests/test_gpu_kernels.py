@@ -434,3 +434,23 @@ def test_windows_dense_against_the_three_layers(shape, n_out, masked, f32):
                                **({'x_act': dX, 'act': 'leaky', 'alpha': 0.01} if masked else {}))
     check(dx, ref_dx, 1e-5, 'dx')
     check(dw, ref_dw + 0.5, 2e-5, 'dw')
+
+
+@pytest.mark.parametrize('m,n_in,n_out', [(2048, 512, 1024), (70, 36, 50), (300, 128, 162)])
+def test_dense_with_fused_activations(m, n_in, n_out, f32):
+    """FullyConnected + LeakyRelu as one GEMM (epilogue of the MFMA kernel, elementwise pass behind the generic
+    one) and dx through the fused activation that produced the layer's input (uocr_dense_fwd_act / _bwd_act)."""
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    rng = np.random.default_rng(m)
+    X = rng.standard_normal((m, n_in))
+    w = rng.standard_normal((n_in + 1, n_out)) * 0.1
+    pre = O.dense_fwd(X, w)
+    check(ops.dense_fwd(CP.copy(X), CP.copy(w), 'leaky', 0.01), np.where(pre >= 0, pre, 0.01 * pre), 1e-5, 'leaky fwd')
+    check(ops.dense_fwd(CP.copy(X), CP.copy(w), 'sigmoid'), 1.0 / (1.0 + np.exp(-pre)), 1e-5, 'sigmoid fwd')
+    g = rng.standard_normal(pre.shape)
+    ref_dx, ref_dw = O.dense_bwd(X, w, g)
+    dw = CP.copy(np.zeros(w.shape))
+    dx = ops.dense_bwd(CP.copy(X), CP.copy(w), CP.copy(g), dw, accumulate=False, x_act='leaky', x_alpha=0.01)
+    check(dx, ref_dx * np.where(X >= 0, 1.0, 0.01), 1e-5, 'dx through leaky')
+    check(dw, ref_dw, 2e-5, 'dw')

@@ -211,7 +211,8 @@ def test_fused_activation_graph_matches_reference(net_name, dt):
     model.enable_fusion()
     fused_conv, fused_act = model._fusion_maps()
     n_convs = sum(1 for name in model.layers if name.rsplit('/', 1)[-1].startswith('conv_'))
-    assert len(fused_conv) == n_convs and len(fused_act) == n_convs      # every conv is followed by one
+    n_dense = 2 if net_name == 'Char' else 0             # dense_1, dense_2 + LeakyRelu (dense_3 feeds the loss)
+    assert len(fused_conv) == n_convs + n_dense and len(fused_act) == n_convs + n_dense   # every conv is followed by one
     set_analytic_weights(model)
     X, y = CP.copy(g['sgd/X']), CP.copy(g['sgd/y'])
     close(model.predict(X)[0], g['sgd/pred0'], PASS_TOL[dt], 'pred0')

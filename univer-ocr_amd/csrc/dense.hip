@@ -94,27 +94,38 @@ int uocr_gemm_generic(uocr_ctx* ctx, int dtype, const GemmArgs& g) {
 
 extern "C" {
 
-int uocr_dense_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, void* y, int m, int n_in, int n_out) {
+int uocr_dense_fwd_act(uocr_ctx* ctx, int dtype, const void* x, const void* w, void* y, int m, int n_in, int n_out,
+                       int act, double act_alpha) {
     UOCR_CHECK_CTX(ctx);
     UOCR_REQUIRE(ctx, x && w && y && m > 0 && n_in > 0 && n_out > 0);
+    UOCR_REQUIRE(ctx, act >= UOCR_ACT_NONE && act <= UOCR_ACT_SIGMOID);
     GemmArgs g{};
     g.a = x; g.a_rs = n_in; g.a_cs = 1; g.a_ones_col = 1;
     g.b = w; g.b_rs = n_out; g.b_cs = 1;
     g.c = y; g.ldc = n_out;
     g.m = m; g.n = n_out; g.depth = n_in + 1;
+    g.act = act; g.act_alpha = act_alpha;
     return uocr_gemm(ctx, dtype, g);
 }
 
-int uocr_dense_bwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* dy, void* dx, void* dw, int m,
-                   int n_in, int n_out, int accumulate) {
+int uocr_dense_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, void* y, int m, int n_in, int n_out) {
+    return uocr_dense_fwd_act(ctx, dtype, x, w, y, m, n_in, n_out, UOCR_ACT_NONE, 0.0);
+}
+
+int uocr_dense_bwd_act(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* dy, void* dx, void* dw,
+                       int m, int n_in, int n_out, int accumulate, int x_act, double x_act_alpha) {
     UOCR_CHECK_CTX(ctx);
     UOCR_REQUIRE(ctx, x && w && dy && dw && m > 0 && n_in > 0 && n_out > 0);
-    if (dx) {   // dx[m, n_in] = dy[m, n_out] . w[:n_in, :]^T
+    UOCR_REQUIRE(ctx, x_act == UOCR_ACT_NONE || x_act == UOCR_ACT_SIGMOID || (x_act == UOCR_ACT_LEAKY && x_act_alpha > 0));
+    if (dx) {   // dx[m, n_in] = dy[m, n_out] . w[:n_in, :]^T  (* act'(x) when x is the output of a fused activation)
         GemmArgs g{};
         g.a = dy; g.a_rs = n_out; g.a_cs = 1;
         g.b = w; g.b_rs = 1; g.b_cs = n_out;
         g.c = dx; g.ldc = n_in;
         g.m = m; g.n = n_in; g.depth = n_out;
+        if (x_act != UOCR_ACT_NONE) {
+            g.mask_y = x; g.mask_act = x_act; g.mask_alpha = x_act_alpha;
+        }
         int rc = uocr_gemm(ctx, dtype, g);
         if (rc) return rc;
     }
@@ -125,6 +136,11 @@ int uocr_dense_bwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, const
     g.m = n_in + 1; g.n = n_out; g.depth = m;
     g.accumulate = accumulate;
     return uocr_gemm(ctx, dtype, g);
+}
+
+int uocr_dense_bwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* dy, void* dx, void* dw, int m,
+                   int n_in, int n_out, int accumulate) {
+    return uocr_dense_bwd_act(ctx, dtype, x, w, dy, dx, dw, m, n_in, n_out, accumulate, UOCR_ACT_NONE, 0.0);
 }
 
 }  // extern "C"

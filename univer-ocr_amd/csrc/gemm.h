@@ -11,6 +11,12 @@ struct GemmArgs {
     int a_ones_col;     // A's LAST column (p == depth-1) is all ones and not stored  ([x,1], layers.py:336)
     int a_ones_row;     // A's LAST row (i == m-1) is all ones and not stored         ([x,1]^T, layers.py:345)
     int accumulate;     // C += instead of C =
+    // fused activations of the dense layers (both zero / null in a plain GEMM; not combined with accumulate):
+    int act;            // C = act(C)                      -- forward of FullyConnected + LeakyRelu / Sigmoid
+    double act_alpha;
+    const void* mask_y; // C *= act'(mask_y[i*ldc + j])    -- dx through the fused activation that produced the
+    int mask_act;       //                                    layer's input (mask_y = that input)
+    double mask_alpha;
 };
 
 int uocr_gemm_generic(uocr_ctx* ctx, int dtype, const GemmArgs& g);

@@ -668,7 +668,12 @@ bool uocr_gemm_mfma_eligible(uocr_ctx* ctx, int dtype, const GemmArgs& g) {
 }
 
 int uocr_gemm_mfma(uocr_ctx* ctx, const GemmArgs& g) {
-    const Epilogue ep0 = plain_epilogue((float*)g.c, g.ldc, g.accumulate);
+    Epilogue ep0 = plain_epilogue((float*)g.c, g.ldc, g.accumulate);
+    ep0.act = g.act;                                  // fused activations of the dense layers (gemm.h)
+    ep0.alpha = (float)g.act_alpha;
+    ep0.mask_y = (const float*)g.mask_y;
+    ep0.mask_act = g.mask_act;
+    ep0.mask_alpha = (float)g.mask_alpha;
     if (g.b_cs != 1 && g.b_rs == 1 && g.a_cs == 1) {
         // dense dx: B(p, j) = w[j * n_out + p] is read along the depth as it lies in memory
         const int stored = g.a_ones_col ? g.depth - 1 : g.depth;
@@ -691,7 +696,7 @@ int uocr_gemm_mfma(uocr_ctx* ctx, const GemmArgs& g) {
         // transpose_kernel wrote out[c*rows + r] for c < cols = b_cs; rows = n  => out[p*n + j]
         B = BRowMajor{bt, g.n, g.depth, g.n, (g.n % 4 == 0 && aligned16(bt)) ? 1 : 0};
     }
-    const Epilogue ep = plain_epilogue((float*)g.c, g.ldc, g.accumulate);
+    const Epilogue ep = ep0;
     if (g.a_cs == 1) {
         const int stored = g.a_ones_col ? g.depth - 1 : g.depth;
         ARowMajor A{(const float*)g.a, g.a_rs, g.m, stored, g.a_ones_col,

@@ -71,6 +71,8 @@ _PROTOS = {
     'uocr_act_bwd_from_output': [_ctx, _i, _i, _d, _vp, _vp, _vp, _sz],
     'uocr_dense_fwd': [_ctx, _i, _vp, _vp, _vp, _i, _i, _i],
     'uocr_dense_bwd': [_ctx, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i],
+    'uocr_dense_fwd_act': [_ctx, _i, _vp, _vp, _vp, _i, _i, _i, _i, _d],
+    'uocr_dense_bwd_act': [_ctx, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _d],
     'uocr_fixed_width_fwd': [_ctx, _i, _vp, _vp] + [_i] * 5,
     'uocr_fixed_width_bwd': [_ctx, _i, _vp, _vp] + [_i] * 5,
     'uocr_copy_2d': [_ctx, _i, _vp, _sz, _vp, _sz, _sz, _sz],

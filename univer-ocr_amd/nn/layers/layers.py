@@ -355,25 +355,60 @@ class FullyConnected(BaseLayer):
     def _backward(self, grad, mem_id=0):
         return ops.dense_bwd(self._mem[mem_id], self.w.value, grad, self.w.grad, accumulate=True)
 
+    # this layer + the LeakyRelu / Sigmoid that follows it as one GEMM (Model.enable_fusion); same contract as
+    # Convolutional2D.forward_fused / backward_fused
+    @track_method('forward')
+    def forward_fused(self, inputs, activation):
+        X = ops.as_device(make_list_if_not(inputs)[0])
+        self._mem[0] = X
+        y = ops.dense_fwd(X, self.w.value, activation.kind, activation.alpha)
+        self._fused_out = y
+        return y
+
+    @track_method('backward')
+    def backward_fused(self, grads, activation=None, act_grad_applied=False, input_activation=None):
+        """`activation`: the fused activation behind this layer (its gradient is taken from the output unless
+        the consumer already applied it); `input_activation`: the fused activation that produced this layer's
+        input -- dx is then returned w.r.t. that activation's input."""
+        grad = ops.as_device(make_list_if_not(grads)[0])
+        if activation is not None and not act_grad_applied:
+            grad = ops.act_bwd_from_output(activation.kind, self._fused_out, grad, activation.alpha)
+        x = self._mem[0]
+        if input_activation is None:
+            dx = ops.dense_bwd(x, self.w.value, grad, self.w.grad, accumulate=True)
+        else:
+            dx = ops.dense_bwd(x, self.w.value, grad, self.w.grad, accumulate=True, x_act=input_activation.kind,
+                               x_alpha=input_activation.alpha)
+        self._fused_out = None
+        self.clear_memory()
+        return dx
+
     # this layer fed by Conv2DToBatchedFixedWidthed + Flatten: one implicit GEMM on the conv feature map
     # (Model._find_windows; ops.windows_dense_fwd)
     @track_method('forward')
-    def forward_windows(self, x, width):
+    def forward_windows(self, x, width, activation=None):
         x = ops.as_device(x)
         self._mem[0] = x
-        return ops.windows_dense_fwd(x, self.w.value, width)
+        y = ops.windows_dense_fwd(x, self.w.value, width, None if activation is None else activation.kind,
+                                  0.0 if activation is None else activation.alpha)
+        self._fused_out = y if activation is not None else None
+        return y
 
     @track_method('backward')
-    def backward_windows(self, grads, width, input_activation=None):
+    def backward_windows(self, grads, width, activation=None, act_grad_applied=False, input_activation=None):
         """Returns the gradient w.r.t. the feature map the windows were cut from; with `input_activation`
-        (the fused activation that produced it) times that activation's derivative."""
+        (the fused activation that produced it) times that activation's derivative.  `activation` as in
+        backward_fused."""
         grad = ops.as_device(make_list_if_not(grads)[0])
+        if activation is not None and not act_grad_applied:
+            grad = ops.act_bwd_from_output(activation.kind, self._fused_out, grad, activation.alpha)
         x = self._mem[0]
         if input_activation is None:
             dx = ops.windows_dense_bwd(x, self.w.value, grad, self.w.grad, width, accumulate=True)
         else:
             dx = ops.windows_dense_bwd(x, self.w.value, grad, self.w.grad, width, accumulate=True, x_act=x,
                                        act=input_activation.kind, alpha=input_activation.alpha)
+        self._fused_out = None
         self.clear_memory()
         return dx
 

@@ -210,7 +210,8 @@ class Model(BaseModel):
                 src = self.relations[fw][0]
                 x = inputs[src] if isinstance(src, int) else outputs[src]
                 if x.shape[3] % 32 == 0:
-                    outputs[node] = self.layers[node].forward_windows(x, self.layers[fw].width)
+                    act = self.layers[fused_conv[node]] if node in fused_conv else None
+                    outputs[node] = self.layers[node].forward_windows(x, self.layers[fw].width, act)
                     continue
                 for part in (fw, wins[node][1]):      # channel count the implicit GEMM does not take
                     out = self.layers[part].forward([x])
@@ -280,8 +281,10 @@ class Model(BaseModel):
                 continue
             if node in wins:                          # dW and dX w.r.t. the conv feature map in one go
                 fw, flat, act_in = wins[node]
+                act = self.layers[fused_conv[node]] if node in fused_conv else None
                 dx = self.layers[node].backward_windows(
-                    incoming(node), self.layers[fw].width,
+                    incoming(node), self.layers[fw].width, act,
+                    act_grad_applied=act is not None and self._act_folded(fused_conv[node]),
                     input_activation=None if act_in is None else self.layers[act_in])
                 grads_mem[node] = [None]
                 grads_mem[flat] = [None]
@@ -360,12 +363,12 @@ class Model(BaseModel):
             self._wins = {}
             return {}, {}
         if self._fusion is None:
-            from .layers import Convolutional2D, LeakyRelu, Sigmoid
-            fused_conv, fused_act = {}, {}
+            from .layers import Convolutional2D, FullyConnected, LeakyRelu, Sigmoid
+            fused_conv, fused_act = {}, {}           # ("conv": Convolutional2D or FullyConnected)
             for node in self._plan:
                 layer = self.layers[node]
                 consumers = self.relations_backward.get(node, {})
-                if not isinstance(layer, Convolutional2D) or len(consumers) != 1:
+                if not isinstance(layer, (Convolutional2D, FullyConnected)) or len(consumers) != 1:
                     continue
                 (dst, _), = consumers.items()
                 if isinstance(dst, int) or self.relations[dst] != [node]:
@@ -384,7 +387,7 @@ class Model(BaseModel):
                 if len(consumers) != 1:
                     continue
                 (dst, _), = consumers.items()
-                if not isinstance(dst, int) and isinstance(self.layers[dst], Convolutional2D) and \
+                if not isinstance(dst, int) and isinstance(self.layers[dst], (Convolutional2D, FullyConnected)) and \
                         self.relations[dst] == [act_node]:
                     input_of[dst] = act_node
                     folded.add(act_node)
@@ -496,10 +499,11 @@ class Model(BaseModel):
         Returns {second conv: (first conv, its LeakyReLU, the second conv's fused activation or None)}."""
         from .layers import LeakyRelu, Sigmoid
         pairs = {}
+        from .layers import Convolutional2D
         for conv_b, act_a in input_of.items():
             conv_a = self._fusion[1][act_a]
             a, b, act = self.layers[conv_a], self.layers[conv_b], self.layers[act_a]
-            if not isinstance(act, LeakyRelu):
+            if not isinstance(act, LeakyRelu) or not (isinstance(a, Convolutional2D) and isinstance(b, Convolutional2D)):
                 continue
             same = all(l.kernel_size == (3, 3) and l.stride == (1, 1) and l.padding == (1, 1) for l in (a, b))
             if not (same and (a.in_channels, a.out_channels, b.in_channels, b.out_channels) == (1, 16, 16, 1)

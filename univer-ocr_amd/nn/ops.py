@@ -207,22 +207,25 @@ def act_bwd_from_output(kind, y, dy, alpha=0.0):
 
 
 # ---- FullyConnected ---------------------------------------------------------------------------------
-def dense_fwd(x, w):
+def dense_fwd(x, w, act=None, alpha=0.0):
+    """y = act([x, 1] . w): `act` is the LeakyRelu / Sigmoid that follows the layer (None: plain dense)."""
     m, n_in = x.shape
     if w.shape[0] != n_in + 1:
         raise AssertionError(f'weights {w.shape} do not fit input {x.shape} (bias row included)')
     y = CP.empty((m, w.shape[1]), x.dtype)
-    _rt().call('uocr_dense_fwd', _same_dtype(x, w), x.ptr, w.ptr, y.ptr, m, n_in, w.shape[1])
+    _rt().call('uocr_dense_fwd_act', _same_dtype(x, w), x.ptr, w.ptr, y.ptr, m, n_in, w.shape[1], ACT_CODES[act],
+               float(alpha))
     return y
 
 
-def dense_bwd(x, w, dy, dw, accumulate=True, need_dx=True):
+def dense_bwd(x, w, dy, dw, accumulate=True, need_dx=True, x_act=None, x_alpha=0.0):
+    """`x_act`: x is the output of that (fused) activation and dx is wanted w.r.t. the activation's INPUT."""
     m, n_in = x.shape
     n_out = w.shape[1]
     code = _same_dtype(x, w, dy, dw)
     dx = CP.empty((m, n_in), dy.dtype) if need_dx else None
-    _rt().call('uocr_dense_bwd', code, x.ptr, w.ptr, dy.ptr, dx.ptr if need_dx else None, dw.ptr, m, n_in,
-               n_out, int(bool(accumulate)))
+    _rt().call('uocr_dense_bwd_act', code, x.ptr, w.ptr, dy.ptr, dx.ptr if need_dx else None, dw.ptr, m, n_in,
+               n_out, int(bool(accumulate)), ACT_CODES[x_act], float(x_alpha))
     return dx
 
 
@@ -243,12 +246,12 @@ def _windows_dims(x_shape, w, width):
     return dims, n_in * w.shape[1] * w.t.element_size()
 
 
-def windows_dense_fwd(x, w, width):
-    """(n, h, W, c) -> (n * W, n_out): fixed-width windows, flatten and dense in one kernel."""
+def windows_dense_fwd(x, w, width, act=None, alpha=0.0):
+    """(n, h, W, c) -> (n * W, n_out): fixed-width windows, flatten and dense (+ its activation) in one kernel."""
     dims, bias_off = _windows_dims(x.shape, w, width)
     y = CP.empty((dims[0] * dims[2], dims[4]), x.dtype)
     _rt().call('uocr_conv2d_fwd', _same_dtype(x, w), x.ptr, w.ptr, w.ptr + bias_off, y.ptr, *dims, 0.0, 1,
-               ACT_CODES[None], 0.0)
+               ACT_CODES[act], float(alpha))
     return y
 
 
