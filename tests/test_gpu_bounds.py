@@ -238,3 +238,29 @@ def test_fused_optimizer_tail_stays_inside_its_buffers(rt):
     for name, b in bufs.items():
         b.check(name, expect_written=False)
     assert not np.any(bufs['g'].check('g', expect_written=False))
+
+
+@pytest.mark.parametrize('shape,n_out', [((3, 1, 70, 64), 96), ((2, 2, 19, 32), 64), ((2, 1, 8, 64), 32)])
+def test_windows_dense_stays_inside_its_buffers(shape, n_out, rt):
+    """Conv2DToBatchedFixedWidthed + Flatten + FullyConnected through the conv entry points: kernel (h, 8),
+    padding (0, 4), the output cut to W columns (fewer than the padding would allow); dw and its bias row are ONE
+    array."""
+    from univer_ocr_amd.hip import lib as hiplib
+    CP, runtime = rt
+    n, h, wd, c = shape
+    n_in = h * 8 * c
+    rng = np.random.default_rng(wd)
+    x = CP.copy(rng.standard_normal(shape))
+    w = CP.copy(rng.standard_normal((n_in + 1, n_out)) * 0.1)
+    dims = (n, h, wd, c, n_out, h, 8, 1, 1, 0, 4, 1, wd)
+    bias_off = n_in * n_out * 4
+    y = Guarded(CP, n * wd * n_out)
+    runtime.call('uocr_conv2d_fwd', hiplib.F32, x.ptr, w.ptr, w.ptr + bias_off, y.ptr, *dims, 0.0, 1, hiplib.ACT_LEAKY, 0.01)
+    y.check('windows y')
+    g = CP.copy(rng.standard_normal((n * wd, n_out)))
+    dx = Guarded(CP, n * h * wd * c)
+    runtime.call('uocr_conv2d_bwd_data', hiplib.F32, g.ptr, w.ptr, dx.ptr, *dims, x.ptr, hiplib.ACT_LEAKY, 0.01)
+    dx.check('windows dx')
+    dw = Guarded(CP, (n_in + 1) * n_out)
+    runtime.call('uocr_conv2d_bwd_weight', hiplib.F32, x.ptr, g.ptr, dw.ptr, dw.ptr + bias_off, *dims, 0.0, 1, 0)
+    dw.check('windows dw + bias row')
