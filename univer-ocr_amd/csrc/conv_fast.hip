@@ -313,6 +313,49 @@ __global__ __launch_bounds__(256) void conv_dgrad_s2(const float* __restrict__ d
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward data of the Char net's first conv (5x3, stride (2, 1), pad (0, 1), 1 <- 64 channels): the page-input
+// gradient of that net.  conv_dgrad_fast gives a thread a whole pixel -- 15 predicated taps x 16 float4 loads one
+// after the other on 65 k threads (one wave per SIMD): latency.  Here SIXTEEN lanes share a pixel, each owns 4
+// of the 64 channels (a pixel's dy is one contiguous 256-B read), only the tap rows of the pixel's stride phase
+// are visited, and the 16 partial sums are added with four DPP row shifts.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_dgrad_c64s2(const float* __restrict__ dy, const float* __restrict__ w,
+                                                        float* __restrict__ dx, int n, int h, int wd, int oh, int ow,
+                                                        const float* __restrict__ mask_y, int mask_act,
+                                                        float mask_alpha) {
+    constexpr int KH = 5, KW = 3, CO = 64;
+    const size_t pix = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int q = threadIdx.x & 15;                        // channels 4q .. 4q + 3
+    const size_t total = (size_t)n * h * wd;
+    const bool live = pix < total;
+    const size_t p = live ? pix : total - 1;
+    const int x = (int)(p % wd), y = (int)((p / wd) % h), b = (int)(p / ((size_t)wd * h));
+    const float* gb = dy + (size_t)b * oh * ow * CO + 4 * q;
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {                          // tap rows ky = (y & 1) + 2t: y - ky even
+        const int ky = (y & 1) + 2 * t, gy = (y - ky) / 2;
+        if (ky >= KH || y - ky < 0 || gy >= oh) continue;  // (uniform over the 16 lanes of a pixel)
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            const int gx = x + 1 - kx;
+            if (gx < 0 || gx >= ow) continue;
+            const float4 g = *reinterpret_cast<const float4*>(gb + ((size_t)gy * ow + gx) * CO);
+            const float4 wv = *reinterpret_cast<const float4*>(w + (ky * KW + kx) * CO + 4 * q);
+            acc += g.x * wv.x + g.y * wv.y + g.z * wv.z + g.w * wv.w;
+        }
+    }
+    // sum over the 16 lanes of the pixel (one DPP row = 16 lanes)
+    acc += __shfl_xor(acc, 8, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 1, 64);
+    if (!live || q != 0) return;
+    if (mask_act != UOCR_ACT_NONE) acc *= act_grad_from_output<float>(mask_y[pix], mask_act, mask_alpha);
+    dx[pix] = acc;
+}
+
 // One-channel row segment seg[j] = row[first + j], j < N, as aligned float4 loads: `first` = 4*a - OFFS
 // with OFFS compile-time, the row start 16-byte aligned and width % 4 == 0, so every float4 is either
 // fully inside or fully outside the row (outside -> fill).  8-11 dword loads at a 16 B lane stride
@@ -1293,6 +1336,14 @@ int uocr_conv_dgrad_fast(uocr_ctx* ctx, const void* dy, const void* w, void* dx,
         hipLaunchKernelGGL((conv_c16_reduce<3, 3, PY, true>), grid, block, 0, ctx->stream, (const float*)dy,
                            (const float*)w, (const float*)nullptr, (float*)dx, d.n, d.h, d.w, d.ph, d.pw, 0.f, 0,
                            (int)UOCR_ACT_NONE, 0.f, (const float*)mask.y, mask.act, (float)mask.alpha);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
+    if (d.kh == 5 && d.kw == 3 && d.sh == 2 && d.sw == 1 && d.ph == 0 && d.pw == 1 && d.cin == 1 && d.cout == 64) {
+        const size_t pixels = (size_t)d.n * d.h * d.w;
+        hipLaunchKernelGGL(conv_dgrad_c64s2, dim3((unsigned)((pixels + 15) / 16)), dim3(256), 0, ctx->stream,
+                           (const float*)dy, (const float*)w, (float*)dx, d.n, d.h, d.w, d.oh, d.ow,
+                           (const float*)mask.y, mask.act, (float)mask.alpha);
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
