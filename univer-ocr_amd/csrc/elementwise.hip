@@ -303,6 +303,7 @@ template <typename T, int OPT, int VEC>
 __global__ __launch_bounds__(256) void opt_fused_kernel(T* __restrict__ w, T* __restrict__ g, T* __restrict__ s1,
                                                         T* __restrict__ s2, size_t n, T p0, T p1, T p2, T p3,
                                                         RegRanges rr, double* __restrict__ partial /* [grid][4] */,
+                                                        double* __restrict__ loss_out /* used when gridDim.x == 1 */,
                                                         int zero_grad) {
     struct alignas(sizeof(T) * VEC) Vec {
         T v[VEC];
@@ -351,6 +352,14 @@ __global__ __launch_bounds__(256) void opt_fused_kernel(T* __restrict__ w, T* __
         if (lane == 0) smem[wv_id][r] = t;
     }
     __syncthreads();
+    if (gridDim.x == 1) {                                  // small nets: the one block IS the whole sum, no finish launch
+        if (threadIdx.x == 0) {
+            double total = 0.0;
+            for (int r = 0; r < rr.n; ++r) total += rr.strength[r] * (smem[0][r] + smem[1][r] + smem[2][r] + smem[3][r]);
+            *loss_out = total;
+        }
+        return;
+    }
     if (threadIdx.x < 4)
         partial[(size_t)blockIdx.x * 4 + threadIdx.x] =
             smem[0][threadIdx.x] + smem[1][threadIdx.x] + smem[2][threadIdx.x] + smem[3][threadIdx.x];
@@ -626,7 +635,7 @@ static int launch_opt_fused(uocr_ctx* ctx, int dtype, int opt, void* w, void* g,
     UOCR_DISPATCH(ctx, dtype, {
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, ctx->stream, (T*)w, (T*)g, (T*)s1, (T*)s2, count, (T)p0,
-                               (T)p1, (T)p2, (T)p3, rr, partial, zero_grad);
+                               (T)p1, (T)p2, (T)p3, rr, partial, reg_loss_out, zero_grad);
         };
         if (opt == 0 && vec) launch(opt_fused_kernel<T, 0, 4>);
         else if (opt == 0) launch(opt_fused_kernel<T, 0, 1>);
@@ -634,7 +643,7 @@ static int launch_opt_fused(uocr_ctx* ctx, int dtype, int opt, void* w, void* g,
         else launch(opt_fused_kernel<T, 1, 1>);
         UOCR_LAUNCH_CHECK(ctx);
     });
-    if (nranges > 0) {
+    if (nranges > 0 && grid > 1) {
         hipLaunchKernelGGL(fused_reg_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)partial, (int)grid,
                            rr, reg_loss_out);
         UOCR_LAUNCH_CHECK(ctx);
