@@ -5,7 +5,7 @@ ROOT="$(cd "$(dirname "$0")" && pwd)"
 SRC="$ROOT/univer-ocr_amd/csrc"
 OUT="$ROOT/univer-ocr_amd/libuniver_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++20 -fPIC -I"$ROOT/include" -I"$SRC" -Wall -Wno-unused-function -Wno-unused-value)
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++20 -fPIC -I"$ROOT/include" -I"$SRC" -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-local-typedef)
 mkdir -p "$SRC/.obj"
 pids=()
 for f in "$SRC"/*.hip; do

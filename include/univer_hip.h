@@ -13,8 +13,15 @@
  *    C-contiguous, NHWC for images, (kh,kw,Cin,Cout) for conv weights, (n_in+1,n_out) with the
  *    bias as the LAST ROW for dense weights (layers.py:326-338);
  *  - `dtype` selects the arithmetic/storage type of every tensor argument of the call:
- *    UOCR_F32 (the production type) or UOCR_F64 (the reference's own type, used by the parity
- *    and numeric-gradient tests);
+ *    UOCR_F32 (the production type), UOCR_F64 (the reference's own type, used by the parity
+ *    and numeric-gradient tests) or UOCR_F16 (BASELINE configs[4], the HBM-bound high-resolution
+ *    regime): ACTIVATION tensors (x, y, dy, dx, pred, gt, grad, activation masks) are IEEE binary16
+ *    in HBM, PARAMETER tensors (w, b, dw, db, optimizer state) stay float32, every sum is
+ *    accumulated in float32 (float64 for the long reductions, as in the other modes).  Activation
+ *    GRADIENTS of the F16 mode carry a power-of-two scale so that Dice gradients of a 2-Mpixel page
+ *    (~1e-6) do not fall below binary16's range: dtype = UOCR_F16_SCALED(k) makes the loss entry
+ *    points write grad * 2^k and the bwd_weight entry points multiply dw/db by 2^-k (exact);
+ *    every other entry point is linear in the gradient and ignores k (UOCR_F16 == k = 0);
  *  - every function returns 0 (UOCR_OK) or a negative UOCR_ERR_* code and never throws;
  *    uocr_last_error(ctx) returns a human readable message for the last failure on that ctx;
  *  - all work is enqueued asynchronously on the ctx's HIP stream; nothing synchronises unless
@@ -33,20 +40,25 @@
 extern "C" {
 #endif
 
-#define UOCR_ABI_VERSION 1
+#define UOCR_ABI_VERSION 2
 
 typedef struct uocr_ctx uocr_ctx;
 
-enum { UOCR_F32 = 0, UOCR_F64 = 1 };
+enum { UOCR_F32 = 0, UOCR_F64 = 1, UOCR_F16 = 2 };
+/* F16 with activation gradients scaled by 2^k, 0 <= k <= 30 (see the conventions above) */
+#define UOCR_F16_SCALED(k) (UOCR_F16 | ((k) << 8))
+#define UOCR_DTYPE_BASE(dtype) ((dtype) & 0xff)
+#define UOCR_DTYPE_GRAD_SCALE_LOG2(dtype) (((dtype) >> 8) & 0xff)
 enum { UOCR_ACT_NONE = 0, UOCR_ACT_RELU = 1, UOCR_ACT_LEAKY = 2, UOCR_ACT_SIGMOID = 3 };
 enum { UOCR_LOSS_DICE = 0, UOCR_LOSS_JACCARD = 1 };
 enum {
     UOCR_OK = 0,
     UOCR_ERR_ARG = -1,         /* null pointer, negative size, inconsistent shape */
-    UOCR_ERR_DTYPE = -2,       /* dtype is not UOCR_F32 / UOCR_F64 */
+    UOCR_ERR_DTYPE = -2,       /* dtype is not UOCR_F32 / UOCR_F64 / UOCR_F16 (or F16 where a kernel has no F16 form) */
     UOCR_ERR_HIP = -3,         /* a HIP runtime call failed (see uocr_last_error) */
     UOCR_ERR_WORKSPACE = -4,   /* ctx workspace too small: call uocr_ctx_reserve_workspace */
-    UOCR_ERR_UNSUPPORTED = -5  /* shape outside what the kernels implement */
+    UOCR_ERR_UNSUPPORTED = -5, /* shape outside what the kernels implement */
+    UOCR_ERR_RCCL = -6         /* librccl.so.1 missing, or an RCCL call failed (see uocr_last_error) */
 };
 
 /* ---- context, memory, events (stand in for CP / cupy, gpu.py:5-29) ------------------------- */
@@ -76,6 +88,8 @@ int uocr_stream_sync(uocr_ctx* ctx);                                            
 int uocr_event_create(void** out_event);
 int uocr_event_destroy(void* event);
 int uocr_event_record(uocr_ctx* ctx, void* event);
+/* the ctx's stream waits (on the device) for `event`, recorded on any other ctx's stream: orders lanes */
+int uocr_stream_wait_event(uocr_ctx* ctx, void* event);
 int uocr_event_elapsed_ms_sync(void* start, void* stop, float* out_ms);
 /* name, CU count, HBM bytes of the ctx's device (train.py:70-90 prints the numba equivalents) */
 int uocr_device_info(uocr_ctx* ctx, char* name_out, size_t name_cap, int* cu_count, size_t* hbm_bytes);
@@ -231,16 +245,43 @@ int uocr_momentum_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* v
  * *reg_loss_out = sum_r strength_r * R_r (float64 device slot).  lo / hi / kind / strength are HOST arrays. */
 int uocr_momentum_step_fused(uocr_ctx* ctx, int dtype, void* w, void* g, void* v, size_t count, double lr,
                              double momentum, int nranges, const long long* lo, const long long* hi,
-                             const int* kind, const double* strength, double* reg_loss_out, int zero_grad);
+                             const int* kind, const double* strength, double* reg_loss_out, int zero_grad,
+                             /* optional DEVICE array {lr, momentum, -, -}: when given the kernel reads the
+                              * hyper-parameters from it instead of the by-value arguments, so a call captured in
+                              * a HIP graph follows the trainer's learning-rate decay (my_model/trainer.py:260);
+                              * NULL = use the arguments */
+                             const double* hyper_dev);
 /* the same with the Adam update of optimizers.py:56-61 (no bias correction, as the reference) */
 int uocr_adam_step_fused(uocr_ctx* ctx, int dtype, void* w, void* g, void* v, void* a, size_t count, double lr,
                          double beta1, double beta2, double eps, int nranges, const long long* lo,
                          const long long* hi, const int* kind, const double* strength, double* reg_loss_out,
-                         int zero_grad);
+                         int zero_grad, const double* hyper_dev /* {lr, beta1, beta2, eps} on the device, or NULL */);
 int uocr_rmsprop_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* a, size_t count,
                       double lr, double rho, double eps);
 /* *flag_out (int32, device) = 1 if any element is NaN else 0  (nan_weights, layers.py:139-140) */
 int uocr_has_nan(uocr_ctx* ctx, int dtype, const void* x, size_t count, int32_t* flag_out);
+
+/* ---- data parallel over the GPUs of one node: RCCL over xGMI ------------------------------------
+ * The reference has no multi-GPU path; BASELINE.json adds one to the step loop my_model/trainer.py:213-233
+ * -> nn/model_system.py:104-118 -> nn/models.py:250-254: between compute_loss_and_gradients and update_grads
+ * every rank's flat gradient buffer is summed.  One process per GPU, one communicator per process and device.
+ * librccl.so.1 is bound at run time (no link-time dependency; single-GPU use needs no RCCL).
+ *   rank 0:   uocr_dp_get_unique_id(id)  -> ship the 128 bytes to the other ranks by ANY channel (file, socket,
+ *             MPI, torch.distributed, the launcher's environment)
+ *   all:      uocr_dp_init(ctx, rank, world, id)                 (collective; blocks until every rank called)
+ *             uocr_dp_broadcast(ctx, weights, n, UOCR_F32, 0)    identical replicas
+ *   per step: uocr_dp_allreduce_sum(ctx, grads, n, UOCR_F32)     in place, asynchronous on THAT ctx's stream
+ *   all:      uocr_dp_finalize(ctx)
+ * Collectives of the communicator must be issued in the same order on every rank and must not overlap each
+ * other: issue them through one ctx (a communication lane), or chain the issuing streams with
+ * uocr_event_record / uocr_stream_wait_event. */
+#define UOCR_DP_UNIQUE_ID_BYTES 128
+int uocr_dp_get_unique_id(void* out_bytes /* UOCR_DP_UNIQUE_ID_BYTES */);
+int uocr_dp_init(uocr_ctx* ctx, int rank, int world, const void* unique_id_bytes);
+int uocr_dp_info(uocr_ctx* ctx, int* rank, int* world /* 0 = no communicator */);
+int uocr_dp_allreduce_sum(uocr_ctx* ctx, void* buf, size_t count, int dtype);
+int uocr_dp_broadcast(uocr_ctx* ctx, void* buf, size_t count, int dtype, int root);
+int uocr_dp_finalize(uocr_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,56 @@ def conv2d_bwd(X, w, g, stride=1, padding=0, padding_value=0.0, bias=True):
     return np.ascontiguousarray(dx), dw, db
 
 
+# ---- the same two functions in the reference's own COST MODEL: one Python iteration per output pixel ----
+# (convolutional.py:90-96 and :121-134).  Used by bench.py's cpu_baseline leg to time what the reference's
+# NumPy path costs per page beside the vectorised restatement above; results agree with conv2d_fwd / conv2d_bwd
+# to float64 rounding (tests/test_oracle_golden.py).
+def conv2d_fwd_loop(X, w, b, stride=1, padding=0, padding_value=0.0, bias=True):
+    """convolutional.py:62-99, loop for loop: per (y, x) a reshape, a concatenate with the bias column and a
+    dot with [[w],[b]]."""
+    kh, kw, cin, cout = w.shape
+    (sh, sw), (ph, pw) = _pair(stride), _pair(padding)
+    bsz = X.shape[0]
+    oh, ow = conv2d_out_hw(X.shape[1], X.shape[2], (kh, kw), (sh, sw), (ph, pw))
+    wb = np.concatenate((w.reshape(kh * kw * cin, cout), b.reshape(1, cout)))
+    Xp = _pad_const(X, ph, pw, padding_value)
+    result = np.zeros((bsz, oh, ow, cout))
+    bias_vec = float(bool(bias)) * np.ones((bsz, 1))
+    for y in range(oh):
+        for x in range(ow):
+            in_y, in_x = y * sh, x * sw
+            i = np.reshape(Xp[:, in_y:in_y + kh, in_x:in_x + kw, :], (bsz, kh * kw * cin))
+            i = np.concatenate((i, bias_vec), axis=1)
+            result[:, y, x, :] = np.dot(i, wb)
+    return result
+
+
+def conv2d_bwd_loop(X, w, g, stride=1, padding=0, padding_value=0.0, bias=True):
+    """convolutional.py:101-145, loop for loop: per (y, x) two dots and a scatter-add.  Returns (dx, dw, db)."""
+    kh, kw, cin, cout = w.shape
+    (sh, sw), (ph, pw) = _pair(stride), _pair(padding)
+    bsz, h, wd, _ = X.shape
+    oh, ow = g.shape[1], g.shape[2]
+    Xp = _pad_const(X, ph, pw, padding_value)
+    bias_vec = float(bool(bias)) * np.ones((bsz, 1))
+    dx_total = np.zeros(Xp.shape)
+    dw_temp = np.zeros((kh * kw * cin + 1, cout))
+    wt = np.transpose(w.reshape(kh * kw * cin, cout))
+    for y in range(oh):
+        for x in range(ow):
+            in_y, in_x = y * sh, x * sw
+            cur = g[:, y, x, :]
+            xt = np.reshape(Xp[:, in_y:in_y + kh, in_x:in_x + kw, :], (bsz, kh * kw * cin))
+            xt = np.transpose(np.concatenate((xt, bias_vec), axis=1))
+            dw_temp += np.dot(xt, cur)
+            dx = np.reshape(np.dot(cur, wt), (bsz, kh, kw, cin))
+            dx_total[:, in_y:in_y + kh, in_x:in_x + kw, :] += dx
+    db = dw_temp[-1, :]
+    dw = dw_temp[:-1, :].reshape(kh, kw, cin, cout)
+    dx = dx_total[:, ph:ph + h, pw:pw + wd, :]
+    return np.ascontiguousarray(dx), dw, db
+
+
 # ----------------------------------------------------------------------------
 # MaxPool2D  (layers/maxpool.py, CPU path = the oracle, SURVEY section 7)
 # ----------------------------------------------------------------------------
@@ -370,11 +420,14 @@ class Net:
       fixed_width cfg: width
     """
 
-    def __init__(self, spec, loss):
+    def __init__(self, spec, loss, loops=False):
         self.spec = spec
         self.loss = loss
         self.params = {}
         self.grads = {}
+        # loops=True: convolutions run one Python iteration per output pixel, as the reference's NumPy path does
+        self._conv_fwd = conv2d_fwd_loop if loops else conv2d_fwd
+        self._conv_bwd = conv2d_bwd_loop if loops else conv2d_bwd
 
     def param_names(self):
         return sorted(self.params.keys())
@@ -384,7 +437,7 @@ class Net:
         for name, kind, cfg in self.spec:
             inp = X
             if kind == 'conv':
-                X = conv2d_fwd(X, self.params[f'{name}/w'], self.params[f'{name}/b'], cfg['stride'],
+                X = self._conv_fwd(X, self.params[f'{name}/w'], self.params[f'{name}/b'], cfg['stride'],
                                cfg['padding'], cfg.get('padding_value', 0.0), cfg.get('bias', True))
             elif kind == 'dense':
                 X = dense_fwd(X, self.params[f'{name}/w'])
@@ -418,7 +471,7 @@ class Net:
         grads = {}
         for (name, kind, cfg), inp in zip(reversed(self.spec), reversed(stash)):
             if kind == 'conv':
-                g, dw, db = conv2d_bwd(inp, self.params[f'{name}/w'], g, cfg['stride'], cfg['padding'],
+                g, dw, db = self._conv_bwd(inp, self.params[f'{name}/w'], g, cfg['stride'], cfg['padding'],
                                        cfg.get('padding_value', 0.0), cfg.get('bias', True))
                 grads[f'{name}/w'], grads[f'{name}/b'] = dw, db
             elif kind == 'dense':
@@ -564,9 +617,9 @@ def analytic_net_weights(spec):
     return out
 
 
-def make_net(name, weights=None):
+def make_net(name, weights=None, loops=False):
     spec, loss = NET_SPECS[name]()
-    net = Net(spec, loss)
+    net = Net(spec, loss, loops=loops)
     net.params = dict(analytic_net_weights(spec) if weights is None else weights)
     return net
 

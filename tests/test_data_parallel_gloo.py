@@ -1,7 +1,9 @@
-"""Data-parallel path on CPU: world_size 2, gloo backend (the GPU path uses the same code with the
-"nccl" = RCCL backend).  Without a GPU the DeviceArrays are storage-only host tensors, so this
-covers what is host logic: weight broadcast at construction, the flat-gradient all-reduce, SUM vs
-MEAN semantics per loss type, deferred (overlapped) completion and the replica-consistency check."""
+"""Data-parallel path on CPU: world_size 2, gloo backend (on GPUs the same queueing / ordering code drives the
+RCCL entry points of the C ABI).  Without a GPU the DeviceArrays are storage-only host tensors, so this covers
+what is host logic: the packs re-homed into one flat buffer, weight broadcast at construction, the
+flat-gradient all-reduce, SUM vs MEAN semantics per loss type, deferred (overlapped) completion, the
+rank-independent issue order of the collectives, coalescing into one collective, the `Trainer` epoch loop with
+data parallelism, and the replica-consistency check."""
 import os
 import socket
 
@@ -18,23 +20,33 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, results, side_stream=True):
+def _worker(rank, world, port, results, coalesce):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from univer_ocr_amd.my_model.model import make_char, make_monochrome
+        from univer_ocr_amd.my_model.model import make_char, make_monochrome, make_paragraph
         from univer_ocr_amd.nn.optimizers import Momentum
         from univer_ocr_amd.parallel import DataParallel, mean_type_loss
 
         np.random.seed(100 + rank)                    # different initial weights on every rank
         mono = make_monochrome((2, 8, 8, 1), Momentum(lr=0.1))
+        para = make_paragraph((2, 16, 16, 1), Momentum(lr=0.1))
         char = make_char((1, 32, 8, 1), Momentum(lr=0.1))
         before = mono.pack.value.t.clone()
-        dp = DataParallel({'Monochrome': mono, 'Char': char}, overlap=True, side_stream=side_stream)
-        out = {'rank': rank}
+        views_before = {n: p.value.numpy().copy() for n, p in char.params().items()}
+        dp = DataParallel({'Monochrome': mono, 'Paragraph': para, 'Char': char}, overlap=True, coalesce=coalesce)
+        out = {'rank': rank, 'backend': dp.backend}
+        # 0. the packs now live in ONE flat buffer, parameters are views of it, values survived the move
+        out['one_buffer'] = (mono.pack.value.t.data_ptr() == dp.flat_value.t.data_ptr() and
+                             char.pack.grad.t.data_ptr() == dp.flat_grad.t[dp._slice[id(char)][0]:].data_ptr())
+        char.params()['Char/dense_block/dense_3/w'].value.t[0, 0] = 123.0
+        out['views'] = float(dp.flat_value.t[dp._slice[id(char)][0] + [o for p, o, s in char.pack.entries
+                                                                      if p is char.params()['Char/dense_block/dense_3/w']][0]]) == 123.0
+        if rank == 0:
+            out['kept'] = all(np.array_equal(views_before[n][1:], p.value.numpy()[1:]) for n, p in char.params().items())
         # 1. replicas start identical (rank 0's weights), and they were different before
-        out['sync0'] = dp.replicas_in_sync(mono) and dp.replicas_in_sync(char)
+        out['sync0'] = all(dp.replicas_in_sync(m) for m in (mono, para, char))
         out['changed'] = bool((before != mono.pack.value.t).any().item()) if rank != 0 else True
         assert not mean_type_loss(mono) and mean_type_loss(char)
         # 2. Dice nets SUM the gradients, immediate completion
@@ -42,31 +54,34 @@ def _worker(rank, world, port, results, side_stream=True):
         mono.defer_grad_sync = False
         mono.grad_sync(mono)
         out['mono_grad'] = float(mono.pack.grad.t[0].item())              # 1 + 2 = 3
-        # 3. SoftmaxCE nets average; deferred completion (overlap): finished only by wait()
+        out['after_one'] = dp.collectives
+        # 3. deferred completion: nothing is issued until somebody waits; then everything queued goes out in
+        # CONSTRUCTION order (Monochrome, Paragraph, Char) although it was queued Char, Monochrome, Paragraph;
+        # SoftmaxCE nets average
+        for m in (mono, para, char):
+            m.defer_grad_sync = True
         char.pack.grad.t.fill_(float(10 * (rank + 1)))
-        char.defer_grad_sync = True
+        mono.pack.grad.t.fill_(float(rank + 1))
+        para.pack.grad.t.fill_(float(5 * (rank + 1)))
         char.grad_sync(char)
-        out['pending'] = id(char) in dp._pending
+        mono.grad_sync(mono)
+        para.grad_sync(para)
+        out['queued'] = [m.name if hasattr(m, 'name') else None for m, _ in dp._queue] and len(dp._queue) == 3
+        out['not_yet'] = dp.collectives == out['after_one']
+        issued = []
+        real = dp.comm.all_reduce
+        dp.comm.all_reduce = lambda arr: (issued.append(arr.size), real(arr))[1]
+        dp.wait(para)
+        dp.comm.all_reduce = real
+        out['issued_sizes'] = issued
+        out['expected_sizes'] = ([mono.pack.total + para.pack.total + char.pack.total] if coalesce else
+                                 [mono.pack.total, para.pack.total, char.pack.total])
         dp.wait(char)
+        dp.wait(mono)
         out['char_grad'] = float(char.pack.grad.t[0].item())              # (10 + 20) / 2 = 15
-        out['drained'] = id(char) not in dp._pending
-        # 3b. bucketed all-reduce inside the Char net: the dense layers' gradients (the tail of the flat
-        # buffer) go out when dense_1 has run its backward, the conv block's with the final sync
-        out['own_groups'] = dp._groups[id(mono)] is not dp._groups[id(char)]
-        trigger, lo, hi = dp._plans[id(char)]
-        out['bucket'] = (trigger, lo > 0, hi == char.pack.total, (hi - lo) * 4 >= (1 << 20))
-        out['no_bucket_for_mono'] = id(mono) not in dp._plans and mono.bucket_hook is None
-        char.pack.grad.t.fill_(float(rank + 1))
-        char.bucket_hook(char, 'Char/dense_block/dense_2')           # not the trigger: nothing happens
-        out['early_idle'] = id(char) not in dp._early
-        char.bucket_hook(char, trigger)
-        out['early_sent'] = id(char) in dp._early
-        char.pack.grad.t[:lo].fill_(float(100 * (rank + 1)))         # the head changes after the tail left
-        char.grad_sync(char)
-        dp.wait(char)
-        out['bucket_head'] = float(char.pack.grad.t[0].item())        # (100 + 200) / 2
-        out['bucket_tail'] = float(char.pack.grad.t[-1].item())       # (1 + 2) / 2
-        out['early_drained'] = id(char) not in dp._early
+        out['para_grad'] = float(para.pack.grad.t[0].item())              # 5 + 10 = 15
+        out['mono_grad2'] = float(mono.pack.grad.t[-1].item())            # 3
+        out['drained'] = not dp._queue and not dp._reduced
         # 4. a diverged replica is detected
         if rank == 1:
             mono.pack.value.t[0] += 1.0
@@ -76,24 +91,23 @@ def _worker(rank, world, port, results, side_stream=True):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('side_stream', [True, False])
-def test_flat_gradient_allreduce_world2(side_stream):
-    """side_stream=True: asynchronous collectives on the default group, completed by wait();
-    False (the default on GPUs): synchronous collectives, one process group per net."""
+@pytest.mark.parametrize('coalesce', [False, True])
+def test_flat_gradient_allreduce_world2(coalesce):
     if torch.cuda.is_available():
         pytest.skip('CPU (gloo) rehearsal of the data-parallel logic')
     world, port = 2, _free_port()
     with mp.Manager() as manager:
         results = manager.dict()
-        mp.spawn(_worker, args=(world, port, results, side_stream), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, results, coalesce), nprocs=world, join=True)
         results = dict(results)
     assert set(results) == {0, 1}
+    assert results[0]['kept']
     for rank, out in results.items():
+        assert out['backend'] == 'gloo' and out['one_buffer'] and out['views']
         assert out['sync0'] and out['changed']
-        assert out['mono_grad'] == 3.0
-        assert out['pending'] == side_stream and out['drained'] and out['own_groups'] == (not side_stream)
-        assert out['char_grad'] == 15.0
-        assert out['bucket'] == ('Char/dense_block/dense_1', True, True, True) and out['no_bucket_for_mono']
-        assert out['early_idle'] and out['early_sent'] and out['early_drained']
-        assert out['bucket_head'] == 150.0 and out['bucket_tail'] == 1.5
+        assert out['mono_grad'] == 3.0 and out['after_one'] == 1
+        assert out['queued'] and out['not_yet']
+        assert out['issued_sizes'] == out['expected_sizes']
+        assert out['char_grad'] == 15.0 and out['para_grad'] == 15.0 and out['mono_grad2'] == 3.0
+        assert out['drained']
         assert out['sync1'] is False

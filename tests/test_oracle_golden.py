@@ -37,6 +37,28 @@ def test_conv2d(tag):
         assert np.all(db == 0) and np.all(g[f'{tag}/db'] == 0)
 
 
+@pytest.mark.parametrize('tag', conv_names())
+def test_conv2d_loop_formulation(tag):
+    """The per-output-pixel loops of the reference's NumPy path (convolutional.py:90-96, 121-134), restated in
+    oracle.conv2d_fwd_loop / conv2d_bwd_loop for bench.py's `reference-cost-model` baseline, against the
+    reference's outputs (skipped for the one large identity-test shape: 76 800 iterations per call)."""
+    g = load_golden('conv2d')
+    X = g[f'{tag}/X']
+    if X.shape[1] * X.shape[2] > 64 * 64:
+        pytest.skip('large shape: covered by the vectorised restatement')
+    kh, kw, sh, sw, ph, pw, pv, bias = g[f'{tag}/cfg']
+    kw_ = dict(stride=(int(sh), int(sw)), padding=(int(ph), int(pw)), padding_value=pv, bias=bool(bias))
+    w, b = g[f'{tag}/w'], g[f'{tag}/b']
+    close(O.conv2d_fwd_loop(X, w, b, **kw_), g[f'{tag}/y'])
+    dx, dw, db = O.conv2d_bwd_loop(X, w, g[f'{tag}/g'], **kw_)
+    close(dx, g[f'{tag}/dx'])
+    close(dw, g[f'{tag}/dw'])
+    if bias:
+        close(db, g[f'{tag}/db'])
+    else:
+        assert np.all(db == 0)
+
+
 @pytest.mark.parametrize('tag', [str(n) for n in load_golden('maxpool2d')['names']])
 def test_maxpool2d(tag):
     g = load_golden('maxpool2d')

@@ -37,9 +37,10 @@ __device__ __forceinline__ T apply_act(T v, int act, T alpha) {
 // thread = (output pixel, block of CB consecutive output channels); channel block fastest, so a
 // wave stores 64*CB contiguous elements.  Sum order = (ky, kx, ic), bias last: the order of the
 // reference's [patch, 1].[w; b] dot product (convolutional.py:92-95).
-template <typename T, int CB>
-__global__ __launch_bounds__(256) void conv_fwd_generic(const T* __restrict__ x, const T* __restrict__ w,
-                                                        const T* __restrict__ bias, T* __restrict__ y, ConvDims d,
+// TS = activation storage type (T itself, or _Float16 with T = float: UOCR_F16), T = arithmetic / parameter type
+template <typename TS, typename T, int CB>
+__global__ __launch_bounds__(256) void conv_fwd_generic(const TS* __restrict__ x, const T* __restrict__ w,
+                                                        const T* __restrict__ bias, TS* __restrict__ y, ConvDims d,
                                                         T pad_value, int use_bias, int act, T act_alpha) {
     const int nob = d.cout / CB;
     const size_t total = (size_t)d.n * d.oh * d.ow * nob;
@@ -60,32 +61,32 @@ __global__ __launch_bounds__(256) void conv_fwd_generic(const T* __restrict__ x,
             for (int kx = 0; kx < d.kw; ++kx) {
                 const int ix = ix0 + kx;
                 const bool inside = iy >= 0 && iy < d.h && ix >= 0 && ix < d.w;
-                const T* xp = x + (((size_t)b * d.h + iy) * d.w + ix) * d.cin;
+                const TS* xp = x + (((size_t)b * d.h + iy) * d.w + ix) * d.cin;
                 const T* wp = w + ((size_t)(ky * d.kw + kx) * d.cin) * d.cout + oc0;
                 for (int ic = 0; ic < d.cin; ++ic) {
-                    const T xv = inside ? xp[ic] : pad_value;
+                    const T xv = inside ? (T)xp[ic] : pad_value;
 #pragma unroll
                     for (int j = 0; j < CB; ++j) acc[j] += xv * wp[(size_t)ic * d.cout + j];
                 }
             }
         }
-        Pack<T, CB> out;
+        Pack<TS, CB> out;
 #pragma unroll
         for (int j = 0; j < CB; ++j) {
             T v = acc[j];
             if (use_bias) v += bias[oc0 + j];
-            out.v[j] = apply_act(v, act, act_alpha);
+            out.v[j] = (TS)apply_act(v, act, act_alpha);
         }
-        *reinterpret_cast<Pack<T, CB>*>(y + pix * d.cout + oc0) = out;
+        *reinterpret_cast<Pack<TS, CB>*>(y + pix * d.cout + oc0) = out;
     }
 }
 
 // thread = (input pixel, block of CB input channels).  dx[b,y,x,ic] = sum over the output pixels
 // whose window covers (y,x): dy[b,gy,gx,:] . w[ky,kx,ic,:].  Windows are visited in raster order
 // (gy, gx ascending = ky, kx descending), the order the reference scatter-adds them (:121-134).
-template <typename T, int CB>
-__global__ __launch_bounds__(256) void conv_dgrad_generic(const T* __restrict__ dy, const T* __restrict__ w,
-                                                          T* __restrict__ dx, ConvDims d, const T* __restrict__ mask_y,
+template <typename TS, typename T, int CB>
+__global__ __launch_bounds__(256) void conv_dgrad_generic(const TS* __restrict__ dy, const T* __restrict__ w,
+                                                          TS* __restrict__ dx, ConvDims d, const TS* __restrict__ mask_y,
                                                           int mask_act, T mask_alpha) {
     const int nib = d.cin / CB;
     const size_t total = (size_t)d.n * d.h * d.w * nib;
@@ -110,31 +111,32 @@ __global__ __launch_bounds__(256) void conv_dgrad_generic(const T* __restrict__ 
                 if (tx < 0 || tx % d.sw) continue;
                 const int gx = tx / d.sw;
                 if (gx >= d.ow) continue;
-                const T* gp = dy + (((size_t)b * d.oh + gy) * d.ow + gx) * d.cout;
+                const TS* gp = dy + (((size_t)b * d.oh + gy) * d.ow + gx) * d.cout;
                 const T* wp = w + ((size_t)(ky * d.kw + kx) * d.cin + ic0) * d.cout;
                 for (int oc = 0; oc < d.cout; ++oc) {
-                    const T g = gp[oc];
+                    const T g = (T)gp[oc];
 #pragma unroll
                     for (int j = 0; j < CB; ++j) acc[j] += g * wp[(size_t)j * d.cout + oc];
                 }
             }
         }
-        Pack<T, CB> out;
+        Pack<TS, CB> out;
 #pragma unroll
         for (int j = 0; j < CB; ++j) {
-            out.v[j] = acc[j];
+            T v = acc[j];
             if (mask_act != UOCR_ACT_NONE)
-                out.v[j] *= act_grad_from_output<T>(mask_y[pix * d.cin + ic0 + j], mask_act, mask_alpha);
+                v *= act_grad_from_output<T>((T)mask_y[pix * d.cin + ic0 + j], mask_act, mask_alpha);
+            out.v[j] = (TS)v;
         }
-        *reinterpret_cast<Pack<T, CB>*>(dx + pix * d.cin + ic0) = out;
+        *reinterpret_cast<Pack<TS, CB>*>(dx + pix * d.cin + ic0) = out;
     }
 }
 
 // stage 1 of dw/db: block `blk` owns output pixels [p0,p1); thread owns pair q = (k, oc) with
 // k = (ky,kx,ic) flattened, k == K = the bias row (its "x" is 1, convolutional.py:125).
 // float64 accumulation whatever T is: the sum runs over n*oh*ow (4.2 M at 32x256x512) terms.
-template <typename T>
-__global__ __launch_bounds__(256) void conv_wgrad_partial_generic(const T* __restrict__ x, const T* __restrict__ dy,
+template <typename TS, typename T>
+__global__ __launch_bounds__(256) void conv_wgrad_partial_generic(const TS* __restrict__ x, const TS* __restrict__ dy,
                                                                   double* __restrict__ partial, ConvDims d,
                                                                   T pad_value, int npairs, int pix_per_block) {
     const size_t npix = (size_t)d.n * d.oh * d.ow;
@@ -177,25 +179,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial_generic(const T* __res
 template <typename T>
 __global__ __launch_bounds__(256) void conv_wgrad_finish(const double* __restrict__ partial, T* __restrict__ dw,
                                                          T* __restrict__ db, int npairs, int nblocks, int kc,
-                                                         int accumulate) {
+                                                         int accumulate, double unscale) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= npairs) return;
     double acc = 0.0;
     for (int blk = 0; blk < nblocks; ++blk) acc += partial[(size_t)blk * npairs + q];
+    acc *= unscale;                                      // UOCR_F16_SCALED(k): 2^-k, else 1
     T* dst = q < kc ? dw + q : db + (q - kc);
     *dst = accumulate ? (T)((double)*dst + acc) : (T)acc;
 }
 
-template <typename T>
+template <typename TS, typename T>
 int fwd_generic(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
                 double pad_value, int use_bias, int act, double act_alpha) {
     int cb = (d.cout % 4 == 0) ? 4 : (d.cout % 2 == 0 ? 2 : 1);
-    while (cb > 1 && (reinterpret_cast<uintptr_t>(y) % (sizeof(T) * cb))) cb >>= 1;
+    while (cb > 1 && (reinterpret_cast<uintptr_t>(y) % (sizeof(TS) * cb))) cb >>= 1;
     const size_t total = (size_t)d.n * d.oh * d.ow * (d.cout / cb);
     const dim3 grid(uocr_blocks_for(total, 256, 1u << 20)), block(256);
 #define LAUNCH_FWD(CB)                                                                                      \
-    hipLaunchKernelGGL((conv_fwd_generic<T, CB>), grid, block, 0, ctx->stream, (const T*)x, (const T*)w,   \
-                       (const T*)b, (T*)y, d, (T)pad_value, use_bias, act, (T)act_alpha)
+    hipLaunchKernelGGL((conv_fwd_generic<TS, T, CB>), grid, block, 0, ctx->stream, (const TS*)x, (const T*)w, \
+                       (const T*)b, (TS*)y, d, (T)pad_value, use_bias, act, (T)act_alpha)
     if (cb == 4) LAUNCH_FWD(4);
     else if (cb == 2) LAUNCH_FWD(2);
     else LAUNCH_FWD(1);
@@ -204,15 +207,15 @@ int fwd_generic(uocr_ctx* ctx, const void* x, const void* w, const void* b, void
     return UOCR_OK;
 }
 
-template <typename T>
+template <typename TS, typename T>
 int dgrad_generic(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d, const ActMask& mask) {
     int cb = (d.cin % 4 == 0) ? 4 : (d.cin % 2 == 0 ? 2 : 1);
-    while (cb > 1 && (reinterpret_cast<uintptr_t>(dx) % (sizeof(T) * cb))) cb >>= 1;
+    while (cb > 1 && (reinterpret_cast<uintptr_t>(dx) % (sizeof(TS) * cb))) cb >>= 1;
     const size_t total = (size_t)d.n * d.h * d.w * (d.cin / cb);
     const dim3 grid(uocr_blocks_for(total, 256, 1u << 20)), block(256);
 #define LAUNCH_DG(CB) \
-    hipLaunchKernelGGL((conv_dgrad_generic<T, CB>), grid, block, 0, ctx->stream, (const T*)dy, (const T*)w, (T*)dx, d, \
-                       (const T*)mask.y, mask.act, (T)mask.alpha)
+    hipLaunchKernelGGL((conv_dgrad_generic<TS, T, CB>), grid, block, 0, ctx->stream, (const TS*)dy, (const T*)w, (TS*)dx, d, \
+                       (const TS*)mask.y, mask.act, (T)mask.alpha)
     if (cb == 4) LAUNCH_DG(4);
     else if (cb == 2) LAUNCH_DG(2);
     else LAUNCH_DG(1);
@@ -221,8 +224,8 @@ int dgrad_generic(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const 
     return UOCR_OK;
 }
 
-template <typename T>
-int wgrad_generic(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
+template <typename TS, typename T>
+int wgrad_generic(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
                   double pad_value, int use_bias, int accumulate) {
     const int K = d.kh * d.kw * d.cin;
     const int kc = K * d.cout;
@@ -237,11 +240,12 @@ int wgrad_generic(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* 
     const int ppb = (int)((npix + nblk - 1) / nblk);
     nblk = (npix + ppb - 1) / ppb;
     double* partial = (double*)ctx->workspace;
-    hipLaunchKernelGGL((conv_wgrad_partial_generic<T>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
-                       (const T*)x, (const T*)dy, partial, d, (T)pad_value, npairs, ppb);
+    hipLaunchKernelGGL((conv_wgrad_partial_generic<TS, T>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream,
+                       (const TS*)x, (const TS*)dy, partial, d, (T)pad_value, npairs, ppb);
     UOCR_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL((conv_wgrad_finish<T>), dim3((npairs + 255) / 256), dim3(256), 0, ctx->stream,
-                       (const double*)partial, (T*)dw, (T*)db, npairs, (int)nblk, kc, accumulate);
+                       (const double*)partial, (T*)dw, (T*)db, npairs, (int)nblk, kc, accumulate,
+                       uocr_grad_unscale(dtype));
     UOCR_LAUNCH_CHECK(ctx);
     if (!use_bias && !accumulate && db)
         UOCR_HIP(ctx, hipMemsetAsync(db, 0, (size_t)d.cout * sizeof(T), ctx->stream));
@@ -252,18 +256,20 @@ int wgrad_generic(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* 
 
 int uocr_conv_fwd_generic(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* b, void* y,
                           const ConvDims& d, double pad_value, int use_bias, int act, double act_alpha) {
-    UOCR_DISPATCH(ctx, dtype, { return fwd_generic<T>(ctx, x, w, b, y, d, pad_value, use_bias, act, act_alpha); });
+    UOCR_DISPATCH_ACT(ctx, dtype, { return fwd_generic<TS, T>(ctx, x, w, b, y, d, pad_value, use_bias, act, act_alpha); });
     return UOCR_OK;
 }
 
 int uocr_conv_dgrad_generic(uocr_ctx* ctx, int dtype, const void* dy, const void* w, void* dx, const ConvDims& d,
                             const ActMask& mask) {
-    UOCR_DISPATCH(ctx, dtype, { return dgrad_generic<T>(ctx, dy, w, dx, d, mask); });
+    UOCR_DISPATCH_ACT(ctx, dtype, { return dgrad_generic<TS, T>(ctx, dy, w, dx, d, mask); });
     return UOCR_OK;
 }
 
 int uocr_conv_wgrad_generic(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db,
                             const ConvDims& d, double pad_value, int use_bias, int accumulate) {
-    UOCR_DISPATCH(ctx, dtype, { return wgrad_generic<T>(ctx, x, dy, dw, db, d, pad_value, use_bias, accumulate); });
+    UOCR_DISPATCH_ACT(ctx, dtype, {
+        return wgrad_generic<TS, T>(ctx, dtype, x, dy, dw, db, d, pad_value, use_bias, accumulate);
+    });
     return UOCR_OK;
 }

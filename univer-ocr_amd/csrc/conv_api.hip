@@ -29,10 +29,10 @@ int uocr_conv2d_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, cons
     if (rc) return rc;
     UOCR_REQUIRE(ctx, x && w && y && (b || !use_bias));
     UOCR_REQUIRE(ctx, act >= UOCR_ACT_NONE && act <= UOCR_ACT_SIGMOID);
-    if (uocr_conv_tiled_eligible(ctx, dtype, d) && aligned16(x) && aligned16(y))
-        return uocr_conv_fwd_tiled(ctx, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
+    if (uocr_conv_tiled_eligible(ctx, dtype, d) && uocr_aligned_act(x, dtype) && uocr_aligned_act(y, dtype))
+        return uocr_conv_fwd_tiled(ctx, dtype, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
     if (uocr_conv_fast_eligible(ctx, dtype, d, x, y, w))
-        return uocr_conv_fwd_fast(ctx, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
+        return uocr_conv_fwd_fast(ctx, dtype, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
     if (uocr_conv_mfma_eligible(ctx, dtype, d, 0))
         return uocr_conv_fwd_mfma(ctx, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
     return uocr_conv_fwd_generic(ctx, dtype, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
@@ -48,7 +48,7 @@ int uocr_conv2d_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, const void* w
     UOCR_REQUIRE(ctx, dy && w && dx);
     UOCR_REQUIRE(ctx, act == UOCR_ACT_NONE || (x_act && (act == UOCR_ACT_SIGMOID || (act == UOCR_ACT_LEAKY && act_alpha > 0))));
     const ActMask mask{act == UOCR_ACT_NONE ? nullptr : x_act, act, act_alpha};
-    if (uocr_conv_fast_eligible(ctx, dtype, d, dy, dx, w)) return uocr_conv_dgrad_fast(ctx, dy, w, dx, d, mask);
+    if (uocr_conv_fast_eligible(ctx, dtype, d, dy, dx, w)) return uocr_conv_dgrad_fast(ctx, dtype, dy, w, dx, d, mask);
     if (uocr_conv_mfma_eligible(ctx, dtype, d, 1)) return uocr_conv_dgrad_mfma(ctx, dy, w, dx, d, mask);
     return uocr_conv_dgrad_generic(ctx, dtype, dy, w, dx, d, mask);
 }
@@ -62,7 +62,7 @@ int uocr_conv2d_bwd_weight(uocr_ctx* ctx, int dtype, const void* x, const void* 
     if (rc) return rc;
     UOCR_REQUIRE(ctx, x && dy && dw && db);
     if (uocr_conv_fast_eligible(ctx, dtype, d, x, dy, dw))
-        return uocr_conv_wgrad_fast(ctx, x, dy, dw, db, d, pad_value, use_bias, accumulate);
+        return uocr_conv_wgrad_fast(ctx, dtype, x, dy, dw, db, d, pad_value, use_bias, accumulate);
     if (uocr_conv_mfma_eligible(ctx, dtype, d, 2))
         return uocr_conv_wgrad_mfma(ctx, x, dy, dw, db, d, pad_value, use_bias, accumulate);
     return uocr_conv_wgrad_generic(ctx, dtype, x, dy, dw, db, d, pad_value, use_bias, accumulate);

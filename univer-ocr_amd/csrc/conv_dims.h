@@ -23,19 +23,19 @@ int uocr_conv_dgrad_mfma(uocr_ctx* ctx, const void* dy, const void* w, void* dx,
                          const ActMask& mask);
 int uocr_conv_wgrad_mfma(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
                          double pad_value, int use_bias, int accumulate);
-// LDS-tiled forward for the 5x5 stride-1 4-channel convs (conv_tiled.hip), f32
+// LDS-tiled forward for the 5x5 stride-1 4-channel convs (conv_tiled.hip), f32 / f16 storage
 bool uocr_conv_tiled_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d);
-int uocr_conv_fwd_tiled(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
+int uocr_conv_fwd_tiled(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
                         double pad_value, int use_bias, int act, double act_alpha);
-// shape-specialised direct kernels for the skinny my_model convs (conv_fast.hip), f32
+// shape-specialised direct kernels for the skinny my_model convs (conv_fast.hip), f32 / f16 storage
 bool uocr_conv_fast_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d, const void* p0, const void* p1,
                              const void* p2);
-int uocr_conv_fwd_fast(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
-                       double pad_value, int use_bias, int act, double act_alpha);
-int uocr_conv_dgrad_fast(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d,
+int uocr_conv_fwd_fast(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* b, void* y,
+                       const ConvDims& d, double pad_value, int use_bias, int act, double act_alpha);
+int uocr_conv_dgrad_fast(uocr_ctx* ctx, int dtype, const void* dy, const void* w, void* dx, const ConvDims& d,
                          const ActMask& mask);
-int uocr_conv_wgrad_fast(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
-                         double pad_value, int use_bias, int accumulate);
+int uocr_conv_wgrad_fast(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db,
+                         const ConvDims& d, double pad_value, int use_bias, int accumulate);
 // generic direct kernels (conv.hip): any shape, f32 / f64
 int uocr_conv_fwd_generic(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* b, void* y,
                           const ConvDims& d, double pad_value, int use_bias, int act, double act_alpha);

@@ -15,35 +15,21 @@
 
 namespace {
 
-template <int N>
-struct VecT;
-template <>
-struct VecT<1> {
-    using type = float;
-};
-template <>
-struct VecT<2> {
-    using type = float2;
-};
-template <>
-struct VecT<4> {
-    using type = float4;
-};
-
-// load / store C consecutive floats (C = 1, 2, 4 or a multiple of 4) with the widest vectors
-template <int C>
-__device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)[C]) {
+// load / store C consecutive activation elements (C = 1, 2, 4 or a multiple of 4) with the widest accesses;
+// TA = float or _Float16 (uocr_common.h: ld1 / ld2 / ld4), values always arrive as float
+template <int C, typename TA>
+__device__ __forceinline__ void load_vec(const TA* __restrict__ p, float (&v)[C]) {
     if constexpr (C == 1) {
-        v[0] = p[0];
+        v[0] = ld1(p);
     } else if constexpr (C == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(p);
+        const float2 t = ld2(p);
         v[0] = t.x;
         v[1] = t.y;
     } else {
         static_assert(C % 4 == 0, "channel count must be 1, 2 or a multiple of 4");
 #pragma unroll
         for (int q = 0; q < C / 4; ++q) {
-            const float4 t = reinterpret_cast<const float4*>(p)[q];
+            const float4 t = ld4(p + 4 * q);
             v[4 * q] = t.x;
             v[4 * q + 1] = t.y;
             v[4 * q + 2] = t.z;
@@ -52,16 +38,15 @@ __device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)
     }
 }
 
-template <int C>
-__device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&v)[C]) {
+template <int C, typename TA>
+__device__ __forceinline__ void store_vec(TA* __restrict__ p, const float (&v)[C]) {
     if constexpr (C == 1) {
-        p[0] = v[0];
+        st1(p, v[0]);
     } else if constexpr (C == 2) {
-        *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+        st2(p, make_float2(v[0], v[1]));
     } else {
 #pragma unroll
-        for (int q = 0; q < C / 4; ++q)
-            reinterpret_cast<float4*>(p)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        for (int q = 0; q < C / 4; ++q) st4(p + 4 * q, make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]));
     }
 }
 
@@ -79,8 +64,8 @@ struct FastDims {
 };
 
 // dx epilogue: v[c] *= act'(y[off + c]) from the activation output y (ActMask, conv_dims.h)
-template <int C>
-__device__ __forceinline__ void apply_mask(float (&v)[C], const float* __restrict__ mask_y, size_t off, int act,
+template <int C, typename TA>
+__device__ __forceinline__ void apply_mask(float (&v)[C], const TA* __restrict__ mask_y, size_t off, int act,
                                            float alpha) {
     if (act == UOCR_ACT_NONE) return;
     float m[C];
@@ -96,9 +81,9 @@ __device__ __forceinline__ void apply_mask(float (&v)[C], const float* __restric
 // these kernels were L1-bandwidth bound, not HBM bound, with one pixel per thread).
 // NQ = COUT / COB adjacent lanes share a pixel, so one wave stores 64 * COB contiguous floats.
 // ---------------------------------------------------------------------------------------------
-template <int KH, int KW, int CIN, int COUT, int SH, int SW, int COB, int PY>
-__global__ __launch_bounds__(256) void conv_fwd_fast(const float* __restrict__ x, const float* __restrict__ w,
-                                                     const float* __restrict__ bias, float* __restrict__ y,
+template <int KH, int KW, int CIN, int COUT, int SH, int SW, int COB, int PY, typename TA>
+__global__ __launch_bounds__(256) void conv_fwd_fast(const TA* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, TA* __restrict__ y,
                                                      FastDims d, float pad, int use_bias, int act, float alpha) {
     constexpr int NQ = COUT / COB;     // lanes per pixel
     constexpr int PXW = 64 / NQ;       // pixels per wave row
@@ -116,7 +101,7 @@ __global__ __launch_bounds__(256) void conv_fwd_fast(const float* __restrict__ x
 #pragma unroll
         for (int o = 0; o < COB; ++o) acc[p][o] = 0.f;
     const int iy0 = oy0 * SH - d.ph, ix0 = ox * SW - d.pw;
-    const float* xb = x + (size_t)b * d.h * d.w * CIN;
+    const TA* xb = x + (size_t)b * d.h * d.w * CIN;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const int iy = iy0 + r;
@@ -165,10 +150,10 @@ __global__ __launch_bounds__(256) void conv_fwd_fast(const float* __restrict__ x
 // pixels.  Stride 1: the PY + KH - 1 rows of dy that the PY pixels see are loaded once.
 // Stride > 1: PY must be 1 (taps are predicated on the stride phase of each lane).
 // ---------------------------------------------------------------------------------------------
-template <int KH, int KW, int CIN, int COUT, int SH, int SW, int PY>
-__global__ __launch_bounds__(256) void conv_dgrad_fast(const float* __restrict__ dy, const float* __restrict__ w,
-                                                       float* __restrict__ dx, FastDims d,
-                                                       const float* __restrict__ mask_y, int mask_act, float mask_alpha) {
+template <int KH, int KW, int CIN, int COUT, int SH, int SW, int PY, typename TA>
+__global__ __launch_bounds__(256) void conv_dgrad_fast(const TA* __restrict__ dy, const float* __restrict__ w,
+                                                       TA* __restrict__ dx, FastDims d,
+                                                       const TA* __restrict__ mask_y, int mask_act, float mask_alpha) {
     static_assert(PY == 1 || (SH == 1 && SW == 1), "row tiling of dgrad needs stride 1");
     const int ix = blockIdx.x * 64 + threadIdx.x;
     const int iy0 = (blockIdx.y * 4 + threadIdx.y) * PY;
@@ -181,7 +166,7 @@ __global__ __launch_bounds__(256) void conv_dgrad_fast(const float* __restrict__
     for (int p = 0; p < PY; ++p)
 #pragma unroll
         for (int c = 0; c < CIN; ++c) acc[p][c] = 0.f;
-    const float* gb = dy + (size_t)b * d.oh * d.ow * COUT;
+    const TA* gb = dy + (size_t)b * d.oh * d.ow * COUT;
     if constexpr (SH == 1 && SW == 1) {
         constexpr int ROWS = PY + KH - 1;
         const int gy0 = iy0 + d.ph - (KH - 1);
@@ -252,14 +237,14 @@ __global__ __launch_bounds__(256) void conv_dgrad_fast(const float* __restrict__
 // three quarters of the lanes idle in each of the 25 iterations).
 //   y = 2j:     ky = 0, 2, 4 -> dy rows j+1, j, j-1          y = 2j+1:  ky = 1, 3 -> dy rows j+1, j
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void conv_dgrad_s2(const float* __restrict__ dy, const float* __restrict__ w,
-                                                     float* __restrict__ dx, FastDims d,
-                                                     const float* __restrict__ mask_y, int mask_act,
+template <int CIN, int COUT, typename TA>
+__global__ __launch_bounds__(256) void conv_dgrad_s2(const TA* __restrict__ dy, const float* __restrict__ w,
+                                                     TA* __restrict__ dx, FastDims d,
+                                                     const TA* __restrict__ mask_y, int mask_act,
                                                      float mask_alpha) {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, b = blockIdx.z;
     if (2 * i >= d.w || 2 * j >= d.h) return;
-    const float* gb = dy + (size_t)b * d.oh * d.ow * COUT;
+    const TA* gb = dy + (size_t)b * d.oh * d.ow * COUT;
     float g[3][3][COUT];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -360,15 +345,15 @@ __global__ __launch_bounds__(256) void conv_dgrad_c64s2(const float* __restrict_
 // with OFFS compile-time, the row start 16-byte aligned and width % 4 == 0, so every float4 is either
 // fully inside or fully outside the row (outside -> fill).  8-11 dword loads at a 16 B lane stride
 // (25 % of each 128-B line per instruction, TA-bound) become 3-4 fully contiguous 16-B loads.
-template <int N, int OFFS>
-__device__ __forceinline__ void load_row_c1(const float* __restrict__ row, int a4, int width, bool row_ok,
+template <int N, int OFFS, typename TA>
+__device__ __forceinline__ void load_row_c1(const TA* __restrict__ row, int a4, int width, bool row_ok,
                                             float fill, float (&seg)[N][1]) {
     constexpr int NV4 = (OFFS + N + 3) / 4;
     float buf[NV4 * 4];
 #pragma unroll
     for (int k = 0; k < NV4; ++k) {
         const int col = a4 + 4 * k;
-        float4 v = *reinterpret_cast<const float4*>(row + min(max(col, 0), width - 4));
+        float4 v = ld4(row + min(max(col, 0), width - 4));
         if (!(row_ok && col >= 0 && col < width)) v = make_float4(fill, fill, fill, fill);
         buf[4 * k] = v.x;
         buf[4 * k + 1] = v.y;
@@ -390,9 +375,9 @@ __device__ __forceinline__ void load_row_c1(const float* __restrict__ row, int a
 //     loaded once and reused by all PX*KW taps, so L1 traffic per pixel drops from KW to
 //     ((PX-1)*SW + KW)/PX loads per row, and every weight is reused PX times from its SGPR.
 // ---------------------------------------------------------------------------------------------
-template <int KH, int KW, int CIN, int COUT, int SH, int SW, int PX>
-__global__ __launch_bounds__(256) void conv_fwd_px(const float* __restrict__ x, const float* __restrict__ w,
-                                                   const float* __restrict__ bias, float* __restrict__ y,
+template <int KH, int KW, int CIN, int COUT, int SH, int SW, int PX, typename TA>
+__global__ __launch_bounds__(256) void conv_fwd_px(const TA* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, TA* __restrict__ y,
                                                    FastDims d, float pad, int use_bias, int act, float alpha) {
     constexpr int NXV = (PX - 1) * SW + KW;
     const int ox0 = (blockIdx.x * 64 + threadIdx.x) * PX;
@@ -405,12 +390,12 @@ __global__ __launch_bounds__(256) void conv_fwd_px(const float* __restrict__ x, 
 #pragma unroll
         for (int o = 0; o < COUT; ++o) acc[p][o] = 0.f;
     const int ix0 = ox0 * SW - d.pw;
-    const float* xb = x + (size_t)b * d.h * d.w * CIN;
+    const TA* xb = x + (size_t)b * d.h * d.w * CIN;
 #pragma unroll 1
     for (int ky = 0; ky < KH; ++ky) {
         const int iy = oy * SH - d.ph + ky;
         const bool row_ok = iy >= 0 && iy < d.h;
-        const float* xr = xb + (size_t)min(max(iy, 0), d.h - 1) * d.w * CIN;
+        const TA* xr = xb + (size_t)min(max(iy, 0), d.h - 1) * d.w * CIN;
         const float* wr = w + ky * (KW * CIN * COUT);
         float xv[NXV][CIN];
         bool vec_done = false;
@@ -467,10 +452,10 @@ __global__ __launch_bounds__(256) void conv_fwd_px(const float* __restrict__ x, 
 }
 
 // stride-1 backward data with the same structure: dx[y, x0+p, c] = sum_{ky,kx,o} dy[y+ph-ky, x0+p+pw-kx, o] w[ky,kx,c,o]
-template <int KH, int KW, int CIN, int COUT, int PX>
-__global__ __launch_bounds__(256) void conv_dgrad_px(const float* __restrict__ dy, const float* __restrict__ w,
-                                                     float* __restrict__ dx, FastDims d,
-                                                     const float* __restrict__ mask_y, int mask_act, float mask_alpha) {
+template <int KH, int KW, int CIN, int COUT, int PX, typename TA>
+__global__ __launch_bounds__(256) void conv_dgrad_px(const TA* __restrict__ dy, const float* __restrict__ w,
+                                                     TA* __restrict__ dx, FastDims d,
+                                                     const TA* __restrict__ mask_y, int mask_act, float mask_alpha) {
     constexpr int NG = PX + KW - 1;
     const int ix0 = (blockIdx.x * 64 + threadIdx.x) * PX;
     const int iy = blockIdx.y * 4 + threadIdx.y;
@@ -481,13 +466,13 @@ __global__ __launch_bounds__(256) void conv_dgrad_px(const float* __restrict__ d
     for (int p = 0; p < PX; ++p)
 #pragma unroll
         for (int c = 0; c < CIN; ++c) acc[p][c] = 0.f;
-    const float* gb = dy + (size_t)b * d.oh * d.ow * COUT;
+    const TA* gb = dy + (size_t)b * d.oh * d.ow * COUT;
     const int gx0 = ix0 + d.pw - (KW - 1);
 #pragma unroll 1
     for (int ky = KH - 1; ky >= 0; --ky) {
         const int gy = iy + d.ph - ky;
         const bool row_ok = gy >= 0 && gy < d.oh;
-        const float* gr = gb + (size_t)min(max(gy, 0), d.oh - 1) * d.ow * COUT;
+        const TA* gr = gb + (size_t)min(max(gy, 0), d.oh - 1) * d.ow * COUT;
         const float* wr = w + ky * (KW * CIN * COUT);
         float g[NG][COUT];
         bool vec_done = false;
@@ -831,8 +816,8 @@ struct WgradCfg {
     static constexpr int OCG = COUT / COB;              // output-channel groups
 };
 
-template <int KH, int KW, int CIN, int COUT, int SH, int SW, int KYR, int COB, int PX, bool CLAMP>
-__global__ __launch_bounds__(256) void conv_wgrad_fast(const float* __restrict__ x, const float* __restrict__ dy,
+template <int KH, int KW, int CIN, int COUT, int SH, int SW, int KYR, int COB, int PX, bool CLAMP, typename TA>
+__global__ __launch_bounds__(256) void conv_wgrad_fast(const TA* __restrict__ x, const TA* __restrict__ dy,
                                                        float* __restrict__ partial, FastDims d, float pad,
                                                        int rows_per_block, int nbands) {
     // a thread visits PX horizontally adjacent output pixels per step: the (PX-1)*SW + KW input vectors
@@ -849,8 +834,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast(const float* __restrict__
     float acc[C::NP];
 #pragma unroll
     for (int a = 0; a < C::NP; ++a) acc[a] = 0.f;
-    const float* xb = x + (size_t)b * d.h * d.w * CIN;
-    const float* gb = dy + (size_t)b * d.oh * d.ow * COUT + oc0;
+    const TA* xb = x + (size_t)b * d.h * d.w * CIN;
+    const TA* gb = dy + (size_t)b * d.oh * d.ow * COUT + oc0;
     for (int oy = row0 + wv; oy < row1; oy += 4) {
         for (int ox0 = lane * PX; ox0 < d.ow; ox0 += 64 * PX) {
             float g[PX][COB];
@@ -933,7 +918,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast(const float* __restrict__
 template <int KH, int KW, int CIN, int COUT, int KYR, int COB, int NW, int NP>
 __global__ __launch_bounds__(256) void conv_wgrad_fast_finish(const float* __restrict__ partial, float* __restrict__ dw,
                                                               float* __restrict__ db, int nblocks, int use_bias,
-                                                              int accumulate) {
+                                                              int accumulate, float unscale) {
     __shared__ double smem[16];
     const int a = blockIdx.x, grp = blockIdx.y;
     constexpr int OCG = COUT / COB;
@@ -954,6 +939,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_finish(const float* __res
         dst = db + ocg * COB + (a - NW);
         if (!use_bias) s = 0.0;
     }
+    s *= (double)unscale;                                  // UOCR_F16_SCALED(k): 2^-k, else 1
     *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
 
@@ -970,7 +956,8 @@ constexpr int TH = 16, TW = 64, WH = TH + 4, WW = TW + 4, NACC = 42, NP = 64;   
 __device__ __forceinline__ int swz(int row, int c) { return row * WW + (c & 3) * (WW / 4) + (c >> 2); }
 }  // namespace t542
 
-__global__ __launch_bounds__(320) void conv_wgrad_t542(const float* __restrict__ x, const float* __restrict__ dy,
+template <typename TA>
+__global__ __launch_bounds__(320) void conv_wgrad_t542(const TA* __restrict__ x, const TA* __restrict__ dy,
                                                        float* __restrict__ partial, int h, int wd, float pad,
                                                        int tiles_per_block) {
     using namespace t542;
@@ -979,8 +966,8 @@ __global__ __launch_bounds__(320) void conv_wgrad_t542(const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, ky = tid >> 6;
     const int x0 = blockIdx.x * TW, b = blockIdx.z;
     const int tile0 = blockIdx.y * tiles_per_block, tiles_y = (h + TH - 1) / TH;
-    const float4* xb = reinterpret_cast<const float4*>(x) + (size_t)b * h * wd;
-    const float2* gb = reinterpret_cast<const float2*>(dy) + (size_t)b * h * wd;
+    const TA* xb = x + (size_t)b * h * wd * 4;
+    const TA* gb = dy + (size_t)b * h * wd * 2;
     float acc[NP];
 #pragma unroll
     for (int a = 0; a < NP; ++a) acc[a] = 0.f;
@@ -994,14 +981,14 @@ __global__ __launch_bounds__(320) void conv_wgrad_t542(const float* __restrict__
         for (int e = tid; e < WH * WW; e += 320) {
             const int r = e / WW, c = e - r * WW;
             const int gy = y0 - 2 + r, gx = x0 - 2 + c;
-            float4 v = xb[(size_t)min(max(gy, 0), h - 1) * wd + min(max(gx, 0), wd - 1)];
+            float4 v = ld4(xb + ((size_t)min(max(gy, 0), h - 1) * wd + min(max(gx, 0), wd - 1)) * 4);
             if (gy < 0 || gy >= h || gx < 0 || gx >= wd) v = make_float4(pad, pad, pad, pad);
             xs[swz(r, c)] = v;
         }
         for (int e = tid; e < TH * TW; e += 320) {
             const int r = e / TW, c = e - r * TW;
             const int gy = y0 + r, gx = x0 + c;
-            float2 v = gb[(size_t)min(gy, h - 1) * wd + min(gx, wd - 1)];
+            float2 v = ld2(gb + ((size_t)min(gy, h - 1) * wd + min(gx, wd - 1)) * 2);
             if (gy >= h || gx >= wd) v = make_float2(0.f, 0.f);
             gs[e] = v;
         }
@@ -1047,7 +1034,7 @@ __global__ __launch_bounds__(320) void conv_wgrad_t542(const float* __restrict__
 // block a < 200: dw[a] (= tap row a / 40, accumulator a % 40); a = 200, 201: db (from tap row 0's waves)
 __global__ __launch_bounds__(256) void conv_wgrad_t542_finish(const float* __restrict__ partial, float* __restrict__ dw,
                                                               float* __restrict__ db, int nblocks, int use_bias,
-                                                              int accumulate) {
+                                                              int accumulate, float unscale) {
     using namespace t542;
     __shared__ double smem[16];
     const int a = blockIdx.x;
@@ -1058,6 +1045,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_t542_finish(const float* __res
     if (threadIdx.x != 0) return;
     float* dst = a < 200 ? dw + a : db + (a - 200);
     if (a >= 200 && !use_bias) s = 0.0;
+    s *= (double)unscale;                                  // UOCR_F16_SCALED(k): 2^-k, else 1
     *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
 
@@ -1075,8 +1063,8 @@ struct S2Cfg {
     static constexpr int NP = ((NACC + 63) / 64) * 64;
 };
 
-template <int CIN, int COUT>
-__global__ __launch_bounds__(320) void conv_wgrad_s2_tiled(const float* __restrict__ x, const float* __restrict__ dy,
+template <int CIN, int COUT, typename TA>
+__global__ __launch_bounds__(320) void conv_wgrad_s2_tiled(const TA* __restrict__ x, const TA* __restrict__ dy,
                                                            float* __restrict__ partial, int h, int wd, int oh, int ow,
                                                            float pad, int tiles_per_block) {
     using C = S2Cfg<CIN, COUT>;
@@ -1085,8 +1073,8 @@ __global__ __launch_bounds__(320) void conv_wgrad_s2_tiled(const float* __restri
     const int tid = threadIdx.x, lane = tid & 63, ky = tid >> 6;
     const int ox0 = blockIdx.x * C::TW, b = blockIdx.z;
     const int tile0 = blockIdx.y * tiles_per_block, tiles_y = (oh + C::TH - 1) / C::TH;
-    const float* xb = x + (size_t)b * h * wd * CIN;
-    const float* gb = dy + (size_t)b * oh * ow * COUT;
+    const TA* xb = x + (size_t)b * h * wd * CIN;
+    const TA* gb = dy + (size_t)b * oh * ow * COUT;
     float acc[C::NP];
 #pragma unroll
     for (int a = 0; a < C::NP; ++a) acc[a] = 0.f;
@@ -1149,7 +1137,7 @@ __global__ __launch_bounds__(320) void conv_wgrad_s2_tiled(const float* __restri
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv_wgrad_s2_finish(const float* __restrict__ partial, float* __restrict__ dw,
                                                             float* __restrict__ db, int nblocks, int use_bias,
-                                                            int accumulate) {
+                                                            int accumulate, float unscale) {
     using C = S2Cfg<CIN, COUT>;
     __shared__ double smem[16];
     const int a = blockIdx.x, ndw = 5 * C::NW;
@@ -1160,12 +1148,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_s2_finish(const float* __restr
     if (threadIdx.x != 0) return;
     float* dst = a < ndw ? dw + a : db + (a - ndw);
     if (a >= ndw && !use_bias) s = 0.0;
+    s *= (double)unscale;                                  // UOCR_F16_SCALED(k): 2^-k, else 1
     *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
 
 template <int CIN, int COUT>
-int launch_wgrad_s2(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* db, const ConvDims& d, double pad_value,
-                    int use_bias, int accumulate) {
+int launch_wgrad_s2(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
+                    double pad_value, int use_bias, int accumulate) {
     using C = S2Cfg<CIN, COUT>;
     const int tiles_x = (d.ow + C::TW - 1) / C::TW, tiles_y = (d.oh + C::TH - 1) / C::TH;
     int per_block = 1;                                      // ~1024 blocks: a few tiles of one column strip each
@@ -1175,16 +1164,17 @@ int launch_wgrad_s2(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void
     int rc = uocr_need_workspace(ctx, (size_t)nblocks * 5 * C::NP * sizeof(float));
     if (rc) return rc;
     float* partial = (float*)ctx->workspace;
-    hipLaunchKernelGGL((conv_wgrad_s2_tiled<CIN, COUT>), grid, dim3(320), 0, ctx->stream, (const float*)x,
-                       (const float*)dy, partial, d.h, d.w, d.oh, d.ow, (float)pad_value, per_block);
+    UOCR_DISPATCH_TA(ctx, dtype, {
+        hipLaunchKernelGGL((conv_wgrad_s2_tiled<CIN, COUT, TA>), grid, dim3(320), 0, ctx->stream, (const TA*)x,
+                           (const TA*)dy, partial, d.h, d.w, d.oh, d.ow, (float)pad_value, per_block);
+    });
     UOCR_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL((conv_wgrad_s2_finish<CIN, COUT>), dim3(5 * C::NW + COUT), dim3(256), 0, ctx->stream,
-                       (const float*)partial, (float*)dw, (float*)db, nblocks, use_bias, accumulate);
+                       (const float*)partial, (float*)dw, (float*)db, nblocks, use_bias, accumulate,
+                       (float)uocr_grad_unscale(dtype));
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
 }
-
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <int KH, int KW, int CIN, int COUT, int SH, int SW, int COB, int PY, int DPY, int KYR, int WCOB, int WPY, int FPX,
           int DPX>
@@ -1194,44 +1184,49 @@ struct FastConv {
     }
     static FastDims dims(const ConvDims& d) { return FastDims{d.n, d.h, d.w, d.oh, d.ow, d.ph, d.pw}; }
 
-    static int fwd(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
+    static int fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
                    double pad, int use_bias, int act, double alpha) {
-        if constexpr (FPX > 0) {
-            const int groups = (d.ow + FPX - 1) / FPX;
-            const dim3 grid((groups + 63) / 64, (d.oh + 3) / 4, d.n), block(64, 4);
-            hipLaunchKernelGGL((conv_fwd_px<KH, KW, CIN, COUT, SH, SW, FPX>), grid, block, 0, ctx->stream,
-                               (const float*)x, (const float*)w, (const float*)b, (float*)y, dims(d), (float)pad,
-                               use_bias, act, (float)alpha);
-        } else {
-            constexpr int PXW = 64 / (COUT / COB);
-            const dim3 grid((d.ow + PXW - 1) / PXW, (d.oh + 4 * PY - 1) / (4 * PY), d.n), block(64, 4);
-            hipLaunchKernelGGL((conv_fwd_fast<KH, KW, CIN, COUT, SH, SW, COB, PY>), grid, block, 0, ctx->stream,
-                               (const float*)x, (const float*)w, (const float*)b, (float*)y, dims(d), (float)pad,
-                               use_bias, act, (float)alpha);
-        }
+        UOCR_DISPATCH_TA(ctx, dtype, {
+            if constexpr (FPX > 0) {
+                const int groups = (d.ow + FPX - 1) / FPX;
+                const dim3 grid((groups + 63) / 64, (d.oh + 3) / 4, d.n), block(64, 4);
+                hipLaunchKernelGGL((conv_fwd_px<KH, KW, CIN, COUT, SH, SW, FPX, TA>), grid, block, 0, ctx->stream,
+                                   (const TA*)x, (const float*)w, (const float*)b, (TA*)y, dims(d), (float)pad,
+                                   use_bias, act, (float)alpha);
+            } else {
+                constexpr int PXW = 64 / (COUT / COB);
+                const dim3 grid((d.ow + PXW - 1) / PXW, (d.oh + 4 * PY - 1) / (4 * PY), d.n), block(64, 4);
+                hipLaunchKernelGGL((conv_fwd_fast<KH, KW, CIN, COUT, SH, SW, COB, PY, TA>), grid, block, 0, ctx->stream,
+                                   (const TA*)x, (const float*)w, (const float*)b, (TA*)y, dims(d), (float)pad,
+                                   use_bias, act, (float)alpha);
+            }
+        });
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
 
-    static int dgrad(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d, const ActMask& mask) {
-        if constexpr (DPX > 0) {
-            static_assert(DPX == 0 || (SH == 1 && SW == 1), "conv_dgrad_px is stride 1 only");
-            const int groups = (d.w + DPX - 1) / DPX;
-            const dim3 grid((groups + 63) / 64, (d.h + 3) / 4, d.n), block(64, 4);
-            hipLaunchKernelGGL((conv_dgrad_px<KH, KW, CIN, COUT, DPX>), grid, block, 0, ctx->stream,
-                               (const float*)dy, (const float*)w, (float*)dx, dims(d), (const float*)mask.y, mask.act,
-                               (float)mask.alpha);
-        } else {
-            const dim3 grid((d.w + 63) / 64, (d.h + 4 * DPY - 1) / (4 * DPY), d.n), block(64, 4);
-            hipLaunchKernelGGL((conv_dgrad_fast<KH, KW, CIN, COUT, SH, SW, DPY>), grid, block, 0, ctx->stream,
-                               (const float*)dy, (const float*)w, (float*)dx, dims(d), (const float*)mask.y, mask.act,
-                               (float)mask.alpha);
-        }
+    static int dgrad(uocr_ctx* ctx, int dtype, const void* dy, const void* w, void* dx, const ConvDims& d,
+                     const ActMask& mask) {
+        UOCR_DISPATCH_TA(ctx, dtype, {
+            if constexpr (DPX > 0) {
+                static_assert(DPX == 0 || (SH == 1 && SW == 1), "conv_dgrad_px is stride 1 only");
+                const int groups = (d.w + DPX - 1) / DPX;
+                const dim3 grid((groups + 63) / 64, (d.h + 3) / 4, d.n), block(64, 4);
+                hipLaunchKernelGGL((conv_dgrad_px<KH, KW, CIN, COUT, DPX, TA>), grid, block, 0, ctx->stream,
+                                   (const TA*)dy, (const float*)w, (TA*)dx, dims(d), (const TA*)mask.y, mask.act,
+                                   (float)mask.alpha);
+            } else {
+                const dim3 grid((d.w + 63) / 64, (d.h + 4 * DPY - 1) / (4 * DPY), d.n), block(64, 4);
+                hipLaunchKernelGGL((conv_dgrad_fast<KH, KW, CIN, COUT, SH, SW, DPY, TA>), grid, block, 0, ctx->stream,
+                                   (const TA*)dy, (const float*)w, (TA*)dx, dims(d), (const TA*)mask.y, mask.act,
+                                   (float)mask.alpha);
+            }
+        });
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
 
-    static int wgrad(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
+    static int wgrad(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
                      double pad, int use_bias, int accumulate) {
         using C = WgradCfg<KH, KW, CIN, COUT, SH, SW, KYR, WCOB>;
         // bands of output rows: ~512 blocks per (tap group, channel group), at least 4 rows each
@@ -1245,13 +1240,15 @@ struct FastConv {
         int rc = uocr_need_workspace(ctx, bytes);
         if (rc) return rc;
         float* partial = (float*)ctx->workspace;
-        hipLaunchKernelGGL((conv_wgrad_fast<KH, KW, CIN, COUT, SH, SW, KYR, WCOB, WPY, (CIN >= 4)>), dim3(nblocks, ngroups),
-                           dim3(64, 4), 0, ctx->stream, (const float*)x, (const float*)dy, partial, dims(d),
-                           (float)pad, rows, nbands);
+        UOCR_DISPATCH_TA(ctx, dtype, {
+            hipLaunchKernelGGL((conv_wgrad_fast<KH, KW, CIN, COUT, SH, SW, KYR, WCOB, WPY, (CIN >= 4), TA>),
+                               dim3(nblocks, ngroups), dim3(64, 4), 0, ctx->stream, (const TA*)x, (const TA*)dy,
+                               partial, dims(d), (float)pad, rows, nbands);
+        });
         UOCR_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL((conv_wgrad_fast_finish<KH, KW, CIN, COUT, KYR, WCOB, C::NW, C::NP>),
                            dim3(C::NACC, ngroups), dim3(256), 0, ctx->stream, (const float*)partial, (float*)dw,
-                           (float*)db, nblocks, use_bias, accumulate);
+                           (float*)db, nblocks, use_bias, accumulate, (float)uocr_grad_unscale(dtype));
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
@@ -1274,8 +1271,10 @@ struct FastConv {
 
 bool uocr_conv_fast_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d, const void* p0, const void* p1,
                              const void* p2) {
-    if (dtype != UOCR_F32 || !ctx->opt_fast) return false;
-    if (!aligned16(p0) || !aligned16(p1) || !aligned16(p2)) return false;
+    const int base = UOCR_DTYPE_BASE(dtype);
+    if ((base != UOCR_F32 && base != UOCR_F16) || !ctx->opt_fast) return false;
+    // p0, p1: the two activation tensors of the call (4-element accesses); p2: a float32 parameter tensor
+    if (!uocr_aligned_act(p0, dtype) || !uocr_aligned_act(p1, dtype) || !uocr_aligned_act(p2, UOCR_F32)) return false;
 #define X(KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX) \
     if (FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::match(d)) return true;
     UOCR_FAST_CONVS(X)
@@ -1290,9 +1289,12 @@ inline bool is_c16_same(const ConvDims& d, int cin, int cout) {
 }
 }  // namespace
 
-int uocr_conv_fwd_fast(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
-                       double pad_value, int use_bias, int act, double act_alpha) {
-    if (is_c16_same(d, 1, 16)) {
+// (the 16-channel quad-lane kernels and the Char conv_1 dx kernel exist in float32 only: binary16 runs those
+// shapes -- none of them is on the page nets' fused path -- through the FastConv kernels of the table)
+int uocr_conv_fwd_fast(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* b, void* y,
+                       const ConvDims& d, double pad_value, int use_bias, int act, double act_alpha) {
+    const bool f32 = UOCR_DTYPE_BASE(dtype) == UOCR_F32;
+    if (f32 && is_c16_same(d, 1, 16)) {
         constexpr int PY = 2;
         const dim3 grid((d.w + 15) / 16, (d.h + 4 * PY - 1) / (4 * PY), d.n), block(64, 4);
         hipLaunchKernelGGL((conv_c16_expand<3, 3, PY, false>), grid, block, 0, ctx->stream, (const float*)x,
@@ -1301,7 +1303,7 @@ int uocr_conv_fwd_fast(uocr_ctx* ctx, const void* x, const void* w, const void* 
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
-    if (is_c16_same(d, 16, 1)) {
+    if (f32 && is_c16_same(d, 16, 1)) {
         constexpr int PY = 4;
         const dim3 grid((d.w + 15) / 16, (d.h + 4 * PY - 1) / (4 * PY), d.n), block(64, 4);
         hipLaunchKernelGGL((conv_c16_reduce<3, 3, PY, false>), grid, block, 0, ctx->stream, (const float*)x,
@@ -1312,16 +1314,17 @@ int uocr_conv_fwd_fast(uocr_ctx* ctx, const void* x, const void* w, const void* 
     }
 #define X(KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX)                        \
     if (FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::match(d))      \
-        return FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::fwd(ctx, x, w, b, y, d, pad_value, use_bias, act, \
+        return FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::fwd(ctx, dtype, x, w, b, y, d, pad_value, use_bias, act, \
                                                                         act_alpha);
     UOCR_FAST_CONVS(X)
 #undef X
     UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "no fast conv kernel for this shape");
 }
 
-int uocr_conv_dgrad_fast(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d,
+int uocr_conv_dgrad_fast(uocr_ctx* ctx, int dtype, const void* dy, const void* w, void* dx, const ConvDims& d,
                          const ActMask& mask) {
-    if (is_c16_same(d, 16, 1)) {
+    const bool f32 = UOCR_DTYPE_BASE(dtype) == UOCR_F32;
+    if (f32 && is_c16_same(d, 16, 1)) {
         constexpr int PY = 2;
         const dim3 grid((d.w + 15) / 16, (d.h + 4 * PY - 1) / (4 * PY), d.n), block(64, 4);
         hipLaunchKernelGGL((conv_c16_expand<3, 3, PY, true>), grid, block, 0, ctx->stream, (const float*)dy,
@@ -1330,7 +1333,7 @@ int uocr_conv_dgrad_fast(uocr_ctx* ctx, const void* dy, const void* w, void* dx,
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
-    if (is_c16_same(d, 1, 16)) {
+    if (f32 && is_c16_same(d, 1, 16)) {
         constexpr int PY = 4;
         const dim3 grid((d.w + 15) / 16, (d.h + 4 * PY - 1) / (4 * PY), d.n), block(64, 4);
         hipLaunchKernelGGL((conv_c16_reduce<3, 3, PY, true>), grid, block, 0, ctx->stream, (const float*)dy,
@@ -1339,7 +1342,7 @@ int uocr_conv_dgrad_fast(uocr_ctx* ctx, const void* dy, const void* w, void* dx,
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
-    if (d.kh == 5 && d.kw == 3 && d.sh == 2 && d.sw == 1 && d.ph == 0 && d.pw == 1 && d.cin == 1 && d.cout == 64) {
+    if (f32 && d.kh == 5 && d.kw == 3 && d.sh == 2 && d.sw == 1 && d.ph == 0 && d.pw == 1 && d.cin == 1 && d.cout == 64) {
         const size_t pixels = (size_t)d.n * d.h * d.w;
         hipLaunchKernelGGL(conv_dgrad_c64s2, dim3((unsigned)((pixels + 15) / 16)), dim3(256), 0, ctx->stream,
                            (const float*)dy, (const float*)w, (float*)dx, d.n, d.h, d.w, d.oh, d.ow,
@@ -1351,27 +1354,30 @@ int uocr_conv_dgrad_fast(uocr_ctx* ctx, const void* dy, const void* w, void* dx,
         ((d.cin == 1 && (d.cout == 1 || d.cout == 4)) || (d.cin == 4 && d.cout == 4))) {
         const dim3 grid(((d.w + 1) / 2 + 63) / 64, ((d.h + 1) / 2 + 3) / 4, d.n), block(64, 4);
         const FastDims fd{d.n, d.h, d.w, d.oh, d.ow, d.ph, d.pw};
-        auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, (const float*)dy, (const float*)w, (float*)dx, fd,
-                               (const float*)mask.y, mask.act, (float)mask.alpha);
-        };
-        if (d.cin == 4) launch(conv_dgrad_s2<4, 4>);
-        else if (d.cout == 1) launch(conv_dgrad_s2<1, 1>);
-        else launch(conv_dgrad_s2<1, 4>);
+        UOCR_DISPATCH_TA(ctx, dtype, {
+            auto launch = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, grid, block, 0, ctx->stream, (const TA*)dy, (const float*)w, (TA*)dx, fd,
+                                   (const TA*)mask.y, mask.act, (float)mask.alpha);
+            };
+            if (d.cin == 4) launch(conv_dgrad_s2<4, 4, TA>);
+            else if (d.cout == 1) launch(conv_dgrad_s2<1, 1, TA>);
+            else launch(conv_dgrad_s2<1, 4, TA>);
+        });
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
 #define X(KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX)                   \
     if (FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::match(d)) \
-        return FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::dgrad(ctx, dy, w, dx, d, mask);
+        return FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::dgrad(ctx, dtype, dy, w, dx, d, mask);
     UOCR_FAST_CONVS(X)
 #undef X
     UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "no fast conv kernel for this shape");
 }
 
-int uocr_conv_wgrad_fast(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
-                         double pad_value, int use_bias, int accumulate) {
-    if (is_c16_same(d, 16, 1) && pad_value == 0.0) {
+int uocr_conv_wgrad_fast(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db,
+                         const ConvDims& d, double pad_value, int use_bias, int accumulate) {
+    const bool f32 = UOCR_DTYPE_BASE(dtype) == UOCR_F32;
+    if (f32 && is_c16_same(d, 16, 1) && pad_value == 0.0) {
         constexpr int NA = 3 * 3 * 4 + 1;
         int rows = (d.n * d.h + 2047) / 2048;
         rows = ((rows + 3) / 4) * 4;
@@ -1391,7 +1397,8 @@ int uocr_conv_wgrad_fast(uocr_ctx* ctx, const void* x, const void* dy, void* dw,
     if (d.kh == 5 && d.kw == 5 && d.sh == 2 && d.sw == 2 && d.ph == 2 && d.pw == 2 && ctx->opt_tiled == 1) {
         // (measured against conv_wgrad_fast on one box: 1 -> 4 20 vs 25 us; 1 -> 1 17 vs 15 and 4 -> 4 34 vs 29 us
         // lose -- too little work per staged tile -- and stay on the register kernels)
-        if (d.cin == 1 && d.cout == 4) return launch_wgrad_s2<1, 4>(ctx, x, dy, dw, db, d, pad_value, use_bias, accumulate);
+        if (d.cin == 1 && d.cout == 4)
+            return launch_wgrad_s2<1, 4>(ctx, dtype, x, dy, dw, db, d, pad_value, use_bias, accumulate);
     }
     if (d.kh == 5 && d.kw == 5 && d.cin == 4 && d.cout == 2 && d.sh == 1 && d.sw == 1 && d.ph == 2 && d.pw == 2) {
         const int tiles_x = (d.w + t542::TW - 1) / t542::TW, tiles_y = (d.h + t542::TH - 1) / t542::TH;
@@ -1403,17 +1410,19 @@ int uocr_conv_wgrad_fast(uocr_ctx* ctx, const void* x, const void* dy, void* dw,
         int rc = uocr_need_workspace(ctx, (size_t)nblocks * 5 * t542::NACC * sizeof(float));
         if (rc) return rc;
         float* partial = (float*)ctx->workspace;
-        hipLaunchKernelGGL(conv_wgrad_t542, grid, dim3(320), 0, ctx->stream, (const float*)x, (const float*)dy, partial,
-                           d.h, d.w, (float)pad_value, per_block);
+        UOCR_DISPATCH_TA(ctx, dtype, {
+            hipLaunchKernelGGL((conv_wgrad_t542<TA>), grid, dim3(320), 0, ctx->stream, (const TA*)x, (const TA*)dy,
+                               partial, d.h, d.w, (float)pad_value, per_block);
+        });
         UOCR_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(conv_wgrad_t542_finish, dim3(202), dim3(256), 0, ctx->stream, (const float*)partial,
-                           (float*)dw, (float*)db, nblocks, use_bias, accumulate);
+                           (float*)dw, (float*)db, nblocks, use_bias, accumulate, (float)uocr_grad_unscale(dtype));
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
 #define X(KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX)                   \
     if (FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::match(d)) \
-        return FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::wgrad(ctx, x, dy, dw, db, d, pad_value, use_bias, \
+        return FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::wgrad(ctx, dtype, x, dy, dw, db, d, pad_value, use_bias, \
                                                                           accumulate);
     UOCR_FAST_CONVS(X)
 #undef X

@@ -63,10 +63,11 @@ struct Stage {
 // Block = column strip of TW outputs x rows [band*rows_per_block, +rows_per_block) of image blockIdx.z, walked
 // tile by tile (TH x TW = 14 x 30 outputs need a1 on the 16 x 32 region); the next tile's x is in flight
 // (registers) while the current one is computed.  Wave w owns region rows 4w..4w+3 (8 groups of 16 positions).
-__global__ __launch_bounds__(256) void conv_pair_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+template <typename TA>
+__global__ __launch_bounds__(256) void conv_pair_fwd_kernel(const TA* __restrict__ x, const float* __restrict__ w1,
                                                             const float* __restrict__ b1,
                                                             const float* __restrict__ w2,
-                                                            const float* __restrict__ b2, float* __restrict__ y,
+                                                            const float* __restrict__ b2, TA* __restrict__ y,
                                                             int h, int wd, int rows_per_block, float pad1,
                                                             int use_b1, int use_b2, float alpha, int act2) {
     constexpr int TH = RH - 2, TW = RW - 2;
@@ -75,8 +76,8 @@ __global__ __launch_bounds__(256) void conv_pair_fwd_kernel(const float* __restr
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
     const int x0 = blockIdx.x * TW;
     const int row_begin = blockIdx.y * rows_per_block, row_end = min(h, row_begin + rows_per_block);
-    const float* xb = x + (size_t)blockIdx.z * h * wd;
-    float* yb = y + (size_t)blockIdx.z * h * wd;
+    const TA* xb = x + (size_t)blockIdx.z * h * wd;
+    TA* yb = y + (size_t)blockIdx.z * h * wd;
     // constant MFMA operands.  Z: A = W1^T (m = ch = n, k -> tap 4kc+kq), B = x at (pos n) + tap.
     // P: A = a1 register j (m = pos n, k -> ch 4kq+j), B = W2^T (k -> ch 4kq+j, n = tap)
     float w1a[3], w2b[4], bias4[4];
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void conv_pair_fwd_kernel(const float* __restr
     float px[NPF];
     st.locate(tid, row_begin - 2, x0 - 2, h, wd);
 #pragma unroll
-    for (int k = 0; k < NPF; ++k) px[k] = xb[st.off[k]];
+    for (int k = 0; k < NPF; ++k) px[k] = ld1(xb + st.off[k]);
     for (int y0 = row_begin; y0 < row_end; y0 += TH) {
         __syncthreads();                                 // the previous tile's LDS reads are over
 #pragma unroll
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void conv_pair_fwd_kernel(const float* __restr
         if (y0 + TH < row_end) {                         // next tile: loads overlap this tile's math
             st.locate(tid, y0 + TH - 2, x0 - 2, h, wd);
 #pragma unroll
-            for (int k = 0; k < NPF; ++k) px[k] = xb[st.off[k]];
+            for (int k = 0; k < NPF; ++k) px[k] = ld1(xb + st.off[k]);
         }
         // region origin = (y0 - 1, x0 - 1), xs origin one further out: tap (ty,tx) of region (r,c) = xs[r+ty][c+tx]
 #pragma unroll 2
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void conv_pair_fwd_kernel(const float* __restr
             for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
                 for (int tx = 0; tx < 3; ++tx) v += ps[((pr + ty) * RW + pc + tx) * 9 + ty * 3 + tx];
-            if (gy < row_end && gx < wd) yb[(size_t)gy * wd + gx] = out_act(v, act2);
+            if (gy < row_end && gx < wd) st1(yb + (size_t)gy * wd + gx, out_act(v, act2));
         }
     }
 }
@@ -161,13 +162,13 @@ __device__ __forceinline__ int ring_index(int er, int ec) {      // (er, ec) in 
     if (ec == -1) return 2 * XW + er;
     return 2 * XW + RH + er;
 }
-template <bool DX, bool SIG>
-__global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restrict__ x, const float* __restrict__ yout,
-                                                            const float* __restrict__ dy,
+template <bool DX, bool SIG, typename TA>
+__global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const TA* __restrict__ x, const TA* __restrict__ yout,
+                                                            const TA* __restrict__ dy,
                                                             const float* __restrict__ w1,
                                                             const float* __restrict__ b1,
                                                             const float* __restrict__ w2,
-                                                            float* __restrict__ partial, float* __restrict__ dx,
+                                                            float* __restrict__ partial, TA* __restrict__ dx,
                                                             float* __restrict__ border, int h, int wd,
                                                             int rows_per_block, float pad1, int use_b1, float alpha) {
     constexpr int OFF = 0;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restr
     const int x0 = blockIdx.x * TW;
     const int row_begin = blockIdx.y * rows_per_block, row_end = min(h, row_begin + rows_per_block);
     const size_t img = (size_t)blockIdx.z * h * wd;
-    const float *xb = x + img, *gb = dy + img, *yb = yout + img;
+    const TA *xb = x + img, *gb = dy + img, *yb = yout + img;
     // constant operands.  Z^T / S^T: A = x or g at (pos n) shifted by tap 4kc+kq, B = W1 / W2 [tap][ch = n]
     float w1b[3], w2b[3], w1u[4];
     int xoff[3], goff[3];
@@ -214,9 +215,9 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restr
         st.locate(tid, y0 - OFF - 1, x0 - OFF - 1, h, wd);
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
-            px[k] = xb[st.off[k]];
-            pg[k] = gb[st.off[k]];
-            if constexpr (SIG) py[k] = yb[st.off[k]];
+            px[k] = ld1(xb + st.off[k]);
+            pg[k] = ld1(gb + st.off[k]);
+            if constexpr (SIG) py[k] = ld1(yb + st.off[k]);
         }
     };
     prefetch(row_begin);
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restr
                     }
                 const int gy = y0 + er, gx = x0 + ec;
                 if (gy < 0 || gy >= h || gx < 0 || gx >= wd) continue;
-                if (er >= 0 && er < RH && ec >= 0 && ec < RW) dx[img + (size_t)gy * wd + gx] = v;
+                if (er >= 0 && er < RH && ec >= 0 && ec < RW) st1(dx + img + (size_t)gy * wd + gx, v);
                 else border[tile_id * RING + ring_index(er, ec)] = v;
             }
         }
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void conv_pair_bwd_finish(const float* __restrict__ partial, float* __restrict__ dw1,
                                                             float* __restrict__ db1, float* __restrict__ dw2,
                                                             float* __restrict__ db2, int nblocks, int use_b1,
-                                                            int use_b2, int accumulate) {
+                                                            int use_b2, int accumulate, float unscale) {
     __shared__ double smem[16];
     const int k = blockIdx.x, q = blockIdx.y;
     double s = 0.0;
@@ -360,12 +361,14 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_finish(const float* __restr
         dst = db2;
         if (!use_b2) s = 0.0;
     }
+    s *= (double)unscale;                                // UOCR_F16_SCALED(k): 2^-k, else 1
     *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
 
 // dx of the tile-edge pixels += what the 8 neighbouring tiles wrote on their rings (fixed order: N, S, W, E,
 // NW, NE, SW, SE).  One thread per (tile, edge pixel): 2 * RW + 2 * (RH - 2) = 92 per tile.
-__global__ __launch_bounds__(256) void conv_pair_dx_border(const float* __restrict__ border, float* __restrict__ dx,
+template <typename TA>
+__global__ __launch_bounds__(256) void conv_pair_dx_border(const float* __restrict__ border, TA* __restrict__ dx,
                                                            int n, int h, int wd, int tiles_y, int tiles_x) {
     constexpr int EDGE = 2 * RW + 2 * (RH - 2);
     const size_t total = (size_t)n * tiles_y * tiles_x * EDGE;
@@ -392,7 +395,8 @@ __global__ __launch_bounds__(256) void conv_pair_dx_border(const float* __restri
             if (er >= 0 && er < RH && ec >= 0 && ec < RW) continue;          // (cannot happen for a neighbour)
             add += border[(((size_t)b * tiles_y + ny) * tiles_x + nx) * RING + ring_index(er, ec)];
         }
-        dx[((size_t)b * h + gy) * wd + gx] += add;
+        TA* p = dx + ((size_t)b * h + gy) * wd + gx;
+        st1(p, ld1(p) + add);
     }
 }
 
@@ -405,7 +409,8 @@ int pair_rows_per_block(int strips, int h, int n, int th, unsigned max_blocks) {
 }
 
 int check_pair(uocr_ctx* ctx, int dtype, int n, int h, int w, int cmid, int act2) {
-    if (dtype != UOCR_F32) UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "conv_pair: float32 only");
+    if (UOCR_DTYPE_BASE(dtype) != UOCR_F32 && UOCR_DTYPE_BASE(dtype) != UOCR_F16)
+        UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "conv_pair: float32 / float16 only");
     if (cmid != C) UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "conv_pair: 16 middle channels only (got %d)", cmid);
     if (act2 != UOCR_ACT_NONE && act2 != UOCR_ACT_SIGMOID)
         UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "conv_pair: output activation must be none or sigmoid");
@@ -425,9 +430,11 @@ extern "C" int uocr_conv_pair_fwd(uocr_ctx* ctx, int dtype, const void* x, const
     const int strips = (w + RW - 3) / (RW - 2);
     const int rows_per_block = pair_rows_per_block(strips, h, n, RH - 2, 8192u);
     const dim3 grid(strips, (h + rows_per_block - 1) / rows_per_block, n);
-    hipLaunchKernelGGL(conv_pair_fwd_kernel, grid, dim3(256), 0, ctx->stream, (const float*)x, (const float*)w1,
-                       (const float*)b1, (const float*)w2, (const float*)b2, (float*)y, h, w, rows_per_block,
-                       (float)pad_value1, use_bias1, use_bias2, (float)alpha1, act2);
+    UOCR_DISPATCH_TA(ctx, dtype, {
+        hipLaunchKernelGGL((conv_pair_fwd_kernel<TA>), grid, dim3(256), 0, ctx->stream, (const TA*)x, (const float*)w1,
+                           (const float*)b1, (const float*)w2, (const float*)b2, (TA*)y, h, w, rows_per_block,
+                           (float)pad_value1, use_bias1, use_bias2, (float)alpha1, act2);
+    });
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
 }
@@ -451,26 +458,29 @@ extern "C" int uocr_conv_pair_bwd(uocr_ctx* ctx, int dtype, const void* x, const
     float* partial = (float*)ctx->workspace;
     float* border = (float*)((char*)ctx->workspace + partial_bytes);
     const dim3 grid(strips, bands, n);
-    auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, ctx->stream, (const float*)x, (const float*)y, (const float*)dy,
-                           (const float*)w1, (const float*)b1, (const float*)w2, partial, (float*)dx,
-                           dx ? border : (float*)nullptr, h, w, rows_per_block, (float)pad_value1, use_bias1,
-                           (float)alpha1);
-    };
     const bool sig = act2 == UOCR_ACT_SIGMOID;
-    if (dx && sig) launch(conv_pair_bwd_kernel<true, true>);
-    else if (dx) launch(conv_pair_bwd_kernel<true, false>);
-    else if (sig) launch(conv_pair_bwd_kernel<false, true>);
-    else launch(conv_pair_bwd_kernel<false, false>);
-    UOCR_LAUNCH_CHECK(ctx);
-    if (dx) {
-        const size_t edge_px = (size_t)n * tiles_y * strips * (2 * RW + 2 * (RH - 2));
-        hipLaunchKernelGGL(conv_pair_dx_border, dim3(uocr_blocks_for(edge_px, 256, UOCR_MAX_GRID)), dim3(256), 0,
-                           ctx->stream, (const float*)border, (float*)dx, n, h, w, tiles_y, strips);
+    UOCR_DISPATCH_TA(ctx, dtype, {
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, grid, dim3(256), 0, ctx->stream, (const TA*)x, (const TA*)y, (const TA*)dy,
+                               (const float*)w1, (const float*)b1, (const float*)w2, partial, (TA*)dx,
+                               dx ? border : (float*)nullptr, h, w, rows_per_block, (float)pad_value1, use_bias1,
+                               (float)alpha1);
+        };
+        if (dx && sig) launch(conv_pair_bwd_kernel<true, true, TA>);
+        else if (dx) launch(conv_pair_bwd_kernel<true, false, TA>);
+        else if (sig) launch(conv_pair_bwd_kernel<false, true, TA>);
+        else launch(conv_pair_bwd_kernel<false, false, TA>);
         UOCR_LAUNCH_CHECK(ctx);
-    }
+        if (dx) {
+            const size_t edge_px = (size_t)n * tiles_y * strips * (2 * RW + 2 * (RH - 2));
+            hipLaunchKernelGGL((conv_pair_dx_border<TA>), dim3(uocr_blocks_for(edge_px, 256, UOCR_MAX_GRID)), dim3(256),
+                               0, ctx->stream, (const float*)border, (TA*)dx, n, h, w, tiles_y, strips);
+            UOCR_LAUNCH_CHECK(ctx);
+        }
+    });
     hipLaunchKernelGGL(conv_pair_bwd_finish, dim3(NA, 4), dim3(256), 0, ctx->stream, (const float*)partial,
-                       (float*)dw1, (float*)db1, (float*)dw2, (float*)db2, nblocks, use_bias1, use_bias2, accumulate);
+                       (float*)dw1, (float*)db1, (float*)dw2, (float*)db2, nblocks, use_bias1, use_bias2, accumulate,
+                       (float)uocr_grad_unscale(dtype));
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
 }

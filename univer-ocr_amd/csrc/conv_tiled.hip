@@ -29,35 +29,35 @@ __device__ __forceinline__ float act_apply(float v, int act, float alpha) {
     }
 }
 
-template <int C>
-__device__ __forceinline__ void store_c(float* p, const float (&v)[C]) {
-    if constexpr (C == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    else if constexpr (C == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
-    else p[0] = v[0];
+template <int C, typename TA>
+__device__ __forceinline__ void store_c(TA* p, const float (&v)[C]) {
+    if constexpr (C == 4) st4(p, make_float4(v[0], v[1], v[2], v[3]));
+    else if constexpr (C == 2) st2(p, make_float2(v[0], v[1]));
+    else st1(p, v[0]);
 }
 
 // stage rows [y0, y0+ROWS) x cols [x0, x0+COLS) of a C-channel image (C = 2 or 4) into LDS as float4
 // pixels (C = 2: .z/.w unused); outside the image -> fill
-template <int C, int ROWS, int COLS>
-__device__ __forceinline__ void stage_tile(float4* __restrict__ tile, const float* __restrict__ img, int h, int w,
+template <int C, int ROWS, int COLS, typename TA>
+__device__ __forceinline__ void stage_tile(float4* __restrict__ tile, const TA* __restrict__ img, int h, int w,
                                            int y0, int x0, float fill, int tid) {
     for (int i = tid; i < ROWS * COLS; i += TH * TW) {
         const int r = i / COLS, c = i - r * COLS;
         const int y = y0 + r, x = x0 + c;
         float4 v = make_float4(fill, fill, fill, fill);
         if (y >= 0 && y < h && x >= 0 && x < w) {
-            const float* p = img + ((size_t)y * w + x) * C;
-            if constexpr (C == 4) v = *reinterpret_cast<const float4*>(p);
-            else { const float2 t = *reinterpret_cast<const float2*>(p); v.x = t.x; v.y = t.y; }
+            const TA* p = img + ((size_t)y * w + x) * C;
+            if constexpr (C == 4) v = ld4(p);
+            else { const float2 t = ld2(p); v.x = t.x; v.y = t.y; }
         }
         tile[i] = v;
     }
 }
 
 // y[p,o] = sum_{ky,kx,c} x[p + (ky,kx) - pad, c] w[ky,kx,c,o] (+ b, activation)
-template <int KH, int KW, int CIN, int COUT>
-__global__ __launch_bounds__(256) void conv_tiled_kernel(const float* __restrict__ src, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, float* __restrict__ dst,
+template <int KH, int KW, int CIN, int COUT, typename TA>
+__global__ __launch_bounds__(256) void conv_tiled_kernel(const TA* __restrict__ src, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, TA* __restrict__ dst,
                                                          TileDims d, float pad, int use_bias, int act, float alpha) {
     constexpr int SRC = CIN, DST = COUT;
     constexpr int ROWS = TH + KH - 1, COLS = TW + KW - 1;
@@ -113,18 +113,19 @@ constexpr int WTH = 16, WTW = 64, WH = WTH + 4, WW = WTW + 4;
 __device__ __forceinline__ int swz(int row, int c) { return row * WW + (c & 3) * (WW / 4) + (c >> 2); }
 }  // namespace wide
 
-__global__ __launch_bounds__(256) void conv_fwd_t542(const float* __restrict__ src, const float* __restrict__ w,
-                                                     const float* __restrict__ bias, float* __restrict__ dst, int h,
+template <typename TA>
+__global__ __launch_bounds__(256) void conv_fwd_t542(const TA* __restrict__ src, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, TA* __restrict__ dst, int h,
                                                      int wd, float pad, int use_bias, int act, float alpha) {
     using namespace wide;
     __shared__ float4 xs[WH * WW];
     const int tid = threadIdx.x, cg = tid & 15, r = tid >> 4;
     const int x0 = blockIdx.x * WTW, y0 = blockIdx.y * WTH, b = blockIdx.z;
-    const float4* xb = reinterpret_cast<const float4*>(src) + (size_t)b * h * wd;
+    const TA* xb = src + (size_t)b * h * wd * 4;
     for (int e = tid; e < WH * WW; e += 256) {
         const int rr = e / WW, c = e - rr * WW;
         const int gy = y0 - 2 + rr, gx = x0 - 2 + c;
-        float4 v = xb[(size_t)min(max(gy, 0), h - 1) * wd + min(max(gx, 0), wd - 1)];
+        float4 v = ld4(xb + ((size_t)min(max(gy, 0), h - 1) * wd + min(max(gx, 0), wd - 1)) * 4);
         if (gy < 0 || gy >= h || gx < 0 || gx >= wd) v = make_float4(pad, pad, pad, pad);
         xs[swz(rr, c)] = v;
     }
@@ -161,17 +162,14 @@ __global__ __launch_bounds__(256) void conv_fwd_t542(const float* __restrict__ s
         out[2 * p] = act_apply(acc[p][0] + b0, act, alpha);
         out[2 * p + 1] = act_apply(acc[p][1] + b1, act, alpha);
     }
-    float* o = dst + (((size_t)b * h + oy) * wd + ox) * 2;
-    if (ox + 3 < wd && (wd & 1) == 0) {                   // 32 contiguous bytes (row starts are 8-byte aligned
-        *reinterpret_cast<float4*>(o) = make_float4(out[0], out[1], out[2], out[3]);      // multiples of 16: ox % 4 == 0)
-        *reinterpret_cast<float4*>(o + 4) = make_float4(out[4], out[5], out[6], out[7]);
+    TA* o = dst + (((size_t)b * h + oy) * wd + ox) * 2;
+    if (ox + 3 < wd && (wd & 1) == 0) {                   // 8 contiguous elements (row starts are aligned for 4-element
+        st4(o, make_float4(out[0], out[1], out[2], out[3]));                              // accesses: ox % 4 == 0, wd even)
+        st4(o + 4, make_float4(out[4], out[5], out[6], out[7]));
     } else {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-            if (ox + p < wd) {
-                o[2 * p] = out[2 * p];
-                o[2 * p + 1] = out[2 * p + 1];
-            }
+            if (ox + p < wd) st2(o + 2 * p, make_float2(out[2 * p], out[2 * p + 1]));
     }
 }
 
@@ -186,29 +184,30 @@ bool shape_ok(const ConvDims& d) {
 }  // namespace
 
 bool uocr_conv_tiled_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d) {
-    if (dtype != UOCR_F32 || !ctx->opt_fast || ctx->opt_tiled == 0) return false;
+    const int base = UOCR_DTYPE_BASE(dtype);
+    if ((base != UOCR_F32 && base != UOCR_F16) || !ctx->opt_fast || ctx->opt_tiled == 0) return false;
     return shape_ok<4>(d) || shape_ok<2>(d);
 }
 
-int uocr_conv_fwd_tiled(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
-                        double pad_value, int use_bias, int act, double act_alpha) {
+int uocr_conv_fwd_tiled(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* b, void* y,
+                        const ConvDims& d, double pad_value, int use_bias, int act, double act_alpha) {
     const TileDims td{d.n, d.h, d.w, d.ph, d.pw};
     const dim3 grid((d.w + TW - 1) / TW, (d.h + TH - 1) / TH, d.n), block(256);
-    if (d.cout == 2 && d.ph == 2 && d.pw == 2 && ctx->opt_tiled != 2) {
-        const dim3 wgrid((d.w + wide::WTW - 1) / wide::WTW, (d.h + wide::WTH - 1) / wide::WTH, d.n);
-        hipLaunchKernelGGL(conv_fwd_t542, wgrid, block, 0, ctx->stream, (const float*)x, (const float*)w, (const float*)b,
-                           (float*)y, d.h, d.w, (float)pad_value, use_bias, act, (float)act_alpha);
-        UOCR_LAUNCH_CHECK(ctx);
-        return UOCR_OK;
-    }
-    if (d.cout == 4)
-        hipLaunchKernelGGL((conv_tiled_kernel<5, 5, 4, 4>), grid, block, 0, ctx->stream, (const float*)x,
-                           (const float*)w, (const float*)b, (float*)y, td, (float)pad_value, use_bias, act,
-                           (float)act_alpha);
-    else
-        hipLaunchKernelGGL((conv_tiled_kernel<5, 5, 4, 2>), grid, block, 0, ctx->stream, (const float*)x,
-                           (const float*)w, (const float*)b, (float*)y, td, (float)pad_value, use_bias, act,
-                           (float)act_alpha);
+    UOCR_DISPATCH_TA(ctx, dtype, {
+        if (d.cout == 2 && d.ph == 2 && d.pw == 2 && ctx->opt_tiled != 2) {
+            const dim3 wgrid((d.w + wide::WTW - 1) / wide::WTW, (d.h + wide::WTH - 1) / wide::WTH, d.n);
+            hipLaunchKernelGGL((conv_fwd_t542<TA>), wgrid, block, 0, ctx->stream, (const TA*)x, (const float*)w,
+                               (const float*)b, (TA*)y, d.h, d.w, (float)pad_value, use_bias, act, (float)act_alpha);
+        } else if (d.cout == 4) {
+            hipLaunchKernelGGL((conv_tiled_kernel<5, 5, 4, 4, TA>), grid, block, 0, ctx->stream, (const TA*)x,
+                               (const float*)w, (const float*)b, (TA*)y, td, (float)pad_value, use_bias, act,
+                               (float)act_alpha);
+        } else {
+            hipLaunchKernelGGL((conv_tiled_kernel<5, 5, 4, 2, TA>), grid, block, 0, ctx->stream, (const TA*)x,
+                               (const float*)w, (const float*)b, (TA*)y, td, (float)pad_value, use_bias, act,
+                               (float)act_alpha);
+        }
+    });
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
 }

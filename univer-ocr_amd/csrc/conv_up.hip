@@ -73,13 +73,14 @@ __global__ __launch_bounds__(256) void upconv_weff_kernel(const float* __restric
 }
 
 // xl tile (halo 1) of the region at low-res origin (ry, rx), channel-planar in LDS; zero outside the image
-__device__ __forceinline__ void stage_planar(float* __restrict__ xs, const float* __restrict__ xb, int ry, int rx,
+template <typename TA>
+__device__ __forceinline__ void stage_planar(float* __restrict__ xs, const TA* __restrict__ xb, int ry, int rx,
                                              int hl, int wl, int tid) {
     for (int i = tid; i < XH * XW; i += 256) {
         const int r = i / XW, c = i - r * XW;
         const int gy = ry - 1 + r, gx = rx - 1 + c;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy >= 0 && gy < hl && gx >= 0 && gx < wl) v = *reinterpret_cast<const float4*>(xb + ((size_t)gy * wl + gx) * CH);
+        if (gy >= 0 && gy < hl && gx >= 0 && gx < wl) v = ld4(xb + ((size_t)gy * wl + gx) * CH);
         xs[i] = v.x;
         xs[XPLANE + i] = v.y;
         xs[2 * XPLANE + i] = v.z;
@@ -89,17 +90,18 @@ __device__ __forceinline__ void stage_planar(float* __restrict__ xs, const float
 
 // forward.  Block = 16 x 32 low-res positions per tile iteration over a band of rows; wave w owns rows
 // 4w..4w+3 (8 groups of 16 consecutive positions).
-__global__ __launch_bounds__(256) void upconv_fwd_kernel(const float* __restrict__ xl, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, float* __restrict__ y,
+template <typename TA>
+__global__ __launch_bounds__(256) void upconv_fwd_kernel(const TA* __restrict__ xl, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, TA* __restrict__ y,
                                                          int hl, int wl, int rows_per_block, int use_bias, int act,
                                                          float alpha) {
     __shared__ float xs[CH * XPLANE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
     const int rx = blockIdx.x * RW;
     const int row_begin = blockIdx.y * rows_per_block, row_end = min(hl, row_begin + rows_per_block);
-    const float* xb = xl + (size_t)blockIdx.z * hl * wl * CH;
+    const TA* xb = xl + (size_t)blockIdx.z * hl * wl * CH;
     const int W = 2 * wl;
-    float* yb = y + (size_t)blockIdx.z * (2 * hl) * W * CH;
+    TA* yb = y + (size_t)blockIdx.z * (2 * hl) * W * CH;
     // A = Weff^T: lane (m = (phase,o) = n, k = channel kq), one register per tap, summed here from the 25
     // taps of w (each belongs to exactly one source offset for this lane's phase)
     float wa[9];
@@ -135,14 +137,15 @@ __global__ __launch_bounds__(256) void upconv_fwd_kernel(const float* __restrict
                 out.y = act_apply(acc[1], act, alpha);
                 out.z = act_apply(acc[2], act, alpha);
                 out.w = act_apply(acc[3], act, alpha);
-                *reinterpret_cast<float4*>(yb + ((size_t)(2 * py + (kq >> 1)) * W + 2 * pxl + (kq & 1)) * CH) = out;
+                st4(yb + ((size_t)(2 * py + (kq >> 1)) * W + 2 * pxl + (kq & 1)) * CH, out);
             }
         }
     }
 }
 
 // dw: partial[blk][48][16] (rows 36..47 unused) + partial_db[blk][4]
-__global__ __launch_bounds__(256) void upconv_wgrad_kernel(const float* __restrict__ xl, const float* __restrict__ dy,
+template <typename TA>
+__global__ __launch_bounds__(256) void upconv_wgrad_kernel(const TA* __restrict__ xl, const TA* __restrict__ dy,
                                                            float* __restrict__ partial, int hl, int wl,
                                                            int rows_per_block) {
     __shared__ float xs[CH * XPLANE];
@@ -151,9 +154,9 @@ __global__ __launch_bounds__(256) void upconv_wgrad_kernel(const float* __restri
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
     const int rx = blockIdx.x * RW;
     const int row_begin = blockIdx.y * rows_per_block, row_end = min(hl, row_begin + rows_per_block);
-    const float* xb = xl + (size_t)blockIdx.z * hl * wl * CH;
+    const TA* xb = xl + (size_t)blockIdx.z * hl * wl * CH;
     const int W = 2 * wl;
-    const float* gb = dy + (size_t)blockIdx.z * (2 * hl) * W * CH;
+    const TA* gb = dy + (size_t)blockIdx.z * (2 * hl) * W * CH;
     // A = Xcol^T: lane (m = K index 16j + n -> tap K/4, channel K%4; k = position 4i + kq)
     int aoff[3];
     bool aok[3];
@@ -178,12 +181,12 @@ __global__ __launch_bounds__(256) void upconv_wgrad_kernel(const float* __restri
             const int py = ry + r;
             const bool row_ok = py < row_end;
             const float* xr = xs + r * XW + c0;
-            const float* gr = gb + ((size_t)(2 * min(py, hl - 1)) * W + 2 * rx) * CH + boff;
+            const TA* gr = gb + ((size_t)(2 * min(py, hl - 1)) * W + 2 * rx) * CH + boff;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int pl = c0 + 4 * i + kq;          // position of this lane's K slot
                 const bool ok = row_ok && rx + pl < wl;
-                float g = gr[(size_t)2 * min(pl, wl - 1 - rx) * CH];
+                float g = ld1(gr + (size_t)2 * min(pl, wl - 1 - rx) * CH);
                 g = ok ? g : 0.f;
                 dbacc += g;
 #pragma unroll
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(256) void upconv_wgrad_kernel(const float* __restri
 // blocks 400..403: db[o]
 __global__ __launch_bounds__(256) void upconv_wgrad_finish(const float* __restrict__ partial, float* __restrict__ dw,
                                                            float* __restrict__ db, int nblocks, int use_bias,
-                                                           int accumulate) {
+                                                           int accumulate, float unscale) {
     __shared__ double smem[16];
     const int e = blockIdx.x;
     double s = 0.0;
@@ -251,26 +254,28 @@ __global__ __launch_bounds__(256) void upconv_wgrad_finish(const float* __restri
     s = block_reduce_sum(s, smem);
     if (threadIdx.x != 0) return;
     if (e >= 400 && !use_bias) s = 0.0;
+    s *= (double)unscale;                                // UOCR_F16_SCALED(k): 2^-k, else 1
     *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
 
 // dx on the vector ALU.  Block = 16 x 32 low-res positions, 2 per thread (rows r and r + 8); dy tile of the
 // (16 + 2) x (32 + 2) source blocks = 36 x 68 high-res pixels in LDS.
 constexpr int GH = 2 * (RH + 2), GW = 2 * (RW + 2);
-__global__ __launch_bounds__(256) void upconv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ weff,
-                                                           float* __restrict__ dxl, int hl, int wl,
-                                                           const float* __restrict__ mask_y, int mask_act,
+template <typename TA>
+__global__ __launch_bounds__(256) void upconv_dgrad_kernel(const TA* __restrict__ dy, const float* __restrict__ weff,
+                                                           TA* __restrict__ dxl, int hl, int wl,
+                                                           const TA* __restrict__ mask_y, int mask_act,
                                                            float mask_alpha) {
     __shared__ float4 gs[GH * GW];
     const int tid = threadIdx.x;
     const int rx = blockIdx.x * RW, ry = blockIdx.y * RH;
     const int H = 2 * hl, W = 2 * wl;
-    const float* gb = dy + (size_t)blockIdx.z * H * W * CH;
+    const TA* gb = dy + (size_t)blockIdx.z * H * W * CH;
     for (int i = tid; i < GH * GW; i += 256) {
         const int r = i / GW, c = i - r * GW;
         const int gy = 2 * (ry - 1) + r, gx = 2 * (rx - 1) + c;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const float4*>(gb + ((size_t)gy * W + gx) * CH);
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = ld4(gb + ((size_t)gy * W + gx) * CH);
         gs[i] = v;
     }
     __syncthreads();
@@ -306,13 +311,13 @@ __global__ __launch_bounds__(256) void upconv_dgrad_kernel(const float* __restri
         const size_t off = (((size_t)blockIdx.z * hl + qy) * wl + qx) * CH;
         float4 out = make_float4(acc[p][0], acc[p][1], acc[p][2], acc[p][3]);
         if (mask_act != UOCR_ACT_NONE) {
-            const float4 yv = *reinterpret_cast<const float4*>(mask_y + off);
+            const float4 yv = ld4(mask_y + off);
             out.x *= act_grad_from_output<float>(yv.x, mask_act, mask_alpha);
             out.y *= act_grad_from_output<float>(yv.y, mask_act, mask_alpha);
             out.z *= act_grad_from_output<float>(yv.z, mask_act, mask_alpha);
             out.w *= act_grad_from_output<float>(yv.w, mask_act, mask_alpha);
         }
-        *reinterpret_cast<float4*>(dxl + off) = out;
+        st4(dxl + off, out);
     }
 }
 
@@ -337,17 +342,18 @@ __device__ __forceinline__ void weff1_build(float (&we)[36], const float* __rest
 }
 
 // block = 16 x 32 low-res positions, 2 per thread (rows r0 and r0 + 8)
-__global__ __launch_bounds__(256) void up1_fwd_kernel(const float* __restrict__ xl, const float* __restrict__ w,
-                                                      const float* __restrict__ bias, float* __restrict__ y, int hl,
+template <typename TA>
+__global__ __launch_bounds__(256) void up1_fwd_kernel(const TA* __restrict__ xl, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, TA* __restrict__ y, int hl,
                                                       int wl, int use_bias, int act, float alpha) {
     __shared__ float xs[XH * XW];
     const int tid = threadIdx.x;
     const int rx = blockIdx.x * RW, ry = blockIdx.y * RH;
-    const float* xb = xl + (size_t)blockIdx.z * hl * wl;
+    const TA* xb = xl + (size_t)blockIdx.z * hl * wl;
     for (int i = tid; i < XH * XW; i += 256) {
         const int r = i / XW, c = i - r * XW;
         const int gy = ry - 1 + r, gx = rx - 1 + c;
-        xs[i] = (gy >= 0 && gy < hl && gx >= 0 && gx < wl) ? xb[(size_t)gy * wl + gx] : 0.f;
+        xs[i] = (gy >= 0 && gy < hl && gx >= 0 && gx < wl) ? ld1(xb + (size_t)gy * wl + gx) : 0.f;
     }
     float we[36];
     weff1_build(we, w);
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(256) void up1_fwd_kernel(const float* __restrict__ 
     __syncthreads();
     const int c = tid & 31, r0 = tid >> 5;
     const int W = 2 * wl;
-    float* yb = y + (size_t)blockIdx.z * (2 * hl) * W;
+    TA* yb = y + (size_t)blockIdx.z * (2 * hl) * W;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int r = r0 + 8 * p, py = ry + r, pxl = rx + c;
@@ -367,26 +373,27 @@ __global__ __launch_bounds__(256) void up1_fwd_kernel(const float* __restrict__ 
             for (int phase = 0; phase < 4; ++phase) acc[phase] += xv * we[m * 4 + phase];
         }
         if (py < hl && pxl < wl) {
-            float* o = yb + (size_t)(2 * py) * W + 2 * pxl;
-            *reinterpret_cast<float2*>(o) = make_float2(act_apply(acc[0], act, alpha), act_apply(acc[1], act, alpha));
-            *reinterpret_cast<float2*>(o + W) = make_float2(act_apply(acc[2], act, alpha), act_apply(acc[3], act, alpha));
+            TA* o = yb + (size_t)(2 * py) * W + 2 * pxl;
+            st2(o, make_float2(act_apply(acc[0], act, alpha), act_apply(acc[1], act, alpha)));
+            st2(o + W, make_float2(act_apply(acc[2], act, alpha), act_apply(acc[3], act, alpha)));
         }
     }
 }
 
-__global__ __launch_bounds__(256) void up1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                        float* __restrict__ dxl, int hl, int wl,
-                                                        const float* __restrict__ mask_y, int mask_act,
+template <typename TA>
+__global__ __launch_bounds__(256) void up1_dgrad_kernel(const TA* __restrict__ dy, const float* __restrict__ w,
+                                                        TA* __restrict__ dxl, int hl, int wl,
+                                                        const TA* __restrict__ mask_y, int mask_act,
                                                         float mask_alpha) {
     __shared__ float gs[GH * GW];
     const int tid = threadIdx.x;
     const int rx = blockIdx.x * RW, ry = blockIdx.y * RH;
     const int H = 2 * hl, W = 2 * wl;
-    const float* gb = dy + (size_t)blockIdx.z * H * W;
+    const TA* gb = dy + (size_t)blockIdx.z * H * W;
     for (int i = tid; i < GH * GW; i += 256) {
         const int r = i / GW, c = i - r * GW;
         const int gy = 2 * (ry - 1) + r, gx = 2 * (rx - 1) + c;
-        gs[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gb[(size_t)gy * W + gx] : 0.f;
+        gs[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? ld1(gb + (size_t)gy * W + gx) : 0.f;
     }
     float we[36];
     weff1_build(we, w);
@@ -405,13 +412,14 @@ __global__ __launch_bounds__(256) void up1_dgrad_kernel(const float* __restrict_
         const int qy = ry + r, qx = rx + c;
         if (qy >= hl || qx >= wl) continue;
         const size_t off = ((size_t)blockIdx.z * hl + qy) * wl + qx;
-        if (mask_act != UOCR_ACT_NONE) acc *= act_grad_from_output<float>(mask_y[off], mask_act, mask_alpha);
-        dxl[off] = acc;
+        if (mask_act != UOCR_ACT_NONE) acc *= act_grad_from_output<float>(ld1(mask_y + off), mask_act, mask_alpha);
+        st1(dxl + off, acc);
     }
 }
 
 // partial[blk][37]: dWeff[m*4 + phase] and db
-__global__ __launch_bounds__(256) void up1_wgrad_kernel(const float* __restrict__ xl, const float* __restrict__ dy,
+template <typename TA>
+__global__ __launch_bounds__(256) void up1_wgrad_kernel(const TA* __restrict__ xl, const TA* __restrict__ dy,
                                                         float* __restrict__ partial, int hl, int wl,
                                                         int rows_per_block) {
     __shared__ float xs[XH * XW];
@@ -419,9 +427,9 @@ __global__ __launch_bounds__(256) void up1_wgrad_kernel(const float* __restrict_
     const int tid = threadIdx.x;
     const int rx = blockIdx.x * RW;
     const int row_begin = blockIdx.y * rows_per_block, row_end = min(hl, row_begin + rows_per_block);
-    const float* xb = xl + (size_t)blockIdx.z * hl * wl;
+    const TA* xb = xl + (size_t)blockIdx.z * hl * wl;
     const int W = 2 * wl;
-    const float* gb = dy + (size_t)blockIdx.z * (2 * hl) * W;
+    const TA* gb = dy + (size_t)blockIdx.z * (2 * hl) * W;
     const int c = tid & 31, r0 = tid >> 5;
     float acc[36], dbacc = 0.f;
 #pragma unroll
@@ -431,15 +439,15 @@ __global__ __launch_bounds__(256) void up1_wgrad_kernel(const float* __restrict_
         for (int i = tid; i < XH * XW; i += 256) {
             const int r = i / XW, cc = i - r * XW;
             const int gy = ry - 1 + r, gx = rx - 1 + cc;
-            xs[i] = (gy >= 0 && gy < hl && gx >= 0 && gx < wl) ? xb[(size_t)gy * wl + gx] : 0.f;
+            xs[i] = (gy >= 0 && gy < hl && gx >= 0 && gx < wl) ? ld1(xb + (size_t)gy * wl + gx) : 0.f;
         }
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int r = r0 + 8 * p, py = ry + r, pxl = rx + c;
             if (py >= row_end || pxl >= wl) continue;
-            const float* g0 = gb + (size_t)(2 * py) * W + 2 * pxl;
-            const float2 ga = *reinterpret_cast<const float2*>(g0), gbv = *reinterpret_cast<const float2*>(g0 + W);
+            const TA* g0 = gb + (size_t)(2 * py) * W + 2 * pxl;
+            const float2 ga = ld2(g0), gbv = ld2(g0 + W);
             const float g[4] = {ga.x, ga.y, gbv.x, gbv.y};
             dbacc += (g[0] + g[1]) + (g[2] + g[3]);
 #pragma unroll
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(256) void up1_wgrad_kernel(const float* __restrict_
 // block e < 25: dw[ky][kx] (+)= sum over blocks and phases of dWeff[m(phase, k)][phase]; block 25: db
 __global__ __launch_bounds__(256) void up1_wgrad_finish(const float* __restrict__ partial, float* __restrict__ dw,
                                                         float* __restrict__ db, int nblocks, int use_bias,
-                                                        int accumulate) {
+                                                        int accumulate, float unscale) {
     __shared__ double smem[16];
     const int e = blockIdx.x;
     double s = 0.0;
@@ -495,6 +503,7 @@ __global__ __launch_bounds__(256) void up1_wgrad_finish(const float* __restrict_
     if (threadIdx.x != 0) return;
     float* dst = e < 25 ? dw + e : db;
     if (e == 25 && !use_bias) s = 0.0;
+    s *= (double)unscale;
     *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
 
@@ -505,7 +514,8 @@ int up_rows_per_block(int strips, int hl, int n, unsigned max_blocks = 2048u) {
 }
 
 int check_up(uocr_ctx* ctx, int dtype, int n, int hl, int wl, int cin, int cout, int kh, int kw, int ph, int pw) {
-    if (dtype != UOCR_F32) UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "upconv2x: float32 only");
+    if (UOCR_DTYPE_BASE(dtype) != UOCR_F32 && UOCR_DTYPE_BASE(dtype) != UOCR_F16)
+        UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "upconv2x: float32 / float16 only");
     if (!((cin == CH && cout == CH) || (cin == 1 && cout == 1)) || kh != 5 || kw != 5 || ph != 2 || pw != 2)
         UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED,
                   "upconv2x: 5x5 / padding 2 / 4 -> 4 or 1 -> 1 channels only (got %dx%d pad %d,%d %d -> %d)", kh, kw, ph,
@@ -523,17 +533,17 @@ extern "C" int uocr_upconv2x_fwd(uocr_ctx* ctx, int dtype, const void* x_low, co
     UOCR_REQUIRE(ctx, x_low && w && b && y);
     int rc = check_up(ctx, dtype, n, hl, wl, cin, cout, kh, kw, ph, pw);
     if (rc != UOCR_OK) return rc;
-    if (cin == 1) {
-        hipLaunchKernelGGL(up1_fwd_kernel, dim3((wl + RW - 1) / RW, (hl + RH - 1) / RH, n), dim3(256), 0, ctx->stream,
-                           (const float*)x_low, (const float*)w, (const float*)b, (float*)y, hl, wl, use_bias, act,
-                           (float)act_alpha);
-        UOCR_LAUNCH_CHECK(ctx);
-        return UOCR_OK;
-    }
     const int strips = (wl + RW - 1) / RW, rows = up_rows_per_block(strips, hl, n);
-    hipLaunchKernelGGL(upconv_fwd_kernel, dim3(strips, (hl + rows - 1) / rows, n), dim3(256), 0, ctx->stream,
-                       (const float*)x_low, (const float*)w, (const float*)b, (float*)y, hl, wl, rows, use_bias,
-                       act, (float)act_alpha);
+    UOCR_DISPATCH_TA(ctx, dtype, {
+        if (cin == 1)
+            hipLaunchKernelGGL((up1_fwd_kernel<TA>), dim3((wl + RW - 1) / RW, (hl + RH - 1) / RH, n), dim3(256), 0,
+                               ctx->stream, (const TA*)x_low, (const float*)w, (const float*)b, (TA*)y, hl, wl, use_bias,
+                               act, (float)act_alpha);
+        else
+            hipLaunchKernelGGL((upconv_fwd_kernel<TA>), dim3(strips, (hl + rows - 1) / rows, n), dim3(256), 0,
+                               ctx->stream, (const TA*)x_low, (const float*)w, (const float*)b, (TA*)y, hl, wl, rows,
+                               use_bias, act, (float)act_alpha);
+    });
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
 }
@@ -546,20 +556,22 @@ extern "C" int uocr_upconv2x_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, 
     UOCR_REQUIRE(ctx, act == UOCR_ACT_NONE || x_act != nullptr);
     int rc = check_up(ctx, dtype, n, hl, wl, cin, cout, kh, kw, ph, pw);
     if (rc != UOCR_OK) return rc;
-    if (cin == 1) {
-        hipLaunchKernelGGL(up1_dgrad_kernel, dim3((wl + RW - 1) / RW, (hl + RH - 1) / RH, n), dim3(256), 0, ctx->stream,
-                           (const float*)dy, (const float*)w, (float*)dx_low, hl, wl, (const float*)x_act, act,
-                           (float)act_alpha);
-        UOCR_LAUNCH_CHECK(ctx);
-        return UOCR_OK;
+    float* weff = nullptr;
+    if (cin != 1) {
+        rc = uocr_need_workspace(ctx, NWEFF * sizeof(float));
+        if (rc != UOCR_OK) return rc;
+        weff = (float*)ctx->workspace;
+        hipLaunchKernelGGL(upconv_weff_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)w, weff);
     }
-    rc = uocr_need_workspace(ctx, NWEFF * sizeof(float));
-    if (rc != UOCR_OK) return rc;
-    float* weff = (float*)ctx->workspace;
-    hipLaunchKernelGGL(upconv_weff_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)w, weff);
-    hipLaunchKernelGGL(upconv_dgrad_kernel, dim3((wl + RW - 1) / RW, (hl + RH - 1) / RH, n), dim3(256), 0, ctx->stream,
-                       (const float*)dy, (const float*)weff, (float*)dx_low, hl, wl, (const float*)x_act, act,
-                       (float)act_alpha);
+    const dim3 grid((wl + RW - 1) / RW, (hl + RH - 1) / RH, n);
+    UOCR_DISPATCH_TA(ctx, dtype, {
+        if (cin == 1)
+            hipLaunchKernelGGL((up1_dgrad_kernel<TA>), grid, dim3(256), 0, ctx->stream, (const TA*)dy, (const float*)w,
+                               (TA*)dx_low, hl, wl, (const TA*)x_act, act, (float)act_alpha);
+        else
+            hipLaunchKernelGGL((upconv_dgrad_kernel<TA>), grid, dim3(256), 0, ctx->stream, (const TA*)dy,
+                               (const float*)weff, (TA*)dx_low, hl, wl, (const TA*)x_act, act, (float)act_alpha);
+    });
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
 }
@@ -577,20 +589,22 @@ extern "C" int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_
     rc = uocr_need_workspace(ctx, (size_t)nblocks * (36 * 16 + 4) * sizeof(float));
     if (rc != UOCR_OK) return rc;
     float* partial = (float*)ctx->workspace;
-    if (cin == 1) {
-        hipLaunchKernelGGL(up1_wgrad_kernel, dim3(strips, bands, n), dim3(256), 0, ctx->stream, (const float*)x_low,
-                           (const float*)dy, partial, hl, wl, rows);
-        UOCR_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(up1_wgrad_finish, dim3(26), dim3(256), 0, ctx->stream, (const float*)partial, (float*)dw,
-                           (float*)db, nblocks, use_bias, accumulate);
-        UOCR_LAUNCH_CHECK(ctx);
-        return UOCR_OK;
-    }
-    hipLaunchKernelGGL(upconv_wgrad_kernel, dim3(strips, bands, n), dim3(256), 0, ctx->stream, (const float*)x_low,
-                       (const float*)dy, partial, hl, wl, rows);
+    const float unscale = (float)uocr_grad_unscale(dtype);
+    UOCR_DISPATCH_TA(ctx, dtype, {
+        if (cin == 1)
+            hipLaunchKernelGGL((up1_wgrad_kernel<TA>), dim3(strips, bands, n), dim3(256), 0, ctx->stream,
+                               (const TA*)x_low, (const TA*)dy, partial, hl, wl, rows);
+        else
+            hipLaunchKernelGGL((upconv_wgrad_kernel<TA>), dim3(strips, bands, n), dim3(256), 0, ctx->stream,
+                               (const TA*)x_low, (const TA*)dy, partial, hl, wl, rows);
+    });
     UOCR_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(upconv_wgrad_finish, dim3(404), dim3(256), 0, ctx->stream, (const float*)partial, (float*)dw,
-                       (float*)db, nblocks, use_bias, accumulate);
+    if (cin == 1)
+        hipLaunchKernelGGL(up1_wgrad_finish, dim3(26), dim3(256), 0, ctx->stream, (const float*)partial, (float*)dw,
+                           (float*)db, nblocks, use_bias, accumulate, unscale);
+    else
+        hipLaunchKernelGGL(upconv_wgrad_finish, dim3(404), dim3(256), 0, ctx->stream, (const float*)partial, (float*)dw,
+                           (float*)db, nblocks, use_bias, accumulate, unscale);
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
 }

@@ -170,6 +170,13 @@ int uocr_event_record(uocr_ctx* ctx, void* event) {
     return UOCR_OK;
 }
 
+int uocr_stream_wait_event(uocr_ctx* ctx, void* event) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, event != nullptr);
+    UOCR_HIP(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)event, 0));
+    return UOCR_OK;
+}
+
 int uocr_event_elapsed_ms_sync(void* start, void* stop, float* out_ms) {
     if (!start || !stop || !out_ms) return UOCR_ERR_ARG;
     if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return UOCR_ERR_HIP;

@@ -8,6 +8,8 @@
 //   L1 / L2 ........................... regularizations.py:15-26, applied layers.py:147-155
 //   Adam / Momentum / RMSProp ......... optimizers.py:47-98
 //   nan_weights ....................... layers/layers.py:139-140
+#include <type_traits>
+
 #include "uocr_common.h"
 
 namespace {
@@ -25,50 +27,52 @@ constexpr int vec_width() {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- generic N-input map kernel ----------------------------------------------------------
-template <typename T, int NIN>
+// TS = storage type in HBM, T = the type the functor computes in (TS itself, or float for binary16 storage:
+// UOCR_F16 keeps activations as _Float16 and does every operation in float32)
+template <typename TS, int NIN>
 struct MapArgs {
-    T* out;
-    const T* in[NIN];
+    TS* out;
+    const TS* in[NIN];
 };
 
-template <typename T, int NIN, int V, typename Op>
-__global__ __launch_bounds__(256) void map_kernel(MapArgs<T, NIN> a, size_t n, Op op) {
+template <typename TS, typename T, int NIN, int V, typename Op>
+__global__ __launch_bounds__(256) void map_kernel(MapArgs<TS, NIN> a, size_t n, Op op) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t nvec = n / V;
     for (size_t i = tid; i < nvec; i += stride) {
-        Pack<T, V> x[NIN];
+        Pack<TS, V> x[NIN];
 #pragma unroll
-        for (int k = 0; k < NIN; ++k) x[k] = *reinterpret_cast<const Pack<T, V>*>(a.in[k] + i * V);
-        Pack<T, V> r;
+        for (int k = 0; k < NIN; ++k) x[k] = *reinterpret_cast<const Pack<TS, V>*>(a.in[k] + i * V);
+        Pack<TS, V> r;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             T args[NIN];
 #pragma unroll
-            for (int k = 0; k < NIN; ++k) args[k] = x[k].v[j];
-            r.v[j] = op(args);
+            for (int k = 0; k < NIN; ++k) args[k] = (T)x[k].v[j];
+            r.v[j] = (TS)op(args);
         }
-        *reinterpret_cast<Pack<T, V>*>(a.out + i * V) = r;
+        *reinterpret_cast<Pack<TS, V>*>(a.out + i * V) = r;
     }
     for (size_t i = nvec * V + tid; i < n; i += stride) {
         T args[NIN];
 #pragma unroll
-        for (int k = 0; k < NIN; ++k) args[k] = a.in[k][i];
-        a.out[i] = op(args);
+        for (int k = 0; k < NIN; ++k) args[k] = (T)a.in[k][i];
+        a.out[i] = (TS)op(args);
     }
 }
 
-template <typename T, int NIN, typename Op>
-int launch_map(uocr_ctx* ctx, MapArgs<T, NIN> a, size_t n, Op op) {
+template <typename T, typename TS, int NIN, typename Op>
+int launch_map(uocr_ctx* ctx, MapArgs<TS, NIN> a, size_t n, Op op) {
     if (n == 0) return UOCR_OK;
     bool al = aligned16(a.out);
     for (int k = 0; k < NIN; ++k) al = al && aligned16(a.in[k]);
-    constexpr int V = vec_width<T>();
+    constexpr int V = vec_width<TS>();
     const unsigned grid = uocr_blocks_for((n + V - 1) / V, 256, UOCR_MAX_GRID);
     if (al)
-        hipLaunchKernelGGL((map_kernel<T, NIN, V, Op>), dim3(grid), dim3(256), 0, ctx->stream, a, n, op);
+        hipLaunchKernelGGL((map_kernel<TS, T, NIN, V, Op>), dim3(grid), dim3(256), 0, ctx->stream, a, n, op);
     else
-        hipLaunchKernelGGL((map_kernel<T, NIN, 1, Op>), dim3(uocr_blocks_for(n, 256, UOCR_MAX_GRID)),
+        hipLaunchKernelGGL((map_kernel<TS, T, NIN, 1, Op>), dim3(uocr_blocks_for(n, 256, UOCR_MAX_GRID)),
                            dim3(256), 0, ctx->stream, a, n, op);
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
@@ -169,6 +173,40 @@ __global__ __launch_bounds__(256) void convert_kernel(const S* src, D* dst, D sc
     for (size_t i = tid; i < n; i += stride) {
         D v = (D)src[i];
         dst[i] = use_scale ? v * scale : v;
+    }
+}
+
+// dst = (TS)((T)src * scale): the scalar fallback of uocr_u8_to_float
+template <typename S, typename TS, typename T>
+__global__ __launch_bounds__(256) void convert_scaled_kernel(const S* src, TS* dst, T scale, size_t n) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < n; i += stride) dst[i] = (TS)((T)src[i] * scale);
+}
+
+// page images arrive as uint8 (datasets.py:16-19 divides by 255): 16 pixels = one 16-byte load per lane, stored
+// as 16 values of the activation type (float64 computes the product in double like the reference)
+template <typename TS>
+__global__ __launch_bounds__(256) void u8_to_float_vec_kernel(const uint8_t* __restrict__ src, TS* __restrict__ dst,
+                                                              double scale, size_t ngroups) {
+    using T = typename std::conditional<std::is_same<TS, double>::value, double, float>::type;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const T sc = (T)scale;
+    for (size_t g = tid; g < ngroups; g += stride) {
+        const uint4 raw = reinterpret_cast<const uint4*>(src)[g];
+        const uint32_t words[4] = {raw.x, raw.y, raw.z, raw.w};
+        constexpr int PER = 16 / (int)sizeof(TS);                      // elements per 16-byte store
+#pragma unroll
+        for (int q = 0; q < 16 / PER; ++q) {
+            Pack<TS, PER> out;
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+                const int k = q * PER + e;
+                out.v[e] = (TS)((T)((words[k >> 2] >> (8 * (k & 3))) & 0xffu) * sc);
+            }
+            *reinterpret_cast<Pack<TS, PER>*>(dst + g * 16 + q * PER) = out;
+        }
     }
 }
 
@@ -304,7 +342,13 @@ __global__ __launch_bounds__(256) void opt_fused_kernel(T* __restrict__ w, T* __
                                                         T* __restrict__ s2, size_t n, T p0, T p1, T p2, T p3,
                                                         RegRanges rr, double* __restrict__ partial /* [grid][4] */,
                                                         double* __restrict__ loss_out /* used when gridDim.x == 1 */,
-                                                        int zero_grad) {
+                                                        int zero_grad, const double* __restrict__ hyper) {
+    if (hyper) {      // hyper-parameters from device memory: a captured HIP graph follows lr / beta changes
+        p0 = (T)hyper[0];
+        p1 = (T)hyper[1];
+        p2 = (T)hyper[2];
+        p3 = (T)hyper[3];
+    }
     struct alignas(sizeof(T) * VEC) Vec {
         T v[VEC];
     };
@@ -432,12 +476,12 @@ int uocr_act_fwd(uocr_ctx* ctx, int dtype, int kind, double alpha, const void* x
     UOCR_CHECK_CTX(ctx);
     if (!count) return UOCR_OK;
     UOCR_REQUIRE(ctx, x && y);
-    UOCR_DISPATCH(ctx, dtype, {
-        MapArgs<T, 1> a{(T*)y, {(const T*)x}};
+    UOCR_DISPATCH_ACT(ctx, dtype, {
+        MapArgs<TS, 1> a{(TS*)y, {(const TS*)x}};
         switch (kind) {
-            case UOCR_ACT_RELU: return launch_map(ctx, a, count, ReluFwd<T>{});
-            case UOCR_ACT_LEAKY: return launch_map(ctx, a, count, LeakyFwd<T>{(T)alpha});
-            case UOCR_ACT_SIGMOID: return launch_map(ctx, a, count, SigmoidFwd<T>{});
+            case UOCR_ACT_RELU: return launch_map<T>(ctx, a, count, ReluFwd<T>{});
+            case UOCR_ACT_LEAKY: return launch_map<T>(ctx, a, count, LeakyFwd<T>{(T)alpha});
+            case UOCR_ACT_SIGMOID: return launch_map<T>(ctx, a, count, SigmoidFwd<T>{});
             default: UOCR_FAIL(ctx, UOCR_ERR_ARG, "unknown activation kind %d", kind);
         }
     });
@@ -449,12 +493,12 @@ int uocr_act_bwd(uocr_ctx* ctx, int dtype, int kind, double alpha, const void* x
     UOCR_CHECK_CTX(ctx);
     if (!count) return UOCR_OK;
     UOCR_REQUIRE(ctx, x && dy && dx);
-    UOCR_DISPATCH(ctx, dtype, {
-        MapArgs<T, 2> a{(T*)dx, {(const T*)x, (const T*)dy}};
+    UOCR_DISPATCH_ACT(ctx, dtype, {
+        MapArgs<TS, 2> a{(TS*)dx, {(const TS*)x, (const TS*)dy}};
         switch (kind) {
-            case UOCR_ACT_RELU: return launch_map(ctx, a, count, ReluBwd<T>{});
-            case UOCR_ACT_LEAKY: return launch_map(ctx, a, count, LeakyBwd<T>{(T)alpha});
-            case UOCR_ACT_SIGMOID: return launch_map(ctx, a, count, SigmoidBwd<T>{});
+            case UOCR_ACT_RELU: return launch_map<T>(ctx, a, count, ReluBwd<T>{});
+            case UOCR_ACT_LEAKY: return launch_map<T>(ctx, a, count, LeakyBwd<T>{(T)alpha});
+            case UOCR_ACT_SIGMOID: return launch_map<T>(ctx, a, count, SigmoidBwd<T>{});
             default: UOCR_FAIL(ctx, UOCR_ERR_ARG, "unknown activation kind %d", kind);
         }
     });
@@ -467,10 +511,10 @@ int uocr_act_bwd_from_output(uocr_ctx* ctx, int dtype, int kind, double alpha, c
     if (!count) return UOCR_OK;
     UOCR_REQUIRE(ctx, y && dy && dx);
     UOCR_REQUIRE(ctx, kind == UOCR_ACT_SIGMOID || (kind == UOCR_ACT_LEAKY && alpha > 0.0));
-    UOCR_DISPATCH(ctx, dtype, {
-        MapArgs<T, 2> a{(T*)dx, {(const T*)y, (const T*)dy}};
-        if (kind == UOCR_ACT_LEAKY) return launch_map(ctx, a, count, LeakyBwdFromOut<T>{(T)alpha});
-        return launch_map(ctx, a, count, SigmoidBwdFromOut<T>{});
+    UOCR_DISPATCH_ACT(ctx, dtype, {
+        MapArgs<TS, 2> a{(TS*)dx, {(const TS*)y, (const TS*)dy}};
+        if (kind == UOCR_ACT_LEAKY) return launch_map<T>(ctx, a, count, LeakyBwdFromOut<T>{(T)alpha});
+        return launch_map<T>(ctx, a, count, SigmoidBwdFromOut<T>{});
     });
     return UOCR_OK;
 }
@@ -479,9 +523,9 @@ int uocr_add(uocr_ctx* ctx, int dtype, const void* a, const void* b, void* out, 
     UOCR_CHECK_CTX(ctx);
     if (!count) return UOCR_OK;
     UOCR_REQUIRE(ctx, a && b && out);
-    UOCR_DISPATCH(ctx, dtype, {
-        MapArgs<T, 2> m{(T*)out, {(const T*)a, (const T*)b}};
-        return launch_map(ctx, m, count, AddOp<T>{});
+    UOCR_DISPATCH_ACT(ctx, dtype, {
+        MapArgs<TS, 2> m{(TS*)out, {(const TS*)a, (const TS*)b}};
+        return launch_map<T>(ctx, m, count, AddOp<T>{});
     });
     return UOCR_OK;
 }
@@ -490,9 +534,9 @@ int uocr_axpy(uocr_ctx* ctx, int dtype, double alpha, const void* x, void* y, si
     UOCR_CHECK_CTX(ctx);
     if (!count) return UOCR_OK;
     UOCR_REQUIRE(ctx, x && y);
-    UOCR_DISPATCH(ctx, dtype, {
-        MapArgs<T, 2> m{(T*)y, {(const T*)y, (const T*)x}};
-        return launch_map(ctx, m, count, AxpyOp<T>{(T)alpha});
+    UOCR_DISPATCH_ACT(ctx, dtype, {
+        MapArgs<TS, 2> m{(TS*)y, {(const TS*)y, (const TS*)x}};
+        return launch_map<T>(ctx, m, count, AxpyOp<T>{(T)alpha});
     });
     return UOCR_OK;
 }
@@ -501,9 +545,9 @@ int uocr_scale(uocr_ctx* ctx, int dtype, double alpha, void* x, size_t count) {
     UOCR_CHECK_CTX(ctx);
     if (!count) return UOCR_OK;
     UOCR_REQUIRE(ctx, x != nullptr);
-    UOCR_DISPATCH(ctx, dtype, {
-        MapArgs<T, 1> m{(T*)x, {(const T*)x}};
-        return launch_map(ctx, m, count, ScaleOp<T>{(T)alpha});
+    UOCR_DISPATCH_ACT(ctx, dtype, {
+        MapArgs<TS, 1> m{(TS*)x, {(const TS*)x}};
+        return launch_map<T>(ctx, m, count, ScaleOp<T>{(T)alpha});
     });
     return UOCR_OK;
 }
@@ -512,14 +556,14 @@ int uocr_fill(uocr_ctx* ctx, int dtype, void* x, double value, size_t count) {
     UOCR_CHECK_CTX(ctx);
     if (!count) return UOCR_OK;
     UOCR_REQUIRE(ctx, x != nullptr);
-    UOCR_DISPATCH(ctx, dtype, {
-        constexpr int V = vec_width<T>();
+    UOCR_DISPATCH_ACT(ctx, dtype, {
+        constexpr int V = vec_width<TS>();
         if (aligned16(x))
-            hipLaunchKernelGGL((fill_kernel<T, V>), dim3(uocr_blocks_for((count + V - 1) / V, 256, UOCR_MAX_GRID)),
-                               dim3(256), 0, ctx->stream, (T*)x, (T)value, count);
+            hipLaunchKernelGGL((fill_kernel<TS, V>), dim3(uocr_blocks_for((count + V - 1) / V, 256, UOCR_MAX_GRID)),
+                               dim3(256), 0, ctx->stream, (TS*)x, (TS)value, count);
         else
-            hipLaunchKernelGGL((fill_kernel<T, 1>), dim3(uocr_blocks_for(count, 256, UOCR_MAX_GRID)), dim3(256), 0,
-                               ctx->stream, (T*)x, (T)value, count);
+            hipLaunchKernelGGL((fill_kernel<TS, 1>), dim3(uocr_blocks_for(count, 256, UOCR_MAX_GRID)), dim3(256), 0,
+                               ctx->stream, (TS*)x, (TS)value, count);
         UOCR_LAUNCH_CHECK(ctx);
     });
     return UOCR_OK;
@@ -527,6 +571,8 @@ int uocr_fill(uocr_ctx* ctx, int dtype, void* x, double value, size_t count) {
 
 int uocr_convert(uocr_ctx* ctx, int src_dtype, const void* src, int dst_dtype, void* dst, size_t count) {
     UOCR_CHECK_CTX(ctx);
+    src_dtype = UOCR_DTYPE_BASE(src_dtype);
+    dst_dtype = UOCR_DTYPE_BASE(dst_dtype);
     if (!count) return UOCR_OK;
     UOCR_REQUIRE(ctx, src && dst);
     const dim3 grid(uocr_blocks_for(count, 256, UOCR_MAX_GRID)), block(256);
@@ -536,8 +582,20 @@ int uocr_convert(uocr_ctx* ctx, int src_dtype, const void* src, int dst_dtype, v
     else if (src_dtype == UOCR_F64 && dst_dtype == UOCR_F32)
         hipLaunchKernelGGL((convert_kernel<double, float>), grid, block, 0, ctx->stream, (const double*)src,
                            (float*)dst, 1.0f, false, count);
-    else if (src_dtype == dst_dtype && (src_dtype == UOCR_F32 || src_dtype == UOCR_F64))
-        return uocr_d2d(ctx, dst, src, count * (src_dtype == UOCR_F32 ? 4 : 8));
+    else if (src_dtype == UOCR_F32 && dst_dtype == UOCR_F16)
+        hipLaunchKernelGGL((convert_kernel<float, _Float16>), grid, block, 0, ctx->stream, (const float*)src,
+                           (_Float16*)dst, (_Float16)1, false, count);
+    else if (src_dtype == UOCR_F16 && dst_dtype == UOCR_F32)
+        hipLaunchKernelGGL((convert_kernel<_Float16, float>), grid, block, 0, ctx->stream, (const _Float16*)src,
+                           (float*)dst, 1.0f, false, count);
+    else if (src_dtype == UOCR_F64 && dst_dtype == UOCR_F16)
+        hipLaunchKernelGGL((convert_kernel<double, _Float16>), grid, block, 0, ctx->stream, (const double*)src,
+                           (_Float16*)dst, (_Float16)1, false, count);
+    else if (src_dtype == UOCR_F16 && dst_dtype == UOCR_F64)
+        hipLaunchKernelGGL((convert_kernel<_Float16, double>), grid, block, 0, ctx->stream, (const _Float16*)src,
+                           (double*)dst, 1.0, false, count);
+    else if (src_dtype == dst_dtype && (src_dtype == UOCR_F32 || src_dtype == UOCR_F64 || src_dtype == UOCR_F16))
+        return uocr_d2d(ctx, dst, src, count * (src_dtype == UOCR_F32 ? 4 : src_dtype == UOCR_F64 ? 8 : 2));
     else
         UOCR_FAIL(ctx, UOCR_ERR_DTYPE, "unsupported conversion %d -> %d", src_dtype, dst_dtype);
     UOCR_LAUNCH_CHECK(ctx);
@@ -548,10 +606,13 @@ int uocr_u8_to_float(uocr_ctx* ctx, int dtype, const uint8_t* src, void* dst, do
     UOCR_CHECK_CTX(ctx);
     if (!count) return UOCR_OK;
     UOCR_REQUIRE(ctx, src && dst);
-    const dim3 grid(uocr_blocks_for(count, 256, UOCR_MAX_GRID)), block(256);
-    UOCR_DISPATCH(ctx, dtype, {
-        hipLaunchKernelGGL((convert_kernel<uint8_t, T>), grid, block, 0, ctx->stream, src, (T*)dst, (T)scale, true,
-                           count);
+    UOCR_DISPATCH_ACT(ctx, dtype, {
+        if ((count & 15) == 0 && aligned16(src) && aligned16(dst))           // 16 pixels per lane per trip
+            hipLaunchKernelGGL((u8_to_float_vec_kernel<TS>), dim3(uocr_blocks_for(count / 16, 256, UOCR_MAX_GRID)),
+                               dim3(256), 0, ctx->stream, src, (TS*)dst, scale, count / 16);
+        else
+            hipLaunchKernelGGL((convert_scaled_kernel<uint8_t, TS, T>), dim3(uocr_blocks_for(count, 256, UOCR_MAX_GRID)),
+                               dim3(256), 0, ctx->stream, src, (TS*)dst, (T)scale, count);
         UOCR_LAUNCH_CHECK(ctx);
     });
     return UOCR_OK;
@@ -609,7 +670,7 @@ int uocr_momentum_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* v
 static int launch_opt_fused(uocr_ctx* ctx, int dtype, int opt, void* w, void* g, void* s1, void* s2, size_t count,
                             double p0, double p1, double p2, double p3, int nranges, const long long* lo,
                             const long long* hi, const int* kind, const double* strength, double* reg_loss_out,
-                            int zero_grad) {
+                            int zero_grad, const double* hyper_dev) {
     UOCR_REQUIRE(ctx, nranges >= 0 && nranges <= 4 && (nranges == 0 || (lo && hi && kind && strength)));
     UOCR_REQUIRE(ctx, nranges == 0 || reg_loss_out);
     if (!count) return UOCR_OK;
@@ -635,7 +696,7 @@ static int launch_opt_fused(uocr_ctx* ctx, int dtype, int opt, void* w, void* g,
     UOCR_DISPATCH(ctx, dtype, {
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, ctx->stream, (T*)w, (T*)g, (T*)s1, (T*)s2, count, (T)p0,
-                               (T)p1, (T)p2, (T)p3, rr, partial, reg_loss_out, zero_grad);
+                               (T)p1, (T)p2, (T)p3, rr, partial, reg_loss_out, zero_grad, hyper_dev);
         };
         if (opt == 0 && vec) launch(opt_fused_kernel<T, 0, 4>);
         else if (opt == 0) launch(opt_fused_kernel<T, 0, 1>);
@@ -653,19 +714,19 @@ static int launch_opt_fused(uocr_ctx* ctx, int dtype, int opt, void* w, void* g,
 
 int uocr_momentum_step_fused(uocr_ctx* ctx, int dtype, void* w, void* g, void* v, size_t count, double lr,
                              double momentum, int nranges, const long long* lo, const long long* hi, const int* kind,
-                             const double* strength, double* reg_loss_out, int zero_grad) {
+                             const double* strength, double* reg_loss_out, int zero_grad, const double* hyper_dev) {
     UOCR_CHECK_CTX(ctx);
     return launch_opt_fused(ctx, dtype, 0, w, g, v, nullptr, count, lr, momentum, 0.0, 0.0, nranges, lo, hi, kind,
-                            strength, reg_loss_out, zero_grad);
+                            strength, reg_loss_out, zero_grad, hyper_dev);
 }
 
 int uocr_adam_step_fused(uocr_ctx* ctx, int dtype, void* w, void* g, void* v, void* a, size_t count, double lr,
                          double beta1, double beta2, double eps, int nranges, const long long* lo,
                          const long long* hi, const int* kind, const double* strength, double* reg_loss_out,
-                         int zero_grad) {
+                         int zero_grad, const double* hyper_dev) {
     UOCR_CHECK_CTX(ctx);
     return launch_opt_fused(ctx, dtype, 1, w, g, v, a, count, lr, beta1, beta2, eps, nranges, lo, hi, kind, strength,
-                            reg_loss_out, zero_grad);
+                            reg_loss_out, zero_grad, hyper_dev);
 }
 
 int uocr_rmsprop_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* a, size_t count, double lr,

@@ -11,6 +11,11 @@ namespace {
 
 constexpr double SEG_EPS = 1e-8;   // losses.py:17,36
 
+template <typename T, int V>
+struct alignas(16) VecOf {
+    T v[V];
+};
+
 // stage 1: block (chunk, pair=(b,ch)) sums p*g, p, g over its pixel range of image b, channel ch
 template <typename T>
 __global__ __launch_bounds__(256) void seg_partial_kernel(const T* __restrict__ pred, const T* __restrict__ gt,
@@ -24,17 +29,21 @@ __global__ __launch_bounds__(256) void seg_partial_kernel(const T* __restrict__ 
     const T* pp = pred + (size_t)b * hw * c + ch;
     const T* gp = gt + (size_t)b * hw * c + ch;
     double s_pg = 0.0, s_p = 0.0, s_g = 0.0;
-    if constexpr (sizeof(T) == 4) {
-        // one channel, 16-byte aligned rows: 4 pixels per load (the per-chunk sums only change their order
-        // of addition within a thread)
-        if (c == 1 && (hw & 3) == 0 && (per & 3) == 0 && ((uintptr_t)pred & 15) == 0 && ((uintptr_t)gt & 15) == 0) {
-            const float4* p4 = reinterpret_cast<const float4*>(pp);
-            const float4* g4 = reinterpret_cast<const float4*>(gp);
-            for (int q = p0 / 4 + threadIdx.x; q < p1 / 4; q += blockDim.x) {
-                const float4 pv = p4[q], gv = g4[q];
-                s_pg += (double)pv.x * gv.x + (double)pv.y * gv.y + (double)pv.z * gv.z + (double)pv.w * gv.w;
-                s_p += (double)pv.x + (double)pv.y + (double)pv.z + (double)pv.w;
-                s_g += (double)gv.x + (double)gv.y + (double)gv.z + (double)gv.w;
+    if constexpr (sizeof(T) <= 4) {
+        // one channel, 16-byte aligned rows: V = 4 (float) or 8 (binary16) pixels per 16-byte load (the per-chunk
+        // sums only change their order of addition within a thread)
+        constexpr int V = 16 / (int)sizeof(T);
+        if (c == 1 && (hw % V) == 0 && (per % V) == 0 && ((uintptr_t)pred & 15) == 0 && ((uintptr_t)gt & 15) == 0) {
+            const VecOf<T, V>* p4 = reinterpret_cast<const VecOf<T, V>*>(pp);
+            const VecOf<T, V>* g4 = reinterpret_cast<const VecOf<T, V>*>(gp);
+            for (int q = p0 / V + threadIdx.x; q < p1 / V; q += blockDim.x) {
+                const VecOf<T, V> pv = p4[q], gv = g4[q];
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    s_pg += (double)pv.v[k] * (double)gv.v[k];
+                    s_p += (double)pv.v[k];
+                    s_g += (double)gv.v[k];
+                }
             }
             p1 = p0;                                     // nothing left for the scalar loop
         }
@@ -72,7 +81,7 @@ template <typename T, int KIND>
 __global__ __launch_bounds__(256) void seg_grad_kernel(const T* __restrict__ pred, const T* __restrict__ gt,
                                                        const double* __restrict__ partial, T* __restrict__ grad,
                                                        double* __restrict__ loss_out, int hw, int c, int nchunks,
-                                                       int npairs, int out_act) {
+                                                       int npairs, int out_act, double gscale) {
     __shared__ double smem[16];
     __shared__ double coef[2];
     const int chunk = blockIdx.x, pair = blockIdx.y;
@@ -112,6 +121,8 @@ __global__ __launch_bounds__(256) void seg_grad_kernel(const T* __restrict__ pre
             coef[0] = -(den + num) / (den * den);
             coef[1] = num / (den * den);
         }
+        coef[0] *= gscale;                               // UOCR_F16_SCALED(k): grad * 2^k (exact), else 1
+        coef[1] *= gscale;
     }
     __syncthreads();
     const double ca = coef[0], cb = coef[1];
@@ -120,25 +131,28 @@ __global__ __launch_bounds__(256) void seg_grad_kernel(const T* __restrict__ pre
     const int p0 = chunk * per;
     int p1 = min(hw, p0 + per);
     const size_t base = (size_t)b * hw * c + ch;
-    if constexpr (sizeof(T) == 4) {
-        if (c == 1 && (hw & 3) == 0 && (per & 3) == 0 && ((uintptr_t)pred & 15) == 0 && ((uintptr_t)gt & 15) == 0 &&
+    if constexpr (sizeof(T) <= 4) {
+        constexpr int V = 16 / (int)sizeof(T);
+        if (c == 1 && (hw % V) == 0 && (per % V) == 0 && ((uintptr_t)pred & 15) == 0 && ((uintptr_t)gt & 15) == 0 &&
             ((uintptr_t)grad & 15) == 0) {
-            const float4* p4 = reinterpret_cast<const float4*>(pred + base);
-            const float4* g4 = reinterpret_cast<const float4*>(gt + base);
-            float4* o4 = reinterpret_cast<float4*>(grad + base);
+            const VecOf<T, V>* p4 = reinterpret_cast<const VecOf<T, V>*>(pred + base);
+            const VecOf<T, V>* g4 = reinterpret_cast<const VecOf<T, V>*>(gt + base);
+            VecOf<T, V>* o4 = reinterpret_cast<VecOf<T, V>*>(grad + base);
             const bool sig = out_act == UOCR_ACT_SIGMOID;
-            for (int q = p0 / 4 + threadIdx.x; q < p1 / 4; q += blockDim.x) {
-                const float4 gv = g4[q];
-                double r[4] = {ca * (double)gv.x + cb, ca * (double)gv.y + cb, ca * (double)gv.z + cb,
-                               ca * (double)gv.w + cb};
+            for (int q = p0 / V + threadIdx.x; q < p1 / V; q += blockDim.x) {
+                const VecOf<T, V> gv = g4[q];
+                double r[V];
+#pragma unroll
+                for (int k = 0; k < V; ++k) r[k] = ca * (double)gv.v[k] + cb;
                 if (sig) {
-                    const float4 pv = p4[q];
-                    r[0] *= (double)pv.x * (1.0 - (double)pv.x);
-                    r[1] *= (double)pv.y * (1.0 - (double)pv.y);
-                    r[2] *= (double)pv.z * (1.0 - (double)pv.z);
-                    r[3] *= (double)pv.w * (1.0 - (double)pv.w);
+                    const VecOf<T, V> pv = p4[q];
+#pragma unroll
+                    for (int k = 0; k < V; ++k) r[k] *= (double)pv.v[k] * (1.0 - (double)pv.v[k]);
                 }
-                o4[q] = make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
+                VecOf<T, V> out;
+#pragma unroll
+                for (int k = 0; k < V; ++k) out.v[k] = (T)r[k];
+                o4[q] = out;
             }
             p1 = p0;
         }
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(256) void seg_grad_kernel(const T* __restrict__ pre
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const T* __restrict__ pred, const T* __restrict__ gt,
                                                          T* __restrict__ grad, double* __restrict__ row_loss, int m,
-                                                         int c) {
+                                                         int c, double gscale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= m) return;
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const T* __restrict__ p
         const double z = (double)x[j] - mx;
         const double gv = (double)g[j];
         if (gv != 0.0) loss -= gv * (z - lse);
-        if (grad) grad[(size_t)row * c + j] = (T)((exp(z) / se - gv) / (double)m);
+        if (grad) grad[(size_t)row * c + j] = (T)((exp(z) / se - gv) / (double)m * gscale);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) loss += __shfl_xor(loss, off, 64);
@@ -188,7 +202,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const T* __restrict__ p
 template <typename T>
 __global__ __launch_bounds__(256) void sigmoid_ce_kernel(const T* __restrict__ pred, const T* __restrict__ gt,
                                                          T* __restrict__ grad, double* __restrict__ partial,
-                                                         size_t total, double inv_m) {
+                                                         size_t total, double inv_m, double gscale) {
     __shared__ double smem[16];
     double acc = 0.0;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(256) void sigmoid_ce_kernel(const T* __restrict__ p
         const double x = (double)pred[idx], g = (double)gt[idx];
         const double p = 1.0 / (1.0 + exp(-x));
         acc -= g * log(p) + (1.0 - g) * log(1.0 - p);
-        if (grad) grad[idx] = (T)((g * (p - 1.0) + (1.0 - g) * p) * inv_m);
+        if (grad) grad[idx] = (T)((g * (p - 1.0) + (1.0 - g) * p) * inv_m * gscale);
     }
     acc = block_reduce_sum(acc, smem);
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
@@ -220,7 +234,8 @@ int uocr_seg_loss(uocr_ctx* ctx, int dtype, int kind, const void* pred, const vo
     if (rc) return rc;
     double* partial = (double*)ctx->workspace;
     UOCR_REQUIRE(ctx, (size_t)hw * c < (size_t)INT32_MAX && npairs <= 65535);
-    UOCR_DISPATCH(ctx, dtype, {
+    const double gscale = uocr_grad_scale(dtype);
+    UOCR_DISPATCH_STORAGE(ctx, dtype, {
         hipLaunchKernelGGL((seg_partial_kernel<T>), dim3(nchunks, npairs), dim3(256), 0, ctx->stream, (const T*)pred,
                            (const T*)gt, partial, hw, c, nchunks);
         UOCR_LAUNCH_CHECK(ctx);
@@ -229,11 +244,11 @@ int uocr_seg_loss(uocr_ctx* ctx, int dtype, int kind, const void* pred, const vo
         if (kind == UOCR_LOSS_DICE)
             hipLaunchKernelGGL((seg_grad_kernel<T, UOCR_LOSS_DICE>), grid, dim3(256), 0, ctx->stream, (const T*)pred,
                                (const T*)gt, (const double*)partial, (T*)grad, loss_out, hw, c, nchunks, npairs,
-                               out_act);
+                               out_act, gscale);
         else
             hipLaunchKernelGGL((seg_grad_kernel<T, UOCR_LOSS_JACCARD>), grid, dim3(256), 0, ctx->stream,
                                (const T*)pred, (const T*)gt, (const double*)partial, (T*)grad, loss_out, hw, c,
-                               nchunks, npairs, out_act);
+                               nchunks, npairs, out_act, gscale);
         UOCR_LAUNCH_CHECK(ctx);
     });
     return UOCR_OK;
@@ -246,9 +261,9 @@ int uocr_softmax_ce(uocr_ctx* ctx, int dtype, const void* pred, const void* gt, 
     int rc = uocr_need_workspace(ctx, (size_t)m * sizeof(double));
     if (rc) return rc;
     double* row_loss = (double*)ctx->workspace;
-    UOCR_DISPATCH(ctx, dtype, {
+    UOCR_DISPATCH_STORAGE(ctx, dtype, {
         hipLaunchKernelGGL((softmax_ce_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, ctx->stream, (const T*)pred,
-                           (const T*)gt, (T*)grad, row_loss, m, c);
+                           (const T*)gt, (T*)grad, row_loss, m, c, uocr_grad_scale(dtype));
         UOCR_LAUNCH_CHECK(ctx);
     });
     return uocr_finish_sum(ctx, row_loss, m, 1.0 / (double)m, loss_out, 0);
@@ -262,9 +277,9 @@ int uocr_sigmoid_ce(uocr_ctx* ctx, int dtype, const void* pred, const void* gt, 
     int rc = uocr_need_workspace(ctx, grid * sizeof(double));
     if (rc) return rc;
     double* partial = (double*)ctx->workspace;
-    UOCR_DISPATCH(ctx, dtype, {
+    UOCR_DISPATCH_STORAGE(ctx, dtype, {
         hipLaunchKernelGGL((sigmoid_ce_kernel<T>), dim3(grid), dim3(256), 0, ctx->stream, (const T*)pred,
-                           (const T*)gt, (T*)grad, partial, count, 1.0 / (double)m);
+                           (const T*)gt, (T*)grad, partial, count, 1.0 / (double)m, uocr_grad_scale(dtype));
         UOCR_LAUNCH_CHECK(ctx);
     });
     return uocr_finish_sum(ctx, partial, (int)grid, 1.0 / (double)m, loss_out, 0);

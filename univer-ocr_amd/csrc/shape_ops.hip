@@ -366,7 +366,7 @@ int uocr_maxpool2d_fwd(uocr_ctx* ctx, int dtype, const void* x, void* y, uint8_t
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
-    UOCR_DISPATCH(ctx, dtype, {
+    UOCR_DISPATCH_STORAGE(ctx, dtype, {
         hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4)), dim3(256), 0,
                            ctx->stream, (const T*)x, (T*)y, mask, d);
         UOCR_LAUNCH_CHECK(ctx);
@@ -387,7 +387,7 @@ int uocr_maxpool2d_bwd(uocr_ctx* ctx, int dtype, const void* dy, const uint8_t* 
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
-    UOCR_DISPATCH(ctx, dtype, {
+    UOCR_DISPATCH_STORAGE(ctx, dtype, {
         hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4)), dim3(256), 0,
                            ctx->stream, (const T*)dy, mask, (T*)dx, d);
         UOCR_LAUNCH_CHECK(ctx);
@@ -412,7 +412,7 @@ int uocr_upsample2d_fwd(uocr_ctx* ctx, int dtype, const void* x, void* y, int n,
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
-    UOCR_DISPATCH(ctx, dtype, {
+    UOCR_DISPATCH_STORAGE(ctx, dtype, {
         hipLaunchKernelGGL((upsample_fwd_kernel<T>), dim3(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4)), dim3(256),
                            0, ctx->stream, (const T*)x, (T*)y, n, h, wd, c, sy, sx);
         UOCR_LAUNCH_CHECK(ctx);
@@ -437,7 +437,7 @@ int uocr_upsample2d_bwd(uocr_ctx* ctx, int dtype, const void* dy, void* dx, int 
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
-    UOCR_DISPATCH(ctx, dtype, {
+    UOCR_DISPATCH_STORAGE(ctx, dtype, {
         hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4)), dim3(256),
                            0, ctx->stream, (const T*)dy, (T*)dx, n, h, wd, c, sy, sx);
         UOCR_LAUNCH_CHECK(ctx);
@@ -449,7 +449,7 @@ int uocr_fixed_width_fwd(uocr_ctx* ctx, int dtype, const void* x, void* y, int n
     UOCR_CHECK_CTX(ctx);
     UOCR_REQUIRE(ctx, x && y && n > 0 && h > 0 && wd > 0 && c > 0 && width > 0 && wd >= width);
     const size_t total = (size_t)n * wd * h * width * c;
-    UOCR_DISPATCH(ctx, dtype, {
+    UOCR_DISPATCH_STORAGE(ctx, dtype, {
         hipLaunchKernelGGL((fixed_width_fwd_kernel<T>), dim3(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4)),
                            dim3(256), 0, ctx->stream, (const T*)x, (T*)y, n, h, wd, c, width);
         UOCR_LAUNCH_CHECK(ctx);
@@ -462,7 +462,7 @@ int uocr_fixed_width_bwd(uocr_ctx* ctx, int dtype, const void* dy, void* dx, int
     UOCR_CHECK_CTX(ctx);
     UOCR_REQUIRE(ctx, dy && dx && n > 0 && h > 0 && wd > 0 && c > 0 && width > 0 && wd >= width);
     const size_t total = (size_t)n * h * wd * c;
-    UOCR_DISPATCH(ctx, dtype, {
+    UOCR_DISPATCH_STORAGE(ctx, dtype, {
         hipLaunchKernelGGL((fixed_width_bwd_kernel<T>), dim3(uocr_blocks_for(total, 256, UOCR_MAX_GRID * 4)),
                            dim3(256), 0, ctx->stream, (const T*)dy, (T*)dx, n, h, wd, c, width);
         UOCR_LAUNCH_CHECK(ctx);
@@ -475,7 +475,7 @@ int uocr_copy_2d(uocr_ctx* ctx, int dtype, void* dst, size_t dst_ld, const void*
     UOCR_CHECK_CTX(ctx);
     if (!rows || !cols) return UOCR_OK;
     UOCR_REQUIRE(ctx, dst && src && dst_ld >= cols && src_ld >= cols);
-    UOCR_DISPATCH(ctx, dtype, {
+    UOCR_DISPATCH_STORAGE(ctx, dtype, {
         hipLaunchKernelGGL((copy2d_kernel<T>), dim3(uocr_blocks_for(rows * cols, 256, UOCR_MAX_GRID * 4)), dim3(256),
                            0, ctx->stream, (T*)dst, dst_ld, (const T*)src, src_ld, rows, cols);
         UOCR_LAUNCH_CHECK(ctx);

@@ -64,6 +64,34 @@ struct uocr_ctx {
         else UOCR_FAIL(ctx, UOCR_ERR_DTYPE, "unknown dtype %d", (int)(dtype)); \
     } while (0)
 
+// activation-tensor dispatch: BODY sees TS = the storage type in HBM and T = the type to compute in
+// (UOCR_F16: binary16 storage, float32 arithmetic; the gradient-scale bits of dtype are ignored here)
+#define UOCR_DISPATCH_ACT(ctx, dtype, ...)                                                        \
+    do {                                                                                          \
+        const int base_ = UOCR_DTYPE_BASE(dtype);                                                 \
+        if (base_ == UOCR_F32) { using TS = float; using T = float; __VA_ARGS__; }                \
+        else if (base_ == UOCR_F64) { using TS = double; using T = double; __VA_ARGS__; }         \
+        else if (base_ == UOCR_F16) { using TS = _Float16; using T = float; __VA_ARGS__; }        \
+        else UOCR_FAIL(ctx, UOCR_ERR_DTYPE, "unknown dtype %d", (int)(dtype));                    \
+    } while (0)
+
+// storage-type dispatch for kernels that convert every element on load / store themselves: BODY sees T
+#define UOCR_DISPATCH_STORAGE(ctx, dtype, ...)                                                    \
+    do {                                                                                          \
+        const int base_ = UOCR_DTYPE_BASE(dtype);                                                 \
+        if (base_ == UOCR_F32) { using T = float; __VA_ARGS__; }                                  \
+        else if (base_ == UOCR_F64) { using T = double; __VA_ARGS__; }                            \
+        else if (base_ == UOCR_F16) { using T = _Float16; __VA_ARGS__; }                          \
+        else UOCR_FAIL(ctx, UOCR_ERR_DTYPE, "unknown dtype %d", (int)(dtype));                    \
+    } while (0)
+
+// 2^k of UOCR_F16_SCALED(k): the loss kernels multiply their gradient by it, the bwd_weight kernels divide
+// dw / db by it (1 for the other dtypes)
+static inline double uocr_grad_scale(int dtype) {
+    return UOCR_DTYPE_BASE(dtype) == UOCR_F16 ? (double)(1u << (UOCR_DTYPE_GRAD_SCALE_LOG2(dtype) & 31)) : 1.0;
+}
+static inline double uocr_grad_unscale(int dtype) { return 1.0 / uocr_grad_scale(dtype); }
+
 static inline int uocr_need_workspace(uocr_ctx* ctx, size_t bytes) {
     if (bytes > ctx->workspace_bytes)
         UOCR_FAIL(ctx, UOCR_ERR_WORKSPACE, "workspace too small: need %zu bytes, have %zu", bytes,
@@ -110,6 +138,57 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* smem /* >= 
     v = (threadIdx.x < (unsigned)nw) ? smem[threadIdx.x] : 0.0;
     if (wid == 0) v = wave_reduce_sum(v);
     return v;
+}
+
+// ---- activation-tensor element access ---------------------------------------------------------------------
+// TA = float (UOCR_F32) or _Float16 (UOCR_F16: binary16 in HBM, float32 in registers).  1 / 2 / 4 consecutive
+// elements per call as ONE memory instruction (4 / 8 / 16 bytes of float, 2 / 4 / 8 bytes of binary16).
+using uocr_h2 = __attribute__((ext_vector_type(2))) _Float16;
+using uocr_h4 = __attribute__((ext_vector_type(4))) _Float16;
+
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const _Float16* p) { return (float)*p; }
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ float2 ld2(const _Float16* p) {
+    const uocr_h2 v = *reinterpret_cast<const uocr_h2*>(p);
+    return make_float2((float)v.x, (float)v.y);
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const _Float16* p) {
+    const uocr_h4 v = *reinterpret_cast<const uocr_h4*>(p);
+    return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+}
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(_Float16* p, float v) { *p = (_Float16)v; }
+__device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+__device__ __forceinline__ void st2(_Float16* p, float2 v) {
+    uocr_h2 h;
+    h.x = (_Float16)v.x;
+    h.y = (_Float16)v.y;
+    *reinterpret_cast<uocr_h2*>(p) = h;
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(_Float16* p, float4 v) {
+    uocr_h4 h;
+    h.x = (_Float16)v.x;
+    h.y = (_Float16)v.y;
+    h.z = (_Float16)v.z;
+    h.w = (_Float16)v.w;
+    *reinterpret_cast<uocr_h4*>(p) = h;
+}
+
+// float32 / binary16 activation kernels: BODY sees TA (the float64 mode has its own generic kernels)
+#define UOCR_DISPATCH_TA(ctx, dtype, ...)                                                          \
+    do {                                                                                           \
+        const int base_ = UOCR_DTYPE_BASE(dtype);                                                  \
+        if (base_ == UOCR_F32) { using TA = float; __VA_ARGS__; }                                  \
+        else if (base_ == UOCR_F16) { using TA = _Float16; __VA_ARGS__; }                          \
+        else UOCR_FAIL(ctx, UOCR_ERR_DTYPE, "dtype %d: this kernel exists for float32 / float16 only", (int)(dtype)); \
+    } while (0)
+
+// alignment an activation pointer needs for the widest (4-element) access of the dtype
+static inline bool uocr_aligned_act(const void* p, int dtype) {
+    return (reinterpret_cast<uintptr_t>(p) & (UOCR_DTYPE_BASE(dtype) == UOCR_F16 ? 7u : 15u)) == 0;
 }
 
 // d act(x) / dx expressed through the activation OUTPUT y (leaky: alpha > 0 so sign(y) == sign(x))

@@ -9,7 +9,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = 'libuniver_hip.so'
 
-F32, F64 = 0, 1
+F32, F64, F16 = 0, 1, 2
+DP_UNIQUE_ID_BYTES = 128
+
+
+def f16_scaled(k):
+    """UOCR_F16_SCALED(k): binary16 activations whose gradients carry the factor 2^k."""
+    return F16 | (int(k) << 8)
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 LOSS_DICE, LOSS_JACCARD = 0, 1
 
@@ -29,7 +35,9 @@ def dtype_code(np_dtype):
         return F32
     if dt == np.float64:
         return F64
-    raise HipError(f'unsupported dtype {dt}: the HIP backend computes in float32 or float64')
+    if dt == np.float16:
+        return F16
+    raise HipError(f'unsupported dtype {dt}: the HIP backend stores float16 / float32 / float64')
 
 
 _vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
@@ -52,6 +60,7 @@ _PROTOS = {
     'uocr_event_create': [C.POINTER(_vp)],
     'uocr_event_destroy': [_vp],
     'uocr_event_record': [_ctx, _vp],
+    'uocr_stream_wait_event': [_ctx, _vp],
     'uocr_event_elapsed_ms_sync': [_vp, _vp, C.POINTER(C.c_float)],
     'uocr_device_info': [_ctx, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_sz)],
     'uocr_conv2d_fwd': [_ctx, _i, _vp, _vp, _vp, _vp] + [_i] * 13 + [_d, _i, _i, _d],
@@ -90,15 +99,21 @@ _PROTOS = {
     'uocr_adam_step': [_ctx, _i, _vp, _vp, _vp, _vp, _sz, _d, _d, _d, _d],
     'uocr_momentum_step': [_ctx, _i, _vp, _vp, _vp, _sz, _d, _d],
     'uocr_momentum_step_fused': [_ctx, _i, _vp, _vp, _vp, _sz, _d, _d, _i, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
-                                 C.POINTER(C.c_int), C.POINTER(C.c_double), _vp, _i],
+                                 C.POINTER(C.c_int), C.POINTER(C.c_double), _vp, _i, _vp],
     'uocr_adam_step_fused': [_ctx, _i, _vp, _vp, _vp, _vp, _sz, _d, _d, _d, _d, _i, C.POINTER(C.c_longlong),
-                             C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_double), _vp, _i],
+                             C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_double), _vp, _i, _vp],
     'uocr_rmsprop_step': [_ctx, _i, _vp, _vp, _vp, _sz, _d, _d, _d],
     'uocr_has_nan': [_ctx, _i, _vp, _sz, _vp],
+    'uocr_dp_init': [_ctx, _i, _i, _vp],
+    'uocr_dp_info': [_ctx, C.POINTER(_i), C.POINTER(_i)],
+    'uocr_dp_allreduce_sum': [_ctx, _vp, _sz, _i],
+    'uocr_dp_broadcast': [_ctx, _vp, _sz, _i, _i],
+    'uocr_dp_finalize': [_ctx],
 }
 # declared in the header with a non-int return type
 _SPECIAL = {
     'uocr_abi_version': (C.c_int, []),
+    'uocr_dp_get_unique_id': (C.c_int, [_vp]),
     'uocr_last_error': (C.c_char_p, [_ctx]),
     'uocr_ctx_get_stream': (C.c_void_p, [_ctx]),
 }

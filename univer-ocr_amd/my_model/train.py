@@ -34,11 +34,27 @@ def load_weights(path=MODEL_WEIGHTS_FILE_PATH):
         return {}
 
 
+def _init_data_parallel():
+    """Launched by torch.distributed.run (one rank per GPU)?  Then torch.distributed -- gloo: host-side
+    rendezvous only -- carries the RCCL id and the epoch losses; the gradients travel through the C ABI's RCCL
+    entry points (parallel.DataParallel).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1:
+        return 0, 1, None
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    rank = int(os.environ.get('RANK', '0'))
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    return rank, world, int(os.environ.get('LOCAL_RANK', '0'))
+
+
 def train_model(use_gpu=True, show_progress_bar=False, save_train_progress=False, epochs_scale=None,
-                batch=1, height=256, width=512):
+                batch=1, height=256, width=512, dp_backend=None):
     if not use_gpu:
         CP.use_cpu()          # raises: the NumPy path is the reference itself
-    CP.use_gpu()
+    rank, world, local_rank = _init_data_parallel()
+    CP.use_gpu(local_rank)
     info = CP.runtime().device_info()
     message(f'Using GPU\nname = {info["name"]}\nmultiProcessorCount = {info["cu_count"]}\n'
             f'totalGlobalMem = {info["hbm_bytes"]}\nwarpSize = 64\n')
@@ -46,8 +62,9 @@ def train_model(use_gpu=True, show_progress_bar=False, save_train_progress=False
     scale = float(os.environ.get('UOCR_EPOCHS_SCALE', '0.02')) if epochs_scale is None else epochs_scale
     stages = [(Modes.TRAIN_MONOCHROME, 0.0015, 0.995, 100), (Modes.TRAIN_PARAGRAPH, 0.0015, 0.995, 100),
               (Modes.TRAIN_PAGE, 0.001, 0.9, 10)]
-    train_set = SyntheticPages(batch, height, width, seed=1234, length=4)
-    val_set = SyntheticPages(batch, height, width, seed=9999, length=2)
+    # data parallel: every rank trains on its own pages (the batch is sharded by rank: seeds differ)
+    train_set = SyntheticPages(batch, height, width, seed=1234 + 1000 * rank, length=4)
+    val_set = SyntheticPages(batch, height, width, seed=9999 + 1000 * rank, length=2)
     results = {}
     for mode, lr, lr_step, epochs in stages:
         epochs = max(1, int(round(epochs * scale)))
@@ -66,7 +83,13 @@ def train_model(use_gpu=True, show_progress_bar=False, save_train_progress=False
                     merged.update(model.get_weights())
             with open(MODEL_WEIGHTS_FILE_PATH, 'w') as f:
                 json.dump(merged, f, separators=(',', ':'))
+        dp = None
+        if world > 1:
+            from ..parallel import DataParallel
+            dp = DataParallel(models, overlap=False, backend=dp_backend)    # rank 0's weights everywhere
         trainer = Trainer(model_system, make_context_maker(mode), models, train_set, val_set, tracker,
-                          show_progress_bar, optimizer, lr_step, save_weights)
+                          show_progress_bar, optimizer, lr_step, save_weights, data_parallel=dp)
         results[mode.name] = trainer.train(epochs)
+        if dp is not None:
+            dp.close()
     return results

@@ -29,7 +29,7 @@ def make_optimizer(name, lr):
 class PageTrainer:
     def __init__(self, batch, height=256, width=512, char_width=64, optimizer='sgd', lr=0.0015, seed=0,
                  nets=('Monochrome', 'Paragraph', 'Line', 'Char'), data_parallel=None, overlap=True,
-                 dp_side_stream=False,
+                 dp_coalesce=False, dp_backend=None,
                  init='kaiming_normal', fuse=True, lanes=True, input_grads=True, graphs=False, eager_nets=(), pipelined=False,
                  lane_groups=(('Monochrome', 'Paragraph'), ('Line',), ('Char',))):
         np.random.seed(seed)                        # kaiming_uniform draws from the NumPy global RNG
@@ -83,7 +83,12 @@ class PageTrainer:
             data_parallel = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if data_parallel:
             from ..parallel import DataParallel
-            self.dp = DataParallel(self.models, overlap=overlap, side_stream=dp_side_stream)
+            # construction order = the order the collectives of a step are issued in on every rank: the short
+            # Paragraph net first, so its optimizer tail is not held up behind the longer nets' gradients
+            order = [n for n in ('Paragraph', 'Char', 'Line', 'Monochrome') if n in self.models]
+            order += [n for n in self.models if n not in order]
+            self.dp = DataParallel({n: self.models[n] for n in order}, overlap=overlap, coalesce=dp_coalesce,
+                                   backend=dp_backend)
             for model in self.models.values():
                 model.defer_grad_sync = overlap
 
@@ -149,15 +154,10 @@ class PageTrainer:
         return context['losses']
 
     def _lane_order(self):
-        """Enqueue order of the nets.  One process: the nets that are long chains of short kernels first
-        (their chain is the critical path of the concurrent step), the nets of few long kernels last.
-        Data parallel with the collectives on torch's side stream: shortest net first -- all gradient
-        all-reduces then share that one in-order stream, so a collective issued behind the Char net's would
-        wait for Char's backward and couple the lanes (collectives issued from the lanes do not)."""
-        if self.dp is not None and self.dp.side_stream:
-            rank = {'Paragraph': 0, 'Monochrome': 1, 'Line': 2, 'Char': 3}
-        else:
-            rank = {'Char': 0, 'Paragraph': 1, 'Line': 2, 'Monochrome': 3}
+        """Enqueue order of the nets: the nets that are long chains of short kernels first (their chain is the
+        critical path of the concurrent step), the nets of few long kernels last.  (The order the gradient
+        all-reduces are ISSUED in under data parallelism is independent of this: parallel.DataParallel.flush.)"""
+        rank = {'Char': 0, 'Paragraph': 1, 'Line': 2, 'Monochrome': 3}
         return sorted(self.model_system.components, key=lambda comp: rank.get(comp.name, 9))
 
     def _step_lanes(self, context):
@@ -292,6 +292,7 @@ class PageTrainer:
         rt = CP.runtime()
         main = torch.cuda.current_stream()
         comps = self._lane_order()
+        self.optimizer.refresh_hyper()                   # lr / betas changed since the last step? (device array)
         if self.pipelined and any(context[label] is not static for label, static in self._statics.items()):
             self.join()                                      # the copies below overwrite what the lanes read
         copied = set()
@@ -408,7 +409,7 @@ class Trainer:
 
     def __init__(self, model_system, make_context_func, models, train_dataset, validation_dataset,
                  progress_tracker=None, show_progress_bar=False, optimizer=None, learning_rate_step=0.995,
-                 save_weights_func=None, save_pictures_func=None):
+                 save_weights_func=None, save_pictures_func=None, data_parallel=None):
         from ..nn.progress_tracker import BaseProgressTracker
         self.model_system, self.make_context_func, self.models = model_system, make_context_func, models
         self.train_dataset, self.validation_dataset = train_dataset, validation_dataset
@@ -416,6 +417,26 @@ class Trainer:
         self.show_progress_bar = show_progress_bar
         self.optimizer, self.learning_rate_step = optimizer, learning_rate_step
         self.save_weights_func, self.save_pictures_func = save_weights_func, save_pictures_func
+        # data parallel (parallel.DataParallel over `models`, or None): every rank runs this loop on its own
+        # shard of the datasets; the gradient all-reduce happens inside Model.train (grad_sync), so the weights
+        # -- and with them the NaN test and the rollback -- are identical on every rank; the epoch losses are
+        # averaged over the ranks so that every rank also takes the same "better weights" decisions, and only
+        # rank 0 writes model_weights.json
+        self.dp = data_parallel
+
+    def _rank_mean(self, losses):
+        """Average the normalised epoch losses over the ranks (host side, a few floats per epoch)."""
+        if self.dp is None or self.dp.world == 1:
+            return
+        import torch
+        for table in (losses.train_losses, losses.val_losses):
+            names = sorted(table)
+            flat = torch.tensor([v for n in names for v in table[n]], dtype=torch.float64)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat /= self.dp.world
+            it = iter(flat.tolist())
+            for n in names:
+                table[n] = [next(it) for _ in table[n]]
 
     def _weights(self):
         return {name: w for model in self.models.values() for name, w in model.get_weights().items()}
@@ -452,6 +473,7 @@ class Trainer:
             shuffle(val_order)
             self._pass(self.validation_dataset, val_order, losses.validation, False, epoch, 'validation')
             losses.normalize(n_train, n_val)
+            self._rank_mean(losses)
             has_nan = any(model.nan_weights() for model in self.models.values())
             if self.optimizer is not None:
                 reload_attempts += 1
@@ -470,10 +492,11 @@ class Trainer:
                                  'learning_rate_step, so learning rate could be decreased to try avoiding NaN values')
             losses.print(left_margin=2)
             better = losses.get_better_weights(epoch)
-            if better and self.save_weights_func:
+            if better and self.save_weights_func and (self.dp is None or self.dp.rank == 0):
                 print('  Saving weights for ' + ', '.join(better))
                 self.save_weights_func(better)
-                best_weights = self._weights()
+            # (`best_weights` stays what it was before the first epoch, exactly as in the reference, which
+            # never reassigns it: my_model/trainer.py:184, 264-268)
             last_weights = self._weights()
             epoch += 1
             reload_attempts = 0

@@ -26,7 +26,9 @@ from ..hip import lib as hiplib
 from ..hip.lib import HipError
 
 _TORCH_DT = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+             np.dtype(np.float16): torch.float16,
              np.dtype(np.uint8): torch.uint8, np.dtype(np.int32): torch.int32}
+_CODE = {torch.float32: hiplib.F32, torch.float64: hiplib.F64, torch.float16: hiplib.F16}
 _NP_DT = {v: k for k, v in _TORCH_DT.items()}
 
 
@@ -140,11 +142,15 @@ class DeviceArray:
     dtype / reshape (a view) / copy / host round trip / `+` for fan-out gradient sums
     (models.py:218).  All arithmetic happens in libuniver_hip.so."""
 
-    __slots__ = ('t',)
+    __slots__ = ('t', 'gscale')
     __array_priority__ = 100
 
-    def __init__(self, tensor):
+    def __init__(self, tensor, gscale=0):
         self.t = tensor
+        # float16 mode: log2 of the power-of-two factor this array carries when it is an activation GRADIENT
+        # (set by the loss kernels, handed on by every backward op, removed by the bwd_weight kernels:
+        # include/univer_hip.h, UOCR_F16_SCALED).  0 for everything else.
+        self.gscale = gscale
 
     # -- metadata ---------------------------------------------------------------------------
     @property
@@ -173,7 +179,10 @@ class DeviceArray:
 
     @property
     def code(self):
-        return hiplib.F32 if self.t.dtype == torch.float32 else hiplib.F64
+        code = _CODE.get(self.t.dtype)
+        if code is None:
+            raise HipError(f'{self.t.dtype} arrays have no kernel dtype code')
+        return code | (self.gscale << 8) if code == hiplib.F16 else code
 
     def __len__(self):
         return self.t.shape[0]
@@ -185,10 +194,10 @@ class DeviceArray:
     def reshape(self, *shape):
         if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
             shape = tuple(shape[0])
-        return DeviceArray(self.t.view(*[int(s) for s in shape]))
+        return DeviceArray(self.t.view(*[int(s) for s in shape]), self.gscale)
 
     def copy(self):
-        return DeviceArray(self.t.clone())
+        return DeviceArray(self.t.clone(), self.gscale)
 
     def numpy(self):
         return self.t.detach().cpu().numpy()
@@ -272,6 +281,7 @@ class CP:
     is_gpu_used = True
     dtype = np.dtype(os.environ.get('UOCR_DTYPE', 'float32'))
     lazy_losses = False          # True: losses stay on the device until float() is called
+    f16_grad_scale_log2 = None   # float16 mode: None = the loss kernels pick the gradient scale, int k = 2^k
     _runtime = None
     ops = None                   # set by nn/ops.py (kernel wrappers)
 
@@ -288,10 +298,17 @@ class CP:
 
     @staticmethod
     def set_dtype(dtype):
+        """float32 (production), float64 (the reference's type: parity mode) or float16 = binary16 ACTIVATIONS
+        with float32 parameters / gradients / accumulation (BASELINE configs[4], include/univer_hip.h UOCR_F16)."""
         dt = np.dtype(dtype)
-        if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+        if dt not in (np.dtype(np.float32), np.dtype(np.float64), np.dtype(np.float16)):
             raise HipError(f'unsupported compute dtype {dt}')
         CP.dtype = dt
+
+    @staticmethod
+    def param_dtype():
+        """dtype of parameters, their gradients and optimizer state: float32 master copies in float16 mode."""
+        return np.dtype(np.float32) if CP.dtype == np.dtype(np.float16) else CP.dtype
 
     @staticmethod
     def runtime(device_index=None):
@@ -320,15 +337,24 @@ class CP:
 
     @staticmethod
     def zeros(shape, dtype=None):
-        dt = CP.dtype if dtype is None else np.dtype(dtype)
-        shape = (shape,) if isinstance(shape, (int, np.integer)) else tuple(int(s) for s in shape)
-        return DeviceArray(torch.zeros(shape, dtype=_TORCH_DT[dt], device=CP.storage_device()))
+        """cupy.zeros: allocation (torch's caching allocator) + uocr_memset_zero -- no torch kernel runs."""
+        out = CP.empty(shape, dtype)
+        if out.t.is_cuda:
+            if out.size:
+                CP.runtime().call('uocr_memset_zero', out.ptr, out.nbytes)
+        else:
+            out.t.zero_()                   # storage-only mode (no GPU): host memory
+        return out
 
     @staticmethod
     def full(shape, value, dtype=None):
-        dt = CP.dtype if dtype is None else np.dtype(dtype)
-        shape = (shape,) if isinstance(shape, (int, np.integer)) else tuple(int(s) for s in shape)
-        return DeviceArray(torch.full(shape, float(value), dtype=_TORCH_DT[dt], device=CP.storage_device()))
+        out = CP.empty(shape, dtype)
+        if out.t.is_cuda and out.t.dtype in _CODE:
+            if out.size:
+                CP.runtime().call('uocr_fill', _CODE[out.t.dtype], out.ptr, float(value), out.size)
+        else:
+            out.t.fill_(value)
+        return out
 
     # -- host <-> device (gpu.py:19-29) ------------------------------------------------------------
     @staticmethod

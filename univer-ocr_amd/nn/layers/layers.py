@@ -25,7 +25,7 @@ class Param:
     """layers.py:10-21."""
 
     def __init__(self, value, optimizer=None):
-        self._value = CP.copy(value)
+        self._value = CP.copy(value, CP.param_dtype())
         self._grad = CP.zeros(self._value.shape, self._value.dtype)
         self._pack = None                 # set by ParamPack: any access to .grad marks the flat buffer dirty
         self.optimizer = optimizer
@@ -77,7 +77,7 @@ class ParamPack:
 
     def __init__(self, params):
         self.params = list(params)
-        self.dtype = self.params[0].value.dtype if self.params else CP.dtype
+        self.dtype = self.params[0].value.dtype if self.params else CP.param_dtype()
         self.entries = []
         off = 0
         for p in self.params:
@@ -103,6 +103,20 @@ class ParamPack:
     @staticmethod
     def view_of(flat, off, size, shape):
         return DeviceArray(flat.t[off:off + size].view(*shape))
+
+    def rebase(self, value_flat, grad_flat, base):
+        """Move the pack into [base, base + total) of two larger flat buffers (parallel.DataParallel puts the
+        packs of all models of a step next to each other so that neighbouring gradients can go out as one
+        collective).  Parameter views are re-pointed; must happen before any HIP graph is captured."""
+        new_value = DeviceArray(value_flat.t[base:base + self.total])
+        new_grad = DeviceArray(grad_flat.t[base:base + self.total])
+        new_value.t.copy_(self.value.t)
+        new_grad.t.copy_(self._grad.t)
+        self.value, self._grad = new_value, new_grad
+        for p, off, size in self.entries:
+            p._value = self.view_of(self.value, off, size, p._value.shape)
+            p._grad = self.view_of(self._grad, off, size, p._grad.shape)
+        self.grad_dirty = True
 
     def zero_grad(self):
         """The reference zeroes every gradient at the start of forward AND after the update

@@ -20,12 +20,35 @@ def _rt():
     return CP.runtime()
 
 
-def _same_dtype(*arrays):
-    code = arrays[0].code
+def _same_dtype(*arrays, grad=None):
+    """dtype code of a call.  The first array is an ACTIVATION tensor and decides: float32 / float64 calls need
+    every array in that type; float16 calls (UOCR_F16: binary16 activations, float32 parameters) take float16
+    and float32 arrays together.  `grad`: the incoming activation gradient of a backward op -- the power-of-two
+    factor it carries (DeviceArray.gscale) travels in the code's scale bits (UOCR_F16_SCALED)."""
+    base = arrays[0].code & 0xff
     for a in arrays[1:]:
-        if a.code != code:
+        other = a.code & 0xff
+        if other != base and not (base == hiplib.F16 and other == hiplib.F32):
             raise HipError('mixed dtypes in one op: ' + ', '.join(str(x.dtype) for x in arrays))
-    return code
+    if base == hiplib.F16 and grad is not None:
+        return hiplib.f16_scaled(grad.gscale)
+    return base
+
+
+def _like_grad(array, dy):
+    """`array` is the activation gradient a backward op derived from `dy`: it carries the same factor."""
+    array.gscale = dy.gscale
+    return array
+
+
+def f16_grad_scale_log2(kind, n):
+    """log2 of the factor a loss kernel gives its float16 gradient so that it sits around 2^-4 .. 1 instead of
+    around 1 / n (n = pixels per image for the segmentation losses, rows for the cross-entropies), far below
+    binary16's normal range for a 2-Mpixel page.  CP.f16_grad_scale_log2 overrides."""
+    if CP.f16_grad_scale_log2 is not None:
+        return int(CP.f16_grad_scale_log2)
+    k = int(math.floor(math.log2(max(1, n)))) - (4 if kind == 'seg' else 1)
+    return max(0, min(24, k))
 
 
 def as_device(x):
@@ -67,12 +90,12 @@ def conv2d_bwd_data(dy, w, x_shape, stride, padding, x_act=None, act=None, alpha
     """dx of the conv; with `x_act` (the conv's input = output of a fused LeakyReLU / Sigmoid) the
     kernel stores dx * act'(x_act), i.e. the gradient w.r.t. that activation's INPUT."""
     dims = _conv_dims(x_shape, w.shape, stride, padding)
-    code = _same_dtype(dy, w) if x_act is None else _same_dtype(dy, w, x_act)
+    code = _same_dtype(dy, w, grad=dy) if x_act is None else _same_dtype(dy, w, x_act, grad=dy)
     if dy.shape != (dims[0], dims[11], dims[12], dims[4]):
         raise AssertionError(f'grad shape {dy.shape} does not match the layer output')
     if x_act is not None and x_act.shape != tuple(x_shape):
         raise AssertionError(f'activation tensor {x_act.shape} != conv input {tuple(x_shape)}')
-    dx = CP.empty(x_shape, dy.dtype)
+    dx = _like_grad(CP.empty(x_shape, dy.dtype), dy)
     _rt().call('uocr_conv2d_bwd_data', code, dy.ptr, w.ptr, dx.ptr, *dims,
                None if x_act is None else x_act.ptr, ACT_CODES[act if x_act is not None else None], float(alpha))
     return dx
@@ -80,7 +103,7 @@ def conv2d_bwd_data(dy, w, x_shape, stride, padding, x_act=None, act=None, alpha
 
 def conv2d_bwd_weight(x, dy, dw, db, stride, padding, pad_value=0.0, bias=True, accumulate=True):
     dims = _conv_dims(x.shape, dw.shape, stride, padding)
-    code = _same_dtype(x, dy, dw, db)
+    code = _same_dtype(x, dy, dw, db, grad=dy)
     _rt().call('uocr_conv2d_bwd_weight', code, x.ptr, dy.ptr, dw.ptr, db.ptr, *dims, float(pad_value),
                int(bool(bias)), int(bool(accumulate)))
 
@@ -98,8 +121,8 @@ def conv_pair_fwd(x, w1, b1, w2, b2, pad_value1=0.0, bias1=True, bias2=True, alp
 def conv_pair_bwd(x, y, dy, w1, b1, w2, dw1, db1, dw2, db2, pad_value1=0.0, bias1=True, bias2=True, alpha=0.01,
                   act2=hiplib.ACT_NONE, need_dx=True, accumulate=True):
     n, h, wd, _ = x.shape
-    code = _same_dtype(x, y, dy, w1, b1, w2, dw1, db1, dw2, db2)
-    dx = CP.empty(x.shape, x.dtype) if need_dx else None
+    code = _same_dtype(x, y, dy, w1, b1, w2, dw1, db1, dw2, db2, grad=dy)
+    dx = _like_grad(CP.empty(x.shape, x.dtype), dy) if need_dx else None
     _rt().call('uocr_conv_pair_bwd', code, x.ptr, y.ptr, dy.ptr, w1.ptr, b1.ptr, w2.ptr, dw1.ptr, db1.ptr, dw2.ptr,
                db2.ptr, dx.ptr if need_dx else None, n, h, wd, w1.shape[3], float(pad_value1), int(bool(bias1)),
                int(bool(bias2)), float(alpha), int(act2), int(bool(accumulate)))
@@ -125,8 +148,8 @@ def upconv2x_fwd(x_low, w, b, padding, bias=True, act=None, alpha=0.0):
 
 def upconv2x_bwd_data(dy, w, x_low_shape, padding, x_act=None, act=None, alpha=0.0):
     dims = _up_dims(x_low_shape, w.shape, padding)
-    code = _same_dtype(dy, w)
-    dx = CP.empty(x_low_shape, dy.dtype)
+    code = _same_dtype(dy, w, grad=dy)
+    dx = _like_grad(CP.empty(x_low_shape, dy.dtype), dy)
     _rt().call('uocr_upconv2x_bwd_data', code, dy.ptr, w.ptr, dx.ptr, *dims, None if x_act is None else x_act.ptr,
                ACT_CODES[act if x_act is not None else None], float(alpha))
     return dx
@@ -134,7 +157,7 @@ def upconv2x_bwd_data(dy, w, x_low_shape, padding, x_act=None, act=None, alpha=0
 
 def upconv2x_bwd_weight(x_low, dy, dw, db, padding, bias=True, accumulate=True):
     dims = _up_dims(x_low.shape, dw.shape, padding)
-    code = _same_dtype(x_low, dy, dw, db)
+    code = _same_dtype(x_low, dy, dw, db, grad=dy)
     _rt().call('uocr_upconv2x_bwd_weight', code, x_low.ptr, dy.ptr, dw.ptr, db.ptr, *dims, int(bool(bias)),
                int(bool(accumulate)))
 
@@ -160,7 +183,7 @@ def maxpool2d_fwd(x, ks, stride, padding, ceil_mode=False):
 def maxpool2d_bwd(dy, mask, x_shape, ks, stride, padding):
     n, h, wd, c = x_shape
     oh, ow = dy.shape[1], dy.shape[2]
-    dx = CP.empty(x_shape, dy.dtype)
+    dx = _like_grad(CP.empty(x_shape, dy.dtype), dy)
     _rt().call('uocr_maxpool2d_bwd', dy.code, dy.ptr, mask.ptr, dx.ptr, n, h, wd, c, ks[0], ks[1], stride[0],
                stride[1], padding[0], padding[1], oh, ow)
     return dx
@@ -178,7 +201,7 @@ def upsample2d_bwd(dy, x_shape, scale):
     n, h, wd, c = x_shape
     if dy.shape != (n, h * scale[0], wd * scale[1], c):
         raise AssertionError(f'grad shape {dy.shape} does not match the upsampled shape')
-    dx = CP.empty(x_shape, dy.dtype)
+    dx = _like_grad(CP.empty(x_shape, dy.dtype), dy)
     _rt().call('uocr_upsample2d_bwd', dy.code, dy.ptr, dx.ptr, n, h, wd, c, scale[0], scale[1])
     return dx
 
@@ -194,14 +217,14 @@ def act_bwd(kind, x, dy, alpha=0.0):
     code = _same_dtype(x, dy)
     if x.size != dy.size:
         raise AssertionError(f'grad size {dy.shape} != input size {x.shape}')
-    dx = CP.empty(dy.shape, dy.dtype)
+    dx = _like_grad(CP.empty(dy.shape, dy.dtype), dy)
     _rt().call('uocr_act_bwd', code, ACT_CODES[kind], float(alpha), x.ptr, dy.ptr, dx.ptr, x.size)
     return dx
 
 
 def act_bwd_from_output(kind, y, dy, alpha=0.0):
     code = _same_dtype(y, dy)
-    dx = CP.empty(dy.shape, dy.dtype)
+    dx = _like_grad(CP.empty(dy.shape, dy.dtype), dy)
     _rt().call('uocr_act_bwd_from_output', code, ACT_CODES[kind], float(alpha), y.ptr, dy.ptr, dx.ptr, y.size)
     return dx
 
@@ -222,8 +245,8 @@ def dense_bwd(x, w, dy, dw, accumulate=True, need_dx=True, x_act=None, x_alpha=0
     """`x_act`: x is the output of that (fused) activation and dx is wanted w.r.t. the activation's INPUT."""
     m, n_in = x.shape
     n_out = w.shape[1]
-    code = _same_dtype(x, w, dy, dw)
-    dx = CP.empty((m, n_in), dy.dtype) if need_dx else None
+    code = _same_dtype(x, w, dy, dw, grad=dy)
+    dx = _like_grad(CP.empty((m, n_in), dy.dtype), dy) if need_dx else None
     _rt().call('uocr_dense_bwd_act', code, x.ptr, w.ptr, dy.ptr, dx.ptr if need_dx else None, dw.ptr, m, n_in,
                n_out, int(bool(accumulate)), ACT_CODES[x_act], float(x_alpha))
     return dx
@@ -259,12 +282,12 @@ def windows_dense_bwd(x, w, dy, dw, width, accumulate=True, x_act=None, act=None
     """dw (bias row included) and the gradient w.r.t. x (times act'(x) when x is the output of a fused
     activation, as conv2d_bwd_data)."""
     dims, bias_off = _windows_dims(x.shape, w, width)
-    code = _same_dtype(x, w, dy, dw)
+    code = _same_dtype(x, w, dy, dw, grad=dy)
     if dy.shape != (dims[0] * dims[2], dims[4]):
         raise AssertionError(f'grad shape {dy.shape} does not match the layer output')
     _rt().call('uocr_conv2d_bwd_weight', code, x.ptr, dy.ptr, dw.ptr, dw.ptr + bias_off, *dims, 0.0, 1,
                int(bool(accumulate)))
-    dx = CP.empty(x.shape, dy.dtype)
+    dx = _like_grad(CP.empty(x.shape, dy.dtype), dy)
     _rt().call('uocr_conv2d_bwd_data', code, dy.ptr, w.ptr, dx.ptr, *dims, None if x_act is None else x_act.ptr,
                ACT_CODES[act if x_act is not None else None], float(alpha))
     return dx
@@ -280,7 +303,7 @@ def fixed_width_fwd(x, width):
 
 def fixed_width_bwd(dy, x_shape, width):
     n, h, wd, c = x_shape
-    dx = CP.empty(x_shape, dy.dtype)
+    dx = _like_grad(CP.empty(x_shape, dy.dtype), dy)
     _rt().call('uocr_fixed_width_bwd', dy.code, dy.ptr, dx.ptr, n, h, wd, c, width)
     return dx
 
@@ -315,7 +338,7 @@ def split(array, shapes, axis=-1):
     esz = array.t.element_size()
     for shp in shapes:
         cols = int(np.prod(shp[axis:]))
-        out = CP.empty(shp, array.dtype)
+        out = _like_grad(CP.empty(shp, array.dtype), array)
         _rt().call('uocr_copy_2d', out.code, out.ptr, cols, array.ptr + off * esz, total, rows, cols)
         outs.append(out)
         off += cols
@@ -325,7 +348,9 @@ def split(array, shapes, axis=-1):
 def add(a, b):
     if a.shape != b.shape:
         raise AssertionError(f'cannot add {a.shape} and {b.shape}')
-    out = CP.empty(a.shape, a.dtype)
+    if a.gscale != b.gscale:
+        raise HipError(f'cannot add gradients that carry different scales (2^{a.gscale} and 2^{b.gscale})')
+    out = _like_grad(CP.empty(a.shape, a.dtype), a)
     _rt().call('uocr_add', _same_dtype(a, b), a.ptr, b.ptr, out.ptr, a.size)
     return out
 
@@ -360,6 +385,15 @@ def _loss_slot():
     return CP.empty((1,), np.float64)
 
 
+def _loss_code(pred, gt, grad, kind, n):
+    """dtype code of a loss call; a float16 gradient gets its power-of-two scale here (see f16_grad_scale_log2)."""
+    code = _same_dtype(pred, gt)
+    if code == hiplib.F16 and grad is not None:
+        grad.gscale = f16_grad_scale_log2(kind, n)
+        return hiplib.f16_scaled(grad.gscale)
+    return code
+
+
 def _finish_loss(slot):
     return DeviceScalar(slot.t) if CP.lazy_losses else float(slot.t.item())
 
@@ -371,7 +405,7 @@ def seg_loss(kind, pred, gt, need_grad=True, out_act=None):
         raise AssertionError(f'ground truth {gt.shape} != prediction {pred.shape}')
     grad = CP.empty(pred.shape, pred.dtype) if need_grad else None
     slot = _loss_slot()
-    _rt().call('uocr_seg_loss', _same_dtype(pred, gt), hiplib.LOSS_DICE if kind == 'dice' else hiplib.LOSS_JACCARD,
+    _rt().call('uocr_seg_loss', _loss_code(pred, gt, grad, 'seg', h * w), hiplib.LOSS_DICE if kind == 'dice' else hiplib.LOSS_JACCARD,
                pred.ptr, gt.ptr, grad.ptr if need_grad else None, slot.ptr, n, h * w, c, ACT_CODES[out_act])
     return _finish_loss(slot), grad
 
@@ -382,7 +416,7 @@ def softmax_ce(pred, gt, need_grad=True):
         raise AssertionError(f'ground truth {gt.shape} != prediction {pred.shape}')
     grad = CP.empty(pred.shape, pred.dtype) if need_grad else None
     slot = _loss_slot()
-    _rt().call('uocr_softmax_ce', _same_dtype(pred, gt), pred.ptr, gt.ptr, grad.ptr if need_grad else None,
+    _rt().call('uocr_softmax_ce', _loss_code(pred, gt, grad, 'ce', m), pred.ptr, gt.ptr, grad.ptr if need_grad else None,
                slot.ptr, m, c)
     return _finish_loss(slot), grad
 
@@ -392,7 +426,7 @@ def sigmoid_ce(pred, gt, need_grad=True):
         raise AssertionError(f'ground truth {gt.shape} != prediction {pred.shape}')
     grad = CP.empty(pred.shape, pred.dtype) if need_grad else None
     slot = _loss_slot()
-    _rt().call('uocr_sigmoid_ce', _same_dtype(pred, gt), pred.ptr, gt.ptr, grad.ptr if need_grad else None,
+    _rt().call('uocr_sigmoid_ce', _loss_code(pred, gt, grad, 'ce', gt.shape[0]), pred.ptr, gt.ptr, grad.ptr if need_grad else None,
                slot.ptr, gt.shape[0], pred.size)
     return _finish_loss(slot), grad
 
@@ -423,22 +457,24 @@ def _range_args(ranges):
     return n, lo, hi, kind, strength
 
 
-def momentum_step_fused(w, g, v, lr, momentum, ranges, zero_grad=True):
+def momentum_step_fused(w, g, v, lr, momentum, ranges, zero_grad=True, hyper=None):
     """Regularisers of `ranges` = [((kind, strength), lo, hi), ...] (at most 4) + Momentum update + gradient
-    reset in one pass (univer_hip.h: uocr_momentum_step_fused).  Returns the regularisation loss."""
+    reset in one pass (univer_hip.h: uocr_momentum_step_fused).  Returns the regularisation loss.  `hyper`: a
+    float64 DeviceArray {lr, momentum, -, -} the kernel reads instead of the by-value arguments (HIP graphs)."""
     n, lo, hi, kind, strength = _range_args(ranges)
     slot = _loss_slot() if n else None
     _rt().call('uocr_momentum_step_fused', _same_dtype(w, g, v), w.ptr, g.ptr, v.ptr, w.size, float(lr), float(momentum),
-               n, lo, hi, kind, strength, slot.ptr if n else None, int(bool(zero_grad)))
+               n, lo, hi, kind, strength, slot.ptr if n else None, int(bool(zero_grad)),
+               None if hyper is None else hyper.ptr)
     return _finish_loss(slot) if n else 0
 
 
-def adam_step_fused(w, g, v, a, lr, beta1, beta2, eps, ranges, zero_grad=True):
+def adam_step_fused(w, g, v, a, lr, beta1, beta2, eps, ranges, zero_grad=True, hyper=None):
     n, lo, hi, kind, strength = _range_args(ranges)
     slot = _loss_slot() if n else None
     _rt().call('uocr_adam_step_fused', _same_dtype(w, g, v, a), w.ptr, g.ptr, v.ptr, a.ptr, w.size, float(lr),
                float(beta1), float(beta2), float(eps), n, lo, hi, kind, strength, slot.ptr if n else None,
-               int(bool(zero_grad)))
+               int(bool(zero_grad)), None if hyper is None else hyper.ptr)
     return _finish_loss(slot) if n else 0
 
 

@@ -69,6 +69,42 @@ class BaseOptimizer:
             flats = self.bind_pack(pack)
         return flats
 
+    # -- hyper-parameters in device memory (the fused tail kernels read them there) ---------------------------------
+    # A train step captured in a HIP graph freezes by-value kernel arguments; the reference's trainer decays lr
+    # every epoch and on every NaN rollback (my_model/trainer.py:260), so the fused kernels take lr & co. from a
+    # four-double device array that `refresh_hyper()` rewrites whenever the Python attributes have changed.
+    def _hyper_values(self):
+        return None
+
+    def hyper_array(self):
+        """The device array (created on first use on a GPU), brought up to date unless a graph is being captured."""
+        import numpy as np
+        import torch
+        values = self._hyper_values()
+        if values is None or not CP.has_device():
+            return None
+        if getattr(self, '_hyper', None) is None:
+            self._hyper = CP.copy(np.asarray(values, dtype=np.float64), np.float64)
+            self._hyper_host = tuple(values)
+        elif not torch.cuda.is_current_stream_capturing():
+            self.refresh_hyper()
+        return self._hyper
+
+    def refresh_hyper(self):
+        """Push changed hyper-parameters to the device array.  Returns True when something changed.  Every stream
+        may hold kernels that still read the old values (the nets share one optimizer), hence the device-wide
+        synchronisation -- changes happen once per epoch, not per step."""
+        import numpy as np
+        import torch
+        values = self._hyper_values()
+        if values is None or getattr(self, '_hyper', None) is None or tuple(values) == self._hyper_host:
+            return False
+        torch.cuda.synchronize()
+        self._hyper.set(np.asarray(values, dtype=np.float64))
+        torch.cuda.synchronize()
+        self._hyper_host = tuple(values)
+        return True
+
 
 class Adagrad(BaseOptimizer):
     state_names = ('accumulated',)
@@ -93,6 +129,9 @@ class Adam(BaseOptimizer):
         self.lr, self.beta1, self.beta2 = lr, beta1, beta2
         self.initials = [initial_velocity, initial_accumulated]
 
+    def _hyper_values(self):
+        return (float(self.lr), float(self.beta1), float(self.beta2), EPS)
+
     def update(self, param):
         s = self._state_of(param)
         ops.adam_step(param.value, param.grad, s.velocity, s.accumulated, self.lr, self.beta1, self.beta2, EPS)
@@ -105,7 +144,7 @@ class Adam(BaseOptimizer):
         """Regularisers + update + gradient reset in one pass over the pack (Model.train_finish)."""
         f = self._flats(pack)
         loss = ops.adam_step_fused(pack.value, pack.grad, f['velocity'], f['accumulated'], self.lr, self.beta1,
-                                   self.beta2, EPS, reg_ranges)
+                                   self.beta2, EPS, reg_ranges, hyper=self.hyper_array())
         pack.grad_dirty = False
         return loss
 
@@ -119,6 +158,9 @@ class Momentum(BaseOptimizer):
         self.velocity = 0
         self.initials = [initial_velocity]
 
+    def _hyper_values(self):
+        return (float(self.lr), float(self.momentum), 0.0, 0.0)
+
     def update(self, param):
         s = self._state_of(param)
         ops.momentum_step(param.value, param.grad, s.velocity, self.lr, self.momentum)
@@ -131,7 +173,8 @@ class Momentum(BaseOptimizer):
         """Regularisers + update + gradient reset in one pass over the pack (Model.train_finish).
         Returns the regularisation loss."""
         f = self._flats(pack)
-        loss = ops.momentum_step_fused(pack.value, pack.grad, f['velocity'], self.lr, self.momentum, reg_ranges)
+        loss = ops.momentum_step_fused(pack.value, pack.grad, f['velocity'], self.lr, self.momentum, reg_ranges,
+                                       hyper=self.hyper_array())
         pack.grad_dirty = False                     # the kernel left the gradient buffer zeroed
         return loss
 

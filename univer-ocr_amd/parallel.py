@@ -1,35 +1,45 @@
-"""Data-parallel training: one process per GPU, RCCL all-reduce (torch.distributed backend "nccl"
-on ROCm) of each model's FLAT gradient buffer (layers.ParamPack.grad) between backward and the
-L2 / optimizer step.
+"""Data-parallel training: one process per GPU, RCCL all-reduce over xGMI of the models' flat gradient
+buffers (layers.ParamPack.grad) between backward and the L2 / optimizer step -- through the C ABI
+(include/univer_hip.h: uocr_dp_init / uocr_dp_allreduce_sum / uocr_dp_broadcast / uocr_dp_finalize),
+not through torch.distributed.  torch.distributed (any backend, normally gloo) is only the channel that
+carries rank 0's 128-byte RCCL id to the other ranks; `rendezvous=` replaces it with any other channel.
 
 The reference has no multi-GPU path (no collective call sites); this is the
-MI355X-native addition named by BASELINE.json.  Page images are independent, so the batch is
-sharded by rank and the only exchange is the gradient sum:
+MI355X-native addition named by BASELINE.json, hooked where the reference's step loop has a complete
+gradient and has not yet updated (my_model/trainer.py:213-233 -> nn/model_system.py:104-118 ->
+nn/models.py:250-254).  Page images are independent, so the batch is sharded by rank and the only
+exchange is the gradient sum:
   * Dice / Jaccard sum their loss over the batch (losses.py:22-24)  -> SUM over ranks equals the
     single-GPU gradient of the global batch;
   * SoftmaxCE / SigmoidCE divide by the LOCAL batch (losses.py:54-56, 70-72) -> SUM / world;
   * L2 is added after the all-reduce (Model.compute_loss_and_gradients calls grad_sync between
     backward and regularize), so it is counted once.
-Gradient volume is <= 3.2 MB (803 395 parameters), i.e. latency-bound on xGMI: ONE collective per
-model, issued as soon as that model's backward has been enqueued.
+Gradient volume is <= 3.2 MB (803 395 parameters), i.e. latency-bound on xGMI.
 
-Where the collective runs (`side_stream`):
-  * False (default): a synchronous `dist.all_reduce` from inside the net's lane, which ProcessGroupNCCL
-    launches on the CURRENT stream -- the RCCL kernel sits in the lane between backward and the optimizer
-    tail, the other lanes keep the GPU busy, and no further hardware queue becomes active.  The GPU runs
-    about four queues at a time: with three lanes plus torch's internal NCCL stream
-    plus the event traffic between them the step went from 1.0 to 2.2 ms (measured with a one-rank RCCL
-    group, `UOCR_BENCH_FORCE_DP=1 python bench.py`), eager or graph replay alike.  Collectives of ONE
-    communicator must not run concurrently on different streams, so every net gets its own process group
-    (= its own RCCL communicator, `dist.new_group`): the lanes' collectives are independent of each other,
-    small (1-2 channels) and can be resident together, so their relative order may differ between ranks;
-  * True: `async_op=True` on torch's internal NCCL stream with the optimizer step waiting on the work, plus
-    the early bucket of the Char net -- the classic overlap scheme, right when the compute is ONE stream.
+Deadlock freedom by construction: ONE communicator, and every collective is issued from ONE stream (the
+communication lane: its own uocr_ctx) in an order that depends on nothing but the list of models --
+`flush()` sorts the requests of a step by the models' construction order -- so every rank enqueues the
+same sequence.  Lanes and the communication lane are ordered with events only (uocr_event_record /
+uocr_stream_wait_event): a net's lane records "gradient complete", the communication lane waits for it,
+reduces, records "reduced", and the net's lane waits for that before its optimizer tail.
+
+All packs are re-homed into ONE flat value buffer and ONE flat gradient buffer (`coalesce=True`: what is
+queued when flush() runs and lies next to each other goes out as one collective -- a PageTrainer step is
+then ONE all-reduce of all four nets, `bench.py --dp-single-collective`; False, the default: one
+collective per net, so a short net's optimizer tail does not wait for the longest net's backward).
+
+backend='gloo' is the rehearsal / CPU-test path (torch.distributed on host copies of the buffers, same
+queueing and ordering logic); it is never used for a measurement.
 """
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
+from .hip import lib as hiplib
 from .nn import ops
+from .nn.gpu import CP, DeviceArray
 from .nn.losses import SigmoidCrossEntropy, SoftmaxCrossEntropy
 
 
@@ -38,119 +48,243 @@ def mean_type_loss(model):
     return all(isinstance(fn, (SoftmaxCrossEntropy, SigmoidCrossEntropy)) for fn in losses)
 
 
-class DataParallel:
-    def __init__(self, models, process_group=None, overlap=True, bucket_bytes=1 << 20, side_stream=False):
+def torch_rendezvous(id_bytes, group=None):
+    """Default channel for the RCCL id: rank 0's bytes to everybody over an initialised torch.distributed
+    group (gloo or nccl).  Returns (rank, world, id_bytes)."""
+    if not dist.is_initialized():
+        raise RuntimeError('no rendezvous: initialise torch.distributed (torch.distributed.run + '
+                           'init_process_group("gloo")) or pass rendezvous=callable to DataParallel')
+    box = [id_bytes]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return dist.get_rank(group), dist.get_world_size(group), box[0]
+
+
+class _Rccl:
+    """The C-ABI communicator of this process, bound to a communication lane (ctx + stream) of the runtime."""
+    name = 'rccl'
+
+    def __init__(self, rendezvous=None, group=None):
+        rt = CP.runtime()
+        self.rt = rt
+        lib = rt.lib
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        ident = C.create_string_buffer(hiplib.DP_UNIQUE_ID_BYTES)
+        if rank == 0 or rendezvous is not None:
+            rc = lib.uocr_dp_get_unique_id(ident)
+            if rc != 0:
+                raise hiplib.HipError(f'uocr_dp_get_unique_id failed ({rc}): is librccl.so.1 on the loader path?')
+        if rendezvous is not None:
+            self.rank, self.world, raw = rendezvous(ident.raw)
+        elif dist.is_initialized():
+            self.rank, self.world, raw = torch_rendezvous(ident.raw if rank == 0 else None, group)
+        else:
+            self.rank, self.world, raw = 0, 1, ident.raw          # a ONE-rank communicator (rehearsal)
+        self.lane = rt.add_lane(workspace_mb=1)
+        with rt.lane(self.lane):
+            rt.call('uocr_dp_init', self.rank, self.world, C.c_char_p(raw))
+        self._events = []
+
+    def event(self):
+        ev = C.c_void_p()
+        if self.rt.lib.uocr_event_create(C.byref(ev)) != 0:
+            raise hiplib.HipError('uocr_event_create failed')
+        self._events.append(ev)
+        return ev
+
+    def record(self, ev):
+        """on the CURRENT ctx (the lane the caller is in)"""
+        self.rt.call('uocr_event_record', ev)
+
+    def wait(self, ev):
+        self.rt.call('uocr_stream_wait_event', ev)
+
+    def comm_lane(self):
+        return self.rt.lane(self.lane)
+
+    def all_reduce(self, array):
+        """in place SUM on the communication lane (caller is inside comm_lane())"""
+        self.rt.call('uocr_dp_allreduce_sum', array.ptr, array.size, array.code & 0xff)
+
+    def broadcast(self, array, root=0):
+        torch.cuda.synchronize()                 # construction time: whatever filled the buffer is done
+        with self.comm_lane():
+            self.rt.call('uocr_dp_broadcast', array.ptr, array.size, array.code & 0xff, root)
+            self.rt.call('uocr_stream_sync')
+
+    def scale(self, array, factor):
+        ops.scale_(array, factor)
+
+    def close(self):
+        with self.comm_lane():
+            self.rt.call('uocr_dp_finalize')
+        for ev in self._events:
+            self.rt.lib.uocr_event_destroy(ev)
+        self._events = []
+
+
+class _Gloo:
+    """torch.distributed on host tensors: CPU tests (storage-only DeviceArrays) and the several-ranks-on-one-card
+    rehearsal.  Synchronous, so the event calls are no-ops and ordering is the host's program order."""
+    name = 'gloo'
+
+    def __init__(self, group=None):
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised (launch with torch.distributed.run)')
-        self.group = process_group
-        self.world = dist.get_world_size(process_group)
-        self.rank = dist.get_rank(process_group)
-        self.overlap = overlap
-        self.side_stream = side_stream
-        self.models = list(models.values()) if isinstance(models, dict) else list(models)
-        self._pending = {}
-        self._groups = {}         # id(model) -> the model's own process group (lane-stream collectives)
-        self._early = {}          # id(model) -> work of the early bucket of the current step (None: staged path)
-        self._plans = {}          # id(model) -> (trigger node, lo, hi) of the early bucket
-        self.bucket_bytes = bucket_bytes
-        for model in self.models:
-            if model.pack is None:
-                raise RuntimeError('data parallel needs initialised models with a ParamPack')
-            value = model.pack.value.t
-            if value.is_cuda and dist.get_backend(process_group) == 'gloo':
-                host = value.cpu()
-                dist.broadcast(host, src=0, group=process_group)
-                value.copy_(host)
-            else:
-                dist.broadcast(value, src=0, group=process_group)       # identical replicas
-            model.grad_sync = self._sync
-            # (new_group is collective over the default group: same model order on every rank)
-            self._groups[id(model)] = process_group if side_stream else dist.new_group(
-                ranks=None if process_group is None else dist.get_process_group_ranks(process_group),
-                backend=dist.get_backend(process_group))
-            plan = self.early_bucket(model, bucket_bytes)
-            if plan is not None and overlap and (side_stream or dist.get_backend(process_group) == 'gloo'):
-                self._plans[id(model)] = plan
-                model.bucket_hook = self._bucket_ready
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
 
-    @staticmethod
-    def early_bucket(model, bucket_bytes):
-        """Bucketed all-reduce inside ONE net: the tail of the flat gradient buffer whose layers finish
-        their backward first (the Char net: the dense layers, 2.9 of 3.2 MB, are done before the conv
-        block's backward starts) is reduced as soon as it is final, under the rest of the backward pass.
-        Returns (trigger node, lo, hi): the suffix [lo, hi) of the pack is final once `trigger` has run
-        its backward; None when no suffix of >= bucket_bytes finishes early."""
-        pack = model.pack
-        order = {node: i for i, node in enumerate(reversed(model._plan))}
-        owner = {id(p): name for name, layer in model.layers.items() for p in layer.params().values()}
-        itemsize = pack.value.t.element_size()
-        best, ready, last = None, -1, len(order) - 1
-        for p, off, size in reversed(pack.entries):
-            ready = max(ready, order[owner[id(p)]])
-            if (pack.total - off) * itemsize >= bucket_bytes and off > 0 and ready < last:
-                if best is None or ready < best[0]:
-                    best = (ready, off)
-        if best is None:
-            return None
-        trigger = list(reversed(model._plan))[best[0]]
-        return trigger, best[1], pack.total
-
-    def _reduce(self, model, tensor):
-        """SUM all-reduce of a (slice of a) gradient buffer of `model`; returns the work to wait for, or None
-        when nothing is left to wait for (lane-stream collective; gloo staging through the host, see _sync)."""
-        group = self._groups[id(model)]
-        if tensor.is_cuda and dist.get_backend(group) == 'gloo':
-            host = tensor.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-            tensor.copy_(host)
-            return None
-        if self.side_stream:
-            return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)         # on the caller's (lane) stream
+    def event(self):
         return None
 
-    def _bucket_ready(self, model, node):
-        """Model.backward calls this after every node; the early bucket goes out when its trigger has run."""
-        trigger, lo, hi = self._plans[id(model)]
-        if node == trigger:
-            self._early[id(model)] = self._reduce(model, model.pack.grad.t[lo:hi])
+    def record(self, ev):
+        pass
 
-    def _sync(self, model):
-        """Called by Model.compute_loss_and_gradients right after backward."""
-        grad = model.pack.grad.t
-        works = []
-        if id(model) in self._early:               # the tail went out during backward: only the head is left
-            works.append(self._early.pop(id(model)))
-            grad = grad[:self._plans[id(model)][1]]
-        # (gloo with CUDA storage = rehearsal of the N > 1 path on ONE card, which RCCL refuses: _reduce
-        # stages through the host and returns None.  Never used with the nccl backend.)
-        works.append(self._reduce(model, grad))
-        works = [w for w in works if w is not None]
-        if works and self.overlap and model.defer_grad_sync:
-            self._pending[id(model)] = works       # finished later by wait(model)
+    def wait(self, ev):
+        pass
+
+    class _Here:
+        def __enter__(self):
+            return None
+
+        def __exit__(self, *exc):
+            return False
+
+    def comm_lane(self):
+        return self._Here()
+
+    def all_reduce(self, array):
+        t = array.t
+        if t.is_cuda:
+            torch.cuda.synchronize()             # (rehearsal on one card: the other lanes' gradients too)
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(host)
         else:
-            self._finish(model, works)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
-    def _finish(self, model, works):
-        for work in works or ():
-            work.wait()                            # orders the compute stream after the collective
-        if mean_type_loss(model):
-            grad = model.pack.grad
-            if grad.t.is_cuda:
-                ops.scale_(grad, 1.0 / self.world)
-            else:                                  # gloo tests on CPU storage: no HIP kernels there
-                grad.t.mul_(1.0 / self.world)
+    def broadcast(self, array, root=0):
+        t = array.t
+        if t.is_cuda:
+            host = t.cpu()
+            dist.broadcast(host, src=root, group=self.group)
+            t.copy_(host)
+        else:
+            dist.broadcast(t, src=root, group=self.group)
+
+    def scale(self, array, factor):
+        if array.t.is_cuda:
+            ops.scale_(array, factor)
+        else:
+            array.t.mul_(factor)
+
+    def close(self):
+        pass
+
+
+class DataParallel:
+    def __init__(self, models, process_group=None, overlap=True, coalesce=False, backend=None, rendezvous=None):
+        self.models = list(models.values()) if isinstance(models, dict) else list(models)
+        if not self.models or any(m.pack is None for m in self.models):
+            raise RuntimeError('data parallel needs initialised models with a ParamPack')
+        on_gpu = self.models[0].pack.value.t.is_cuda
+        if backend is None:
+            backend = 'rccl' if on_gpu else 'gloo'
+        if backend == 'rccl' and not on_gpu:
+            raise RuntimeError('the RCCL backend needs the models on a GPU')
+        self.comm = _Rccl(rendezvous, process_group) if backend == 'rccl' else _Gloo(process_group)
+        self.backend = backend
+        self.rank, self.world = self.comm.rank, self.comm.world
+        self.overlap = overlap
+        self.coalesce = coalesce
+        self.collectives = 0                     # issued so far (tests, bench diagnostics)
+        self._order = {id(m): i for i, m in enumerate(self.models)}
+        self._queue = []                         # (model, "gradient complete" event) of the current step
+        self._reduced = {}                       # id(model) -> "reduced" event its lane still has to wait for
+        self._rehome()
+        self.comm.broadcast(self.flat_value)     # identical replicas: rank 0's weights
+        self._ev_ready = {id(m): self.comm.event() for m in self.models}
+        self._ev_done = {id(m): self.comm.event() for m in self.models}
+        for model in self.models:
+            model.grad_sync = self._sync
+            model.bucket_hook = None
+
+    # -- one flat value / gradient buffer for all models ------------------------------------------------------------
+    def _rehome(self):
+        packs = [m.pack for m in self.models]
+        dtypes = {p.dtype for p in packs}
+        if len(dtypes) != 1:
+            raise RuntimeError(f'data parallel: the models\' parameter dtypes differ: {dtypes}')
+        total = sum(p.total for p in packs)
+        self.flat_value = CP.zeros((total,), packs[0].dtype)
+        self.flat_grad = CP.zeros((total,), packs[0].dtype)
+        self._slice = {}
+        off = 0
+        for model, pack in zip(self.models, packs):
+            pack.rebase(self.flat_value, self.flat_grad, off)
+            self._slice[id(model)] = (off, off + pack.total)
+            off += pack.total
+
+    def _view(self, lo, hi):
+        return DeviceArray(self.flat_grad.t[lo:hi])
+
+    # -- the step -----------------------------------------------------------------------------------------------------
+    def _sync(self, model):
+        """Called by the model right after its backward, from the model's lane: the gradient is complete once
+        everything enqueued on this lane so far has run."""
+        ev = self._ev_ready[id(model)]
+        self.comm.record(ev)
+        self._queue.append((model, ev))
+        if not (self.overlap and model.defer_grad_sync):
+            self.wait(model)
+
+    def flush(self):
+        """Issue the collectives of everything queued, on the communication lane, in construction order of
+        the models (identical on every rank whatever order the lanes were enqueued in)."""
+        if not self._queue:
+            return
+        queue = sorted(self._queue, key=lambda item: self._order[id(item[0])])
+        self._queue = []
+        runs = []                                # [(lo, hi, [models])]: neighbours merge when coalescing
+        for model, _ in queue:
+            lo, hi = self._slice[id(model)]
+            if self.coalesce and runs and runs[-1][1] == lo:
+                runs[-1] = (runs[-1][0], hi, runs[-1][2] + [model])
+            else:
+                runs.append((lo, hi, [model]))
+        ready = {id(m): ev for m, ev in queue}
+        with self.comm.comm_lane():
+            for lo, hi, members in runs:
+                for m in members:
+                    self.comm.wait(ready[id(m)])
+                self.comm.all_reduce(self._view(lo, hi))
+                self.collectives += 1
+                for m in members:
+                    if mean_type_loss(m):
+                        self.comm.scale(self._view(*self._slice[id(m)]), 1.0 / self.world)
+                done = self._ev_done[id(members[-1])]
+                self.comm.record(done)
+                for m in members:
+                    self._reduced[id(m)] = done
 
     def wait(self, model):
-        works = self._pending.pop(id(model), None)
-        if works is not None:
-            self._finish(model, works)
+        """From the model's lane, before its optimizer tail: the lane waits (on the device) for the reduction."""
+        self.flush()
+        done = self._reduced.pop(id(model), None)
+        if done is not None:
+            self.comm.wait(done)
 
     def replicas_in_sync(self, model, tol=0.0):
-        """Debug check: every rank holds the same weights."""
+        """Debug check: every rank holds the same weights (host-side compare over torch.distributed)."""
         mine = model.pack.value.t.detach().cpu().clone()
+        if not dist.is_initialized() or self.world == 1:
+            return True
         ref = mine.clone()
-        dist.broadcast(ref, src=0, group=self.group)
+        dist.broadcast(ref, src=0)
         diff = (mine - ref).abs().max()
-        dist.all_reduce(diff, op=dist.ReduceOp.MAX, group=self.group)
+        dist.all_reduce(diff, op=dist.ReduceOp.MAX)
         return float(diff.item()) <= tol
+
+    def close(self):
+        for model in self.models:
+            model.grad_sync = None
+        self.comm.close()

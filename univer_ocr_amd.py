@@ -1,8 +1,7 @@
-"""Import shim: makes the package directory `univer-ocr_amd/` (not a valid Python identifier)
-importable as `univer_ocr_amd` -- `import univer_ocr_amd.nn.layers`, etc."""
+"""`import univer_ocr_amd` -> the package directory `univer-ocr_amd/` (the name the project layout prescribes is
+not a valid Python identifier).  A module that sets `__path__` IS a package to the import system, so
+`import univer_ocr_amd.nn.layers` resolves inside that directory; nothing is executed or copied here."""
 import os as _os
 
 __path__ = [_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), 'univer-ocr_amd')]
-with open(_os.path.join(__path__[0], '__init__.py')) as _f:
-    exec(compile(_f.read(), _os.path.join(__path__[0], '__init__.py'), 'exec'))
-del _f
+__version__ = '0.2.0'
