@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: document-images/sec (fwd+bwd+optimizer) on 256x512 synthetic pages.
+"""Benchmark of the hot path: document-images/sec (fwd+bwd+optimizer) on synthetic pages.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one train step of every my_model net on one device-resident synthetic batch
-(BASELINE.json configs[2]: fwd+bwd+SGD, batch 32 per GPU, 256x512 pages): Monochrome, Paragraph and
-Line on (32,256,512,1) pages, Char on (32,32,64,1) line strips; forward, loss, backward, L2,
-optimizer update for each.  Data parallel over N GPUs = N x 32 pages per step (weak scaling), one
-RCCL all-reduce per net per step.  Rank 0 prints ONE JSON line with the whole-job images/s, the
-roofline of the dominant kernel (timed live with HIP events around each of its launches in the
-timed region) and the CPU baseline (oracle/ restatement timed on this box's host cores).
+--config train-b32 (default; BASELINE.json configs[2], the configuration the metric is quoted on):
+    one "step" = one train step of every my_model net on one device-resident synthetic batch: Monochrome,
+    Paragraph and Line on (32,256,512,1) pages, Char on (32,32,64,1) line strips; forward, loss, backward, L2,
+    SGD update for each, float32.
+--config highres-fp16 (configs[4]): Monochrome, Paragraph and Line on (8,1024,2048,1) pages per GPU, binary16
+    activations in HBM (UOCR_F16: float32 master weights, float32 accumulation, scaled activation gradients).
+--config infer-b8 (configs[1]): forward only, 8 pages 256x512 + 8 line strips per GPU, float32.
+
+Data parallel over N GPUs = N x the per-GPU batch per step (weak scaling), the gradient all-reduce through the
+C ABI's RCCL entry points (univer_hip.h: uocr_dp_*); torch.distributed (gloo) is the host-side control plane
+(rendezvous of the RCCL id, barriers, max-over-ranks of the elapsed time).  Rank 0 prints ONE JSON line with the
+whole-job images/s, the roofline of the dominant kernel (HIP events around each of its launches in the timed
+region + the same launch replayed alone), `roofline.secondary` (the wide 3x3 64->64 conv against the f32 MFMA
+peak and the pooling / activation / loss kernels against HBM, measured right after the timed loop) and the CPU
+baseline (oracle/ restatement of the reference timed on this box's host cores, same initial weights).
 """
 import argparse
 import ctypes
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,98 +36,259 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 F32_PEAK_TFLOPS = 157.3        # dense f32 MFMA peak = f32 vector peak on gfx950 (same guide, peak table)
 
+CONFIGS = {
+    'train-b32': dict(batch=32, height=256, width=512, dtype='float32', train=True,
+                      nets=('Monochrome', 'Paragraph', 'Line', 'Char'), baseline='configs[2]'),
+    'highres-fp16': dict(batch=8, height=1024, width=2048, dtype='float16', train=True,
+                         nets=('Monochrome', 'Paragraph', 'Line'), baseline='configs[4]'),
+    'infer-b8': dict(batch=8, height=256, width=512, dtype='float32', train=False,
+                     nets=('Monochrome', 'Paragraph', 'Line', 'Char'), baseline='configs[1]'),
+}
+FEEDS = {'Monochrome': ('image', 'monochrome'), 'Paragraph': ('monochrome', 'paragraph'),
+         'Line': ('monochrome', 'line'), 'Char': ('char_lines', 'char_labels')}
 
-class KernelProbe:
-    """HIP-event pairs around every launch of one C-ABI entry point whose int arguments match;
-    events are recorded on the stream the kernel is launched on (the ctx stream)."""
 
-    def __init__(self, runtime, name, match):
-        self.rt, self.name, self.match = runtime, name, match
-        self.pairs, self.pool = [], []
-        self.enabled = False
-        self._orig = runtime.call
-        runtime.call = self._call
+class Watchdog(threading.Thread):
+    """Multi-rank runs can only hang in a collective or a rendezvous; a hung run would burn the driver's whole
+    timeout.  The main thread calls beat() after every step and phase; if nothing beats for `limit` seconds the
+    process says where it was and exits non-zero (never re-execs: the GPU is initialised)."""
 
-    def _event(self):
+    def __init__(self, limit, rank):
+        super().__init__(daemon=True)
+        self.limit, self.rank = limit, rank
+        self.last, self.where = time.monotonic(), 'start'
+        self.start()
+
+    def beat(self, where):
+        self.last, self.where = time.monotonic(), where
+
+    def run(self):
+        while True:
+            time.sleep(1.0)
+            idle = time.monotonic() - self.last
+            if idle > self.limit:
+                print(f'[bench watchdog] rank {self.rank}: no progress for {idle:.0f} s in "{self.where}" '
+                      f'(limit {self.limit:.0f} s): giving up', file=sys.stderr, flush=True)
+                os._exit(3)
+
+
+class EventTimer:
+    """HIP events of the C ABI on the stream of the runtime's CURRENT ctx."""
+
+    def __init__(self, rt):
+        self.rt, self.pool = rt, []
+
+    def event(self):
         if self.pool:
             return self.pool.pop()
         ev = ctypes.c_void_p()
         assert self.rt.lib.uocr_event_create(ctypes.byref(ev)) == 0
         return ev
 
+    def elapsed_ms(self, a, b):
+        ms = ctypes.c_float()
+        assert self.rt.lib.uocr_event_elapsed_ms_sync(a, b, ctypes.byref(ms)) == 0
+        return ms.value
+
+    def time_us(self, fn, reps=10):
+        """mean duration of fn() over `reps` back-to-back calls on an otherwise idle GPU"""
+        fn()
+        self.rt.call('uocr_stream_sync')
+        a, b = self.event(), self.event()
+        self.rt.call('uocr_event_record', a)
+        for _ in range(reps):
+            fn()
+        self.rt.call('uocr_event_record', b)
+        us = self.elapsed_ms(a, b) * 1e3 / reps
+        self.pool += [a, b]
+        return us
+
+
+class KernelProbe:
+    """HIP-event pairs around every launch of one C-ABI entry point; events are recorded on the stream the
+    kernel is launched on (the ctx stream of its lane)."""
+
+    def __init__(self, runtime, name, timer):
+        self.rt, self.name, self.timer = runtime, name, timer
+        self.pairs = []
+        self.enabled = False
+        self.last_args = None
+        self._orig = runtime.call
+        runtime.call = self._call
+
     def _call(self, name, *args):
-        if self.enabled and name == self.name and self.match(args):
+        if self.enabled and name == self.name:
             self.last_args = args
-            a, b = self._event(), self._event()
+            a, b = self.timer.event(), self.timer.event()
             self._orig('uocr_event_record', a)
             self._orig(name, *args)
             self._orig('uocr_event_record', b)
             self.pairs.append((a, b))
         else:
+            if name == self.name:
+                self.last_args = args
             self._orig(name, *args)
 
-    def solo_ms(self, reps=10):
+    def solo_us(self, reps=10):
         """The same launch (same buffers) replayed alone on an otherwise idle GPU."""
-        if getattr(self, 'last_args', None) is None:
+        if self.last_args is None:
             return None
-        self._orig('uocr_stream_sync')
-        a, b = self._event(), self._event()
-        self._orig(self.name, *self.last_args)
-        self._orig('uocr_event_record', a)
-        for _ in range(reps):
-            self._orig(self.name, *self.last_args)
-        self._orig('uocr_event_record', b)
-        ms = ctypes.c_float()
-        assert self.rt.lib.uocr_event_elapsed_ms_sync(a, b, ctypes.byref(ms)) == 0
-        return ms.value / reps
+        args = self.last_args
+        return self.timer.time_us(lambda: self._orig(self.name, *args), reps)
 
-    def mean_ms(self):
-        total, ms = 0.0, ctypes.c_float()
-        for a, b in self.pairs:
-            assert self.rt.lib.uocr_event_elapsed_ms_sync(a, b, ctypes.byref(ms)) == 0
-            total += ms.value
-        return total / max(1, len(self.pairs)), len(self.pairs)
+    def mean_us(self):
+        total = sum(self.timer.elapsed_ms(a, b) for a, b in self.pairs)
+        return 1e3 * total / max(1, len(self.pairs)), len(self.pairs)
 
 
-def cpu_baseline(height, width, char_width, optimizer, lr, budget_s=12.0):
-    """The oracle (NumPy restatement of the reference, float64) on a bounded sample of the SAME
-    workload: train steps of the four nets on 2 pages + 2 line strips, host cores of this box."""
+def flat_weights(models):
+    """{net: {'<layer>/<param>': float64 array}} of the trainer's CURRENT weights (for the CPU baseline)."""
+    import numpy as np
+    out = {}
+    for name, model in models.items():
+        out[name] = {pn: np.asarray(p.value.numpy(), dtype=np.float64) for pn, p in model.params().items()}
+    return out
+
+
+def cpu_baseline(cfg, args, weights, budget_s=25.0):
+    """The oracle (float64 NumPy restatement of the reference) on a bounded sample of the SAME workload with the
+    SAME initial weights as the GPU run: train steps of the configuration's nets on `sample` pages, host cores
+    of this box; and the reference's own cost model (one Python iteration per output pixel,
+    nn/layers/convolutional.py:90-96,121-134) on one page of the Monochrome net."""
     import numpy as np
 
     from oracle import nn_oracle as O
     from univer_ocr_amd.my_model.synthetic import make_page_batch
-    sample = 2
-    data = make_page_batch(sample, height, width, char_width, seed=1234)
-    rng = np.random.default_rng(0)
-    nets = {}
-    for name in ('Monochrome', 'Paragraph', 'Line', 'Char'):
-        spec, _ = O.NET_SPECS[name]()
-        nets[name] = O.make_net(name, O.kaiming_uniform_weights(spec, rng))
-    feeds = {'Monochrome': ('image', 'monochrome'), 'Paragraph': ('monochrome', 'paragraph'),
-             'Line': ('monochrome', 'line'), 'Char': ('char_lines', 'char_labels')}
-    opts = {n: (O.MomentumState(lr, 0.0) if optimizer == 'sgd' else O.AdamState(lr)) for n in nets}
+    train = cfg['train']
+    sample = 8 if cfg['height'] * cfg['width'] <= 256 * 512 else 1
+    data = make_page_batch(sample, cfg['height'], cfg['width'], args.char_width, seed=1234)
+    warm = make_page_batch(1, 64, 128, args.char_width, seed=1)
+    nets = {name: O.make_net(name, {k: v.copy() for k, v in weights[name].items()}) for name in cfg['nets']}
 
-    def one_step():
+    def opt():
+        return O.MomentumState(args.lr, 0.0) if args.optimizer == 'sgd' else O.AdamState(args.lr)
+    opts = {n: opt() for n in nets}
+
+    def one_step(batch, record=None):
         for name, net in nets.items():
-            x, y = feeds[name]
-            net.train_step(data[x], data[y], opts[name])
-    one_step()                                   # warm-up (page-in, BLAS threads)
+            x, y = FEEDS[name]
+            if train:
+                losses, _ = net.train_step(batch[x], batch[y], opts[name])
+                if record is not None:
+                    record.setdefault(name, []).append(float(losses['output_losses'][0]))
+            else:
+                net.forward(batch[x])
+    saved = {n: {k: v.copy() for k, v in net.params.items()} for n, net in nets.items()}
+    one_step(warm)                               # page-in, BLAS thread pools (on a tiny page)
+    for n, net in nets.items():                  # the warm-up step must not change the timed run's weights
+        net.params = saved[n]
+    opts = {n: opt() for n in nets}
+    losses = {}
     steps, t0 = 0, time.perf_counter()
     while True:
-        one_step()
+        one_step(data, losses)
         steps += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or steps >= 8:
+        if el >= budget_s or steps >= 3:
             break
+    finite = all(np.isfinite(v).all() for v in losses.values())
+    assert finite, f'CPU baseline diverged (losses {losses}): it no longer measures the GPU run\'s arithmetic'
     try:
         from threadpoolctl import threadpool_info
         threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
     except Exception:   # noqa: BLE001
         threads = os.cpu_count() or 1
-    return {'value': round(sample * steps / el, 3), 'unit': 'images/s', 'cores': int(threads),
-            'host_cpus': os.cpu_count(), 'kind': 'port',
-            'sample': f'{steps} train steps of the 4 nets on {sample} pages {height}x{width} + {sample} line '
-                      f'strips 32x{char_width}, float64 NumPy oracle (im2col+BLAS), {el:.1f} s'}
+    what = 'train steps' if train else 'forward passes'
+    out = {'value': round(sample * steps / el, 3), 'unit': 'images/s', 'cores': int(threads), 'blas_threads': int(threads),
+           'host_cpus': os.cpu_count(), 'kind': 'port',
+           'sample': f'{steps} {what} of {"+".join(cfg["nets"])} on {sample} pages {cfg["height"]}x{cfg["width"]}'
+                     f'{" + %d line strips 32x%d" % (sample, args.char_width) if "Char" in cfg["nets"] else ""}, float64 '
+                     f'NumPy oracle (im2col + BLAS), the GPU run\'s initial weights, {el:.1f} s',
+           'first_losses': {n: round(v[0], 6) for n, v in losses.items()} if train else None}
+    # the reference's cost model: a Python loop over output pixels (what its NumPy mode executes)
+    name = 'Monochrome'
+    page = make_page_batch(1, 256, 512, args.char_width, seed=1234)
+    loop_net = O.make_net(name, {k: v.copy() for k, v in weights[name].items()}, loops=True)
+    t0 = time.perf_counter()
+    if train:
+        loop_net.train_step(page['image'], page['monochrome'], opt())
+    else:
+        loop_net.forward(page['image'])
+    el = time.perf_counter() - t0
+    out['reference_cost_model'] = {
+        'value': round(1.0 / el, 4), 'unit': 'images/s', 'cores': 1, 'kind': 'reference-cost-model',
+        'sample': f'1 {"train step" if train else "forward"} of the Monochrome net on one 256x512 page with the '
+                  f'convolutions as one Python iteration per output pixel (nn/layers/convolutional.py:90-96, '
+                  f'121-134: 131 072 iterations of reshape + concatenate + dot per conv and direction), {el:.1f} s'}
+    return out
+
+
+def secondary_rooflines(rt, timer, watchdog):
+    """Kernels north_star prices besides the dominant one, measured alone right after the timed loop:
+    the wide Conv2D (3x3, 64 -> 64, batch 32, 256x512: the shape of the ">= 50 % of MFMA peak on Conv2D at batch
+    32" target) against the f32 MFMA peak, pooling / activation / loss kernels against the HBM peak.
+    achieved = algorithmic flops or bytes / mean launch time."""
+    import numpy as np
+
+    from univer_ocr_amd.nn import CP, ops
+    CP.set_dtype('float32')
+    rng = np.random.default_rng(0)
+    out = []
+    n, h, w, c = 32, 256, 512, 64
+
+    def rand(shape):
+        # one image of random data from the host, replicated on the device (1 GB tensors: keep host memory small)
+        t = CP.empty(shape, np.float32)
+        slab = CP.copy(rng.standard_normal((1,) + tuple(shape[1:])).astype(np.float32))
+        for i in range(shape[0]):
+            t.t[i].copy_(slab.t[0], non_blocking=True)
+        return t
+    x = rand((n, h, w, c))
+    wt = CP.copy((rng.standard_normal((3, 3, c, c)) * 0.05).astype(np.float32))
+    b = CP.copy(rng.standard_normal(c).astype(np.float32))
+    y = ops.conv2d_fwd(x, wt, b, (1, 1), (1, 1))
+    dw, db = CP.zeros(wt.shape), CP.zeros(b.shape)
+    flop = 2.0 * n * h * w * c * 9 * c
+    for label, fn in (('fwd', lambda: ops.conv2d_fwd(x, wt, b, (1, 1), (1, 1))),
+                      ('dx', lambda: ops.conv2d_bwd_data(y, wt, x.shape, (1, 1), (1, 1))),
+                      ('dw', lambda: ops.conv2d_bwd_weight(x, y, dw, db, (1, 1), (1, 1)))):
+        us = timer.time_us(fn, 5)
+        tf = flop / us / 1e6
+        out.append({'kernel': f'Conv2D 3x3 64->64 {label}, batch 32, 256x512 (f32 MFMA implicit GEMM)', 'bound': 'mfma',
+                    'achieved': round(tf, 1), 'peak': F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(tf / F32_PEAK_TFLOPS, 3), 'launch_us': round(us, 1)})
+        watchdog.beat('secondary rooflines')
+    del x, y
+    x4 = rand((n, h, w, 4))
+    g4 = rand((n, h, w, 4))
+    lo4 = rand((n, h // 2, w // 2, 4))
+    y4, mask = ops.maxpool2d_fwd(x4, (2, 2), (2, 2), (0, 0))
+    gy4 = rand(y4.shape)
+    p1 = CP.copy(rng.random((n, h, w, 1)).astype(np.float32))
+    t1 = CP.copy((rng.random((n, h, w, 1)) > 0.5).astype(np.float32))
+    logits = CP.copy(rng.standard_normal((2048, 162)).astype(np.float32))
+    onehot = CP.copy(np.eye(162, dtype=np.float32)[rng.integers(0, 162, 2048)])
+    mb = lambda *arrs: sum(a.nbytes for a in arrs)   # noqa: E731
+    lazy, CP.lazy_losses = CP.lazy_losses, True
+    rows = (
+        ('MaxPool2D 2x2 fwd (x -> y + u8 mask)', lambda: ops.maxpool2d_fwd(x4, (2, 2), (2, 2), (0, 0)), mb(x4, y4, mask)),
+        ('MaxPool2D 2x2 bwd (dy, mask -> dx)', lambda: ops.maxpool2d_bwd(gy4, mask, x4.shape, (2, 2), (2, 2), (0, 0)),
+         mb(gy4, mask, x4)),
+        ('Relu fwd', lambda: ops.act_fwd('relu', x4), mb(x4, x4)),
+        ('LeakyRelu bwd from output', lambda: ops.act_bwd_from_output('leaky', x4, g4, 0.01), mb(x4, g4, x4)),
+        ('Upsample2D 2x fwd (4 ch)', lambda: ops.upsample2d_fwd(lo4, (2, 2)), mb(lo4, x4)),
+        ('Dice loss + grad (1 ch, output Sigmoid folded)', lambda: ops.seg_loss('dice', p1, t1, True, out_act='sigmoid'),
+         mb(p1, t1) + mb(t1, p1, p1)),
+        ('SoftmaxCE + grad (2048 x 162)', lambda: ops.softmax_ce(logits, onehot, True), mb(logits, onehot, logits)),
+    )
+    for label, fn, nbytes in rows:
+        us = timer.time_us(fn, 10)
+        gbs = nbytes / us / 1e3
+        out.append({'kernel': label, 'bound': 'hbm', 'achieved': round(gbs, 0), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(gbs / HBM_PEAK_GBS, 3), 'launch_us': round(us, 1)})
+        watchdog.beat('secondary rooflines')
+    CP.lazy_losses = lazy
+    return out
 
 
 def main():
@@ -126,38 +296,38 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=32, help='pages per GPU per step')
-    ap.add_argument('--height', type=int, default=256)
-    ap.add_argument('--width', type=int, default=512)
+    ap.add_argument('--config', default='train-b32', choices=sorted(CONFIGS))
+    ap.add_argument('--batch', type=int, default=None, help='pages per GPU per step (default: the configuration\'s)')
+    ap.add_argument('--height', type=int, default=None)
+    ap.add_argument('--width', type=int, default=None)
     ap.add_argument('--char-width', type=int, default=64)
     ap.add_argument('--optimizer', default='sgd', choices=['sgd', 'adam'])
     ap.add_argument('--lr', type=float, default=0.0015)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip roofline.secondary (the kernels measured after the loop)')
     ap.add_argument('--no-overlap', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true',
-                    help='end every step with the main stream waiting for all four net streams (default: a net starts '
+                    help='end every step with the main stream waiting for all net streams (default: a net starts '
                          'its next step as soon as ITS previous step is done; the timed region still ends with a full '
                          'device synchronisation)')
-    ap.add_argument('--dp-side-stream', action='store_true',
-                    help='N > 1: all-reduce with async_op=True on torch\'s internal NCCL stream (+ early bucket) instead of '
-                         'synchronously inside each net\'s lane (the default; the side stream is one hardware queue too many)')
+    ap.add_argument('--dp-single-collective', action='store_true',
+                    help='N > 1: ONE all-reduce per step over the flat gradient buffer of all nets (default: one per '
+                         'net, issued in a fixed order from the communication lane)')
     ap.add_argument('--no-graphs', action='store_true', help='eager launches (default: HIP graphs)')
-    ap.add_argument('--graphs', action='store_true',
-                    help='(the default) replay Paragraph, Line and Char as HIP graphs (PageTrainer(graphs=True)); '
-                         'Monochrome stays eager so that the HIP events around the dominant kernel keep working.  Host '
-                         'enqueue 1.1 -> 0.3 ms/step; under data parallelism the all-reduce is issued eagerly between a '
-                         'net\'s two graphs, from its lane (one-rank RCCL rehearsal, UOCR_BENCH_FORCE_DP=1: 0.98 ms/step '
-                         'with graphs, 1.26 ms eager -- the eager step is bound by the host)')
     ap.add_argument('--skip-input-grads', action='store_true',
                     help='DIAGNOSTIC: do not compute the gradient w.r.t. the page inputs (unused by training; the '
                          'reference computes it, and so does the default run)')
-    ap.add_argument('--solo-replay', action='store_true',
-                    help='after the timed loop replay the dominant launch alone (roofline.solo_*); off by default so '
-                         'that a rocprofv3 trace of this command averages only the in-loop launches')
     ap.add_argument('--h2d', action='store_true',
                     help='upload every batch as uint8 from pinned host memory on a copy stream and convert on the '
                          'device (PCIe-inclusive rate; flagged in metric and config, never the headline value)')
+    ap.add_argument('--step-timeout', type=float, default=120.0,
+                    help='watchdog: exit with code 3 when no step / phase completes for this many seconds')
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    for key in ('batch', 'height', 'width'):
+        if getattr(args, key) is not None:
+            cfg[key] = getattr(args, key)
+    train = cfg['train']
 
     # The contract is ONE line on stdout.  Libraries write there too (RCCL prints a version banner when the
     # communicator is created): everything but the final JSON line goes to stderr, at the descriptor level.
@@ -166,9 +336,8 @@ def main():
     os.dup2(2, 1)
 
     # One hardware queue per stream: ROCm's default is 4 queues per process for main + 3 net lanes + copy /
-    # RCCL streams, so two of them share a queue and run one after the other (1.25 -> 1.10 ms/step).  The GPU
-    # keeps 4 queues running at a time, which is why PageTrainer uses 3 lanes, not 4.  Read by the HIP runtime
-    # when it starts, hence set before torch touches the GPU.
+    # communication streams, so two of them share a queue and run one after the other (1.25 -> 1.10 ms/step).
+    # Read by the HIP runtime when it starts, hence set before torch touches the GPU.
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
     import torch
@@ -181,62 +350,66 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit('--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
         args.gpus = world
-    args.graphs = not args.no_graphs
-    # UOCR_BENCH_REHEARSAL=1: several ranks on ONE card with the gloo backend (gradients staged through the
-    # host, parallel.DataParallel) -- exercises this file's multi-rank path where RCCL would refuse two ranks
-    # on one device; never a measurement
+    watchdog = Watchdog(args.step_timeout, rank)
+    graphs = not args.no_graphs and train
+    # UOCR_BENCH_REHEARSAL=1: several ranks on ONE card, gradients through gloo staged over the host
+    # (parallel.DataParallel(backend='gloo')) -- exercises this file's multi-rank path where RCCL would refuse
+    # two ranks on one device; never a measurement
     rehearsal = os.environ.get('UOCR_BENCH_REHEARSAL') == '1'
     if rehearsal:
         local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
-    # UOCR_BENCH_FORCE_DP=1: a ONE-rank RCCL process group with the data-parallel machinery switched on
-    # (flat gradient buffers, all-reduce between the graphs, waits on the lanes) -- the closest a one-GPU box
-    # gets to the N > 1 code path with the real backend; never a measurement either
+    # UOCR_BENCH_FORCE_DP=1: a ONE-rank RCCL communicator (C ABI) with the whole data-parallel machinery on
+    # -- the closest a one-GPU box gets to the N > 1 data path; never a measurement either
     force_dp = world == 1 and os.environ.get('UOCR_BENCH_FORCE_DP') == '1'
-    if world > 1 or force_dp:
+    if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        if rehearsal:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
-        else:
-            dist.init_process_group('nccl', rank=rank, world_size=world,
-                                    device_id=torch.device('cuda', local_rank))
+        dist.init_process_group('gloo', rank=rank, world_size=world)      # host-side control plane only
+    watchdog.beat('rendezvous done')
 
     from univer_ocr_amd.my_model.synthetic import make_page_batch
     from univer_ocr_amd.my_model.trainer import PageTrainer
     from univer_ocr_amd.nn import CP
 
     CP.use_gpu(local_rank)
-    CP.set_dtype('float32')
+    CP.set_dtype(cfg['dtype'])
     CP.lazy_losses = True                        # losses stay on the device; fetched after the loop
     rt = CP.runtime()
+    timer = EventTimer(rt)
 
-    trainer = PageTrainer(args.batch, args.height, args.width, args.char_width, args.optimizer, args.lr,
-                          seed=0, overlap=not args.no_overlap, input_grads=not args.skip_input_grads,
-                          graphs=args.graphs, eager_nets=('Monochrome',),    # probed kernel stays eager
-                          pipelined=not args.no_pipeline, data_parallel=True if force_dp else None,
-                          dp_side_stream=args.dp_side_stream)
-    layers = make_page_batch(args.batch, args.height, args.width, args.char_width, seed=1234 + rank)
+    use_dp = train and (world > 1 or force_dp)
+    trainer = PageTrainer(cfg['batch'], cfg['height'], cfg['width'], args.char_width, args.optimizer, args.lr,
+                          seed=0, nets=cfg['nets'], overlap=not args.no_overlap,
+                          input_grads=not args.skip_input_grads, graphs=graphs,
+                          eager_nets=('Monochrome',),    # the probed kernel's net stays eager (events in a graph are refused)
+                          pipelined=not args.no_pipeline, data_parallel=use_dp,
+                          dp_coalesce=args.dp_single_collective, dp_backend='gloo' if rehearsal else None)
+    watchdog.beat('trainer built')
+    initial = flat_weights(trainer.models) if rank == 0 and not args.no_cpu_baseline and world == 1 else None
+    layers = make_page_batch(cfg['batch'], cfg['height'], cfg['width'], args.char_width, seed=1234 + rank)
     context = trainer.make_context(layers)       # inputs resident in HBM before the timed region
+    watchdog.beat('inputs resident')
 
-    # dominant kernel = the single longest launch of the step in the rocprofv3 trace (profiles/): the fused
-    # backward of the Monochrome block (csrc/conv_pair.hip, entry uocr_conv_pair_bwd).  It recomputes the
-    # 16-channel activation on chip, so it is bound by f32 multiply-adds, not HBM: priced in FLOP/s against
-    # the f32 peak (157.3 TF, matrix = vector rate on gfx950).  ALGORITHMIC flops = the layer-by-layer
-    # algorithm, recompute not counted: conv_2 dw, conv_2 dx, conv_1 dw (+ conv_1 dx when the page-input
-    # gradient is wanted), each 2*9*16 per pixel.
-    npix = args.batch * args.height * args.width
+    # Dominant kernel = the single longest launch of the step in the rocprofv3 trace (profiles/): the fused
+    # backward of the Monochrome block (csrc/conv_pair.hip, entry uocr_conv_pair_bwd).  float32: it recomputes the
+    # 16-channel activation on chip, so it is bound by f32 multiply-adds, priced in FLOP/s against the f32 peak
+    # (ALGORITHMIC flops = the layer-by-layer algorithm, recompute not counted: conv_2 dw, conv_2 dx, conv_1 dw
+    # (+ conv_1 dx), each 2*9*16 per pixel).  float16 (configs[4]): the configuration is the HBM-bound regime
+    # by definition, so the same launch is priced in algorithmic BYTES (x, y, dy read, dx written, 2 B each)
+    # against the HBM peak.
+    npix = cfg['batch'] * cfg['height'] * cfg['width']
     n_convs = 3 if args.skip_input_grads else 4
-    probe = KernelProbe(rt, 'uocr_conv_pair_bwd', lambda a: True)
-    dominant = {'kernel': 'fused backward of conv3x3(1->16)+LeakyReLU+conv3x3(16->1)+Sigmoid (Monochrome; '
-                          'conv_pair_bwd_kernel + its finish kernel)',
-                'flops': 2.0 * 9 * 16 * n_convs * npix,
-                'bytes': 4.0 * npix * (4 if not args.skip_input_grads else 3)}
-    traffic = None            # HBM bytes per launch from rocprofv3 PMC passes, when a profile is committed
-    tpath = os.path.join(ROOT, 'profiles', 'dominant_kernel_traffic.json')
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            traffic = json.load(f).get('hbm_bytes_per_launch')
+    esize = 2 if cfg['dtype'] == 'float16' else 4
+    if train:
+        probe = KernelProbe(rt, 'uocr_conv_pair_bwd', timer)
+        dominant = {'kernel': 'uocr_conv_pair_bwd: fused backward of conv3x3(1->16)+LeakyReLU+conv3x3(16->1)+Sigmoid '
+                              '(Monochrome; conv_pair_bwd_kernel + dx border + finish kernels)',
+                    'flops': 2.0 * 9 * 16 * n_convs * npix, 'bytes': float(esize) * npix * n_convs}
+    else:
+        probe = KernelProbe(rt, 'uocr_conv_pair_fwd', timer)
+        dominant = {'kernel': 'uocr_conv_pair_fwd: fused forward of conv3x3(1->16)+LeakyReLU+conv3x3(16->1)+Sigmoid '
+                              '(Monochrome)', 'flops': 2.0 * 9 * 16 * 2 * npix, 'bytes': float(esize) * npix * 2}
 
     def barrier():
         torch.cuda.synchronize()
@@ -254,6 +427,9 @@ def main():
     statics = {}
 
     def one_step():
+        if not train:
+            trainer.forward(context)
+            return None
         if feeder is None:
             return trainer.step(context)
         if statics:                     # graph replay: convert straight into the arrays the graphs read
@@ -264,40 +440,69 @@ def main():
         feeder.stage(layers_u8)         # start the upload of batch i+1
         return trainer.step(ctx)
 
-    if args.graphs:
+    if graphs:
         try:
             trainer.capture(context)
         except Exception as exc:                   # keep measuring: eager launches are the same computation
             print(f'[bench] HIP graph capture failed ({type(exc).__name__}: {exc}); continuing with eager launches',
                   file=sys.stderr, flush=True)
-            trainer.graphs, trainer._captured, args.graphs = False, None, False
+            trainer.graphs, trainer._captured, graphs = False, None, False
             torch.cuda.synchronize()
-        if feeder is not None and args.graphs:
+        if feeder is not None and graphs:
             statics.update(trainer.static_inputs())
-    for _ in range(args.warmup):
+    watchdog.beat('graphs captured')
+    losses = None
+    for i in range(args.warmup):
         losses = one_step()
+        watchdog.beat(f'warm-up step {i}')
     barrier()
     probe.enabled = True
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         losses = one_step()
+        watchdog.beat(f'timed step {i}')
     barrier()
     elapsed = time.perf_counter() - t0
     probe.enabled = False
+    watchdog.beat('timed region done')
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
     if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    final = {n: [float(v) for v in l['output_losses']] for n, l in losses.items()}
+        elapsed = float(t.item())
+    final = {n: [float(v) for v in l['output_losses']] for n, l in losses.items()} if losses else None
 
     if rank == 0:
-        kernel_ms, launches = probe.mean_ms()
-        achieved = dominant['flops'] / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-        solo_ms = probe.solo_ms() if args.solo_replay else None
-        images = args.batch * world * args.steps
+        kernel_us, launches = probe.mean_us()
+        solo_us = probe.solo_us()
+        watchdog.beat('solo replay done')
+
+        def priced(us):
+            if not us:
+                return None
+            if cfg['dtype'] == 'float16':
+                return dominant['bytes'] / us / 1e3          # GB/s
+            return dominant['flops'] / us / 1e6              # TFLOP/s
+        hbm_bound = cfg['dtype'] == 'float16'
+        peak = HBM_PEAK_GBS if hbm_bound else F32_PEAK_TFLOPS
+        in_loop, solo = priced(kernel_us), priced(solo_us)
+        # `achieved` / `frac`: the launch ALONE on the GPU (the kernel's own roofline; this is what the rocprofv3
+        # per-kernel average under profiles/ corresponds to).  In the timed region the nets run on three streams
+        # and share the machine: that figure is reported next to it.
+        headline = solo if solo else in_loop
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, 'profiles', 'dominant_kernel_traffic.json')
+        if os.path.exists(tpath) and args.config == 'train-b32' and cfg['batch'] == 32 and not args.skip_input_grads:
+            with open(tpath) as f:
+                rec = json.load(f)
+            traffic = rec.get('hbm_bytes_per_launch')
+            traffic_source = ('NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this '
+                              'command, committed as profiles/dominant_kernel_traffic.json (' +
+                              str(rec.get('source', 'see profiles/README.md')) + ')')
+        images = cfg['batch'] * world * args.steps
+        what = 'fwd+bwd' if train else 'fwd only'
         out = {
-            'metric': 'document-images/sec (fwd+bwd) on 256x512 synthetic pages' +
+            'metric': f'document-images/sec ({what}) on {cfg["height"]}x{cfg["width"]} synthetic pages' +
                       (' [DIAGNOSTIC: PCIe upload of every batch inside the timed region]' if args.h2d else '') +
                       (' [DIAGNOSTIC: page-input gradients not computed]' if args.skip_input_grads else ''),
             'value': round(images / elapsed, 2),
@@ -305,34 +510,55 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * elapsed / args.steps, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': {'float32': 'f32', 'float16': 'f16 storage / f32 accumulate', 'float64': 'f64'}[cfg['dtype']],
+            'data': 'synthetic',
             'config': {
-                'workload': f'BASELINE configs[2]: my_model train step (fwd+loss+bwd+L2+{args.optimizer.upper()}) of '
-                            f'Monochrome+Paragraph+Line on ({args.batch},{args.height},{args.width},1) pages and Char on '
-                            f'({args.batch},32,{args.char_width},1) line strips per GPU',
-                'batch_per_gpu': args.batch, 'global_batch': args.batch * world,
-                'page': [args.height, args.width], 'optimizer': args.optimizer,
+                'workload': f'BASELINE {cfg["baseline"]}: my_model ' +
+                            (f'train step (fwd+loss+bwd+L2+{args.optimizer.upper()})' if train else 'forward pass') +
+                            f' of {"+".join(n for n in cfg["nets"] if n != "Char")} on '
+                            f'({cfg["batch"]},{cfg["height"]},{cfg["width"]},1) pages' +
+                            (f' and Char on ({cfg["batch"]},32,{args.char_width},1) line strips' if 'Char' in cfg['nets'] else '') +
+                            ' per GPU',
+                'name': args.config,
+                'batch_per_gpu': cfg['batch'], 'global_batch': cfg['batch'] * world,
+                'page': [cfg['height'], cfg['width']], 'optimizer': args.optimizer if train else None,
                 'parallelism': f'dp{world}',
-                'grad_allreduce': ('gloo (REHEARSAL on one card)' if rehearsal else 'rccl, 1 flat buffer per net') if world > 1 else ('rccl, ONE rank (REHEARSAL)' if force_dp else None),
+                'grad_allreduce': (('gloo (REHEARSAL on one card)' if rehearsal else
+                                    'rccl through the C ABI (uocr_dp_allreduce_sum), ' +
+                                    ('ONE collective per step' if args.dp_single_collective else 'one collective per net, fixed order'))
+                                   if world > 1 else ('rccl through the C ABI, ONE rank (REHEARSAL)' if force_dp else None)),
                 'final_losses': final,
-                'h2d_inclusive': bool(args.h2d), 'input_grads': not args.skip_input_grads, 'hip_graphs': bool(args.graphs), 'pipelined_lanes': not args.no_pipeline,
+                'h2d_inclusive': bool(args.h2d), 'input_grads': not args.skip_input_grads, 'hip_graphs': bool(graphs),
+                'pipelined_lanes': not args.no_pipeline,
                 'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'default (4)'),
             },
-            'roofline': {'bound': 'mfma', 'kernel': dominant['kernel'], 'achieved': round(achieved, 2),
-                         'peak': F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / F32_PEAK_TFLOPS, 4),
-                         'traffic': traffic, 'avg_launch_us': round(kernel_ms * 1e3, 2), 'launches_timed': launches,
+            'roofline': {'bound': 'hbm' if hbm_bound else 'mfma', 'kernel': dominant['kernel'],
+                         'achieved': None if headline is None else round(headline, 2),
+                         'peak': peak, 'unit': 'GB/s' if hbm_bound else 'TFLOP/s',
+                         'frac': None if headline is None else round(headline / peak, 4),
+                         'traffic': traffic, 'traffic_source': traffic_source,
+                         'solo_launch_us': None if solo_us is None else round(solo_us, 2),
+                         'in_loop_launch_us': round(kernel_us, 2), 'in_loop_achieved': None if in_loop is None else round(in_loop, 2),
+                         'launches_timed': launches,
                          'algorithmic_flops_per_launch': dominant['flops'],
-                         'algorithmic_bytes_per_launch': dominant['bytes'],
-                         # in the timed region the four nets run on four streams, so this launch shares HBM
-                         # with other kernels; the same launch replayed alone right after the loop:
-                         'solo_launch_us': None if solo_ms is None else round(solo_ms * 1e3, 2),
-                         'solo_achieved': None if not solo_ms else round(dominant['flops'] / (solo_ms * 1e-3) / 1e12, 2)},
+                         'algorithmic_bytes_per_launch': dominant['bytes']},
         }
+        if world == 1 and not args.no_secondary:
+            del context, layers
+            trainer.join()
+            torch.cuda.synchronize()
+            out['roofline']['secondary'] = secondary_rooflines(rt, timer, watchdog)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.height, args.width, args.char_width, args.optimizer, args.lr)
+            watchdog.limit = max(watchdog.limit, 600.0)      # host-only phase: no collective can hang here
+            out['cpu_baseline'] = cpu_baseline(cfg, args, initial)
         print(json.dumps(out), file=json_out, flush=True)
-    if world > 1 or force_dp:
-        dist.barrier()
+    if trainer.dp is not None:
+        watchdog.beat('closing the communicator')
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        trainer.dp.close()
+    if world > 1:
         dist.destroy_process_group()
 
 

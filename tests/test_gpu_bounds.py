@@ -232,9 +232,12 @@ def test_fused_optimizer_tail_stays_inside_its_buffers(rt):
     kind, strength = (C.c_int * 1)(2), (C.c_double * 1)(0.01)
     slot = CP.empty((1,), np.float64)
     runtime.call('uocr_momentum_step_fused', hiplib.F32, bufs['w'].ptr, bufs['g'].ptr, bufs['v'].ptr, n, 0.01, 0.9, 1, lo,
-                 hi, kind, strength, slot.ptr, 1)
+                 hi, kind, strength, slot.ptr, 1, None)
     runtime.call('uocr_adam_step_fused', hiplib.F32, bufs['w'].ptr, bufs['g'].ptr, bufs['v'].ptr, bufs['a'].ptr, n, 0.01,
-                 0.9, 0.999, 1e-8, 1, lo, hi, kind, strength, slot.ptr, 1)
+                 0.9, 0.999, 1e-8, 1, lo, hi, kind, strength, slot.ptr, 1, None)
+    hyper = CP.copy(np.array([0.01, 0.9, 0.999, 1e-8]), np.float64)      # hyper-parameters from device memory
+    runtime.call('uocr_adam_step_fused', hiplib.F32, bufs['w'].ptr, bufs['g'].ptr, bufs['v'].ptr, bufs['a'].ptr, n, 0.0,
+                 0.0, 0.0, 0.0, 1, lo, hi, kind, strength, slot.ptr, 1, hyper.ptr)
     for name, b in bufs.items():
         b.check(name, expect_written=False)
     assert not np.any(bufs['g'].check('g', expect_written=False))

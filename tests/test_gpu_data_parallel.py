@@ -31,7 +31,7 @@ def _slice(layers, lo, hi, cw):
     return out
 
 
-def _worker(rank, world, port, results, graphs, steps, pipelined):
+def _worker(rank, world, port, results, graphs, steps, pipelined, coalesce=False):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -45,8 +45,8 @@ def _worker(rank, world, port, results, graphs, steps, pipelined):
         CP.lazy_losses = graphs
         per = BATCH // world
         trainer = PageTrainer(per, H, W, CW, optimizer='sgd', lr=0.01, seed=5 + rank, overlap=True, graphs=graphs,
-                              pipelined=pipelined)
-        assert trainer.dp is not None
+                              pipelined=pipelined, dp_backend='gloo', dp_coalesce=coalesce)
+        assert trainer.dp is not None and trainer.dp.backend == 'gloo'
         layers = make_page_batch(BATCH, H, W, CW, seed=77)
         context = trainer.make_context(_slice(layers, rank * per, (rank + 1) * per, CW))
         for _ in range(steps):
@@ -60,16 +60,19 @@ def _worker(rank, world, port, results, graphs, steps, pipelined):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('graphs,steps,pipelined', [(False, 2, False), (True, 5, False), (False, 4, True), (True, 6, True)])
-def test_two_ranks_equal_one_process_on_the_whole_batch(graphs, steps, pipelined):
+@pytest.mark.parametrize('graphs,steps,pipelined,coalesce', [(False, 2, False, False), (True, 5, False, False),
+                                                             (False, 4, True, False), (True, 6, True, False),
+                                                             (True, 6, True, True), (False, 3, False, True)])
+def test_two_ranks_equal_one_process_on_the_whole_batch(graphs, steps, pipelined, coalesce):
     """graphs=True: steps 3-5 replay the per-net HIP graphs with the all-reduce issued between them;
-    pipelined=True: no per-step join of the lanes (the bench default); both: graph replay on free-running lanes."""
+    pipelined=True: no per-step join of the lanes (the bench default); both: graph replay on free-running lanes;
+    coalesce=True: the four nets' gradients go out as ONE collective per step (bench.py --dp-single-collective)."""
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     with ctx.Manager() as manager:
         results = manager.dict()
-        mp.spawn(_worker, args=(world, port, results, graphs, steps, pipelined), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, results, graphs, steps, pipelined, coalesce), nprocs=world, join=True)
         results = dict(results)
     assert results[0][0] and results[1][0], 'replicas diverged'
     for name in results[0][1]:
@@ -93,3 +96,55 @@ def test_two_ranks_equal_one_process_on_the_whole_batch(graphs, steps, pipelined
                 assert err <= 1e-11, f'{name}: data-parallel result differs from the single-process one: {err:.2e}'
     finally:
         CP.set_dtype('float32')
+
+
+@pytest.mark.parametrize('graphs,coalesce', [(False, False), (True, False), (True, True)])
+def test_rccl_c_abi_one_rank_communicator(graphs, coalesce):
+    """The REAL data path of N > 1 -- uocr_dp_get_unique_id / uocr_dp_init / uocr_dp_broadcast /
+    uocr_dp_allreduce_sum on the communication lane, event fences to the net lanes, uocr_dp_finalize -- with the
+    only communicator one GPU allows: one rank.  A one-rank SUM is the identity, so the run must reproduce plain
+    training bit for bit; what is exercised is RCCL loading at run time, the lane / event ordering (a missing
+    fence shows up as a stale or half-written gradient) and HIP-graph replay next to the collectives."""
+    import ctypes
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    from univer_ocr_amd.my_model.trainer import PageTrainer
+    from univer_ocr_amd.nn import CP
+    CP.use_gpu(0)
+    CP.set_dtype('float32')
+    lazy, CP.lazy_losses = CP.lazy_losses, True
+    try:
+        layers = make_page_batch(BATCH, H, W, CW, seed=78)
+        weights = {}
+        for use_dp in (False, True):
+            trainer = PageTrainer(BATCH, H, W, CW, optimizer='sgd', lr=0.01, seed=9, graphs=graphs, pipelined=True,
+                                  data_parallel=use_dp, dp_backend='rccl' if use_dp else None, dp_coalesce=coalesce)
+            context = trainer.make_context(layers)
+            for _ in range(5):
+                trainer.step(context)
+            trainer.join()
+            CP.runtime().synchronize()
+            if use_dp:
+                dp = trainer.dp
+                assert dp.backend == 'rccl' and (dp.rank, dp.world) == (0, 1)
+                rank, world = ctypes.c_int(-1), ctypes.c_int(-1)
+                CP.runtime().call('uocr_dp_info', ctypes.byref(rank), ctypes.byref(world))
+                assert (rank.value, world.value) == (0, 1)
+                assert dp.collectives == 5 * (1 if coalesce else 4)
+            weights[use_dp] = {n: p.value.numpy() for m in trainer.models.values() for n, p in m.params().items()}
+            if use_dp:
+                trainer.dp.close()
+                CP.runtime().call('uocr_dp_info', ctypes.byref(rank), ctypes.byref(world))
+                assert world.value == 0                      # communicator gone
+        for name, ref in weights[False].items():
+            assert np.array_equal(ref, weights[True][name]), name
+    finally:
+        CP.lazy_losses = lazy
+
+
+def test_dp_entry_points_fail_loudly_without_init():
+    from univer_ocr_amd.hip.lib import HipError
+    from univer_ocr_amd.nn import CP
+    CP.use_gpu(0)
+    buf = CP.zeros((16,), np.float32)
+    with pytest.raises(HipError, match='before uocr_dp_init'):
+        CP.runtime().call('uocr_dp_allreduce_sum', buf.ptr, buf.size, buf.code)

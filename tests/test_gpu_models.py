@@ -358,3 +358,40 @@ def test_get_weights_single_transfer_equals_per_parameter_lists():
     per_layer = {name: layer.get_weights() for name, layer in model.layers.items() if layer.params()}
     assert packed == per_layer and 'Line/end/conv_1' in packed
     assert np.array(packed['Line/end/conv_1']['w']).shape == (5, 5, 4, 2)
+
+
+@pytest.mark.parametrize('optimizer', ['sgd', 'adam'])
+def test_graph_replay_follows_learning_rate_changes(optimizer):
+    """The reference's trainer changes optimizer.lr every epoch (my_model/trainer.py:260).  The fused optimizer
+    kernels read lr / momentum / betas from a device array (uocr_*_step_fused, hyper_dev), so a step captured in a
+    HIP graph BEFORE the change must train exactly like eager steps issued after it."""
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    from univer_ocr_amd.my_model.trainer import PageTrainer
+    from univer_ocr_amd.nn import CP
+    CP.use_gpu(0)
+    CP.set_dtype('float32')
+    lazy, CP.lazy_losses = CP.lazy_losses, True
+    try:
+        layers = make_page_batch(2, 32, 64, 16, seed=3)
+        weights = {}
+        for graphs in (False, True):
+            trainer = PageTrainer(2, 32, 64, 16, optimizer=optimizer, lr=0.01, seed=4, graphs=graphs, pipelined=True)
+            context = trainer.make_context(layers)
+            for step in range(8):
+                if step == 4:
+                    trainer.join()
+                    assert (trainer._captured is not None) == graphs       # captured with lr = 0.01 ...
+                    trainer.optimizer.lr *= 0.25                          # ... and now it changes
+                if step == 6:
+                    trainer.optimizer.lr = 0.02
+                trainer.step(context)
+            trainer.join()
+            CP.runtime().synchronize()
+            weights[graphs] = {n: p.value.numpy() for m in trainer.models.values() for n, p in m.params().items()}
+        changed = 0
+        for name, ref in weights[False].items():
+            assert np.array_equal(ref, weights[True][name]), name
+            changed += 1
+        assert changed > 10
+    finally:
+        CP.lazy_losses = lazy
