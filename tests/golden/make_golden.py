@@ -578,7 +578,63 @@ def gen_graph_models():
     save('graph_models', **out)
 
 
+def gen_model_system():
+    """ModelSystem / ModelComponent / IterableSelector (nn/model_system.py:76-167) over LISTS of differently sized
+    crops, the way the reference feeds its Line and Char nets (my_model/model.py:353-400): every list entry is its
+    own train step (weights move between the entries), the per-component losses are accumulated
+    (`output_losses` lists concatenate, `regularization_loss` adds up, model_system.py:104-118), every prediction
+    is appended to the selector's list."""
+    from components.my_model import model as mm
+    from components.nn.model_system import IterableSelector, ModelComponent, ModelSystem
+
+    r = rng(900)
+    np.random.seed(11)
+    opt = ref_opt.Momentum(lr=0.01, momentum=0)
+    line = mm.make_line((1, 32, 48, 1), opt)
+    char = mm.make_char((1, 32, 16, 1), opt)
+    set_analytic_weights(line)
+    set_analytic_weights(char)
+    crop_shapes = [(1, 32, 48, 1), (1, 48, 64, 1), (2, 64, 32, 1)]
+    strip_shapes = [(1, 32, 16, 1), (2, 32, 24, 1), (1, 32, 40, 1)]
+    out = {'crop_shapes': np.array(crop_shapes), 'strip_shapes': np.array(strip_shapes)}
+    data = {'line_X': [], 'line_y': [], 'char_X': [], 'char_y': []}
+    for i, shp in enumerate(crop_shapes):
+        data['line_X'].append(r.random(shp))
+        data['line_y'].append((r.random((*shp[:3], 2)) > 0.7).astype(float))
+        out[f'line_X{i}'], out[f'line_y{i}'] = data['line_X'][-1], data['line_y'][-1]
+    for i, shp in enumerate(strip_shapes):
+        n = shp[0] * shp[2]
+        y = np.zeros((n, 162))
+        y[np.arange(n), r.integers(0, 162, n)] = 1
+        data['char_X'].append(r.random(shp))
+        data['char_y'].append(y)
+        out[f'char_X{i}'], out[f'char_y{i}'] = data['char_X'][-1], y
+    system = ModelSystem([
+        ModelComponent('Line', line, IterableSelector('line_X', 'line_y', 'line_pred'), delist_result=True),
+        ModelComponent('Char', char, IterableSelector('char_X', 'char_y', 'char_pred'), delist_result=True)])
+    for mode in ('train1', 'train2', 'test', 'predict'):
+        context = {k: list(v) for k, v in data.items()}
+        getattr(system, mode.rstrip('12'))(context)
+        if mode != 'predict':
+            for name in ('Line', 'Char'):
+                entry = context['losses'][name]
+                out[f'{mode}/{name}/output_losses'] = np.array(entry['output_losses'])
+                if 'regularization_loss' in entry:
+                    out[f'{mode}/{name}/regularization_loss'] = np.array(entry['regularization_loss'])
+        for key in ('line_pred', 'char_pred'):
+            assert len(context[key]) == 3
+            for i, pred in enumerate(context[key]):
+                out[f'{mode}/{key}{i}'] = pred
+    for model in (line, char):
+        for pname, p in model.params().items():
+            sample_param(f'final/{pname}', p.value, out)
+    save('model_system_lists', **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'model_system':      # (adds the one fixture, leaves the others alone)
+        return gen_model_system()
+    gen_model_system()
     gen_conv()
     gen_pool_upsample()
     gen_simple_layers()

@@ -85,6 +85,33 @@ def test_config2_monochrome_train_step_batch8_vs_oracle():
         assert err <= 5e-5, f'{pn}: {err:.2e}'
 
 
+@pytest.mark.parametrize('name,tag_x,tag_y', [('Paragraph', 'monochrome', 'paragraph'), ('Line', 'monochrome', 'line'),
+                                              ('Char', 'char_lines', 'char_labels')])
+def test_config2_net_train_step_batch8_vs_oracle(name, tag_x, tag_y):
+    """The production kernels of the other three nets at the BASELINE configs[2] page size against the oracle:
+    Paragraph / Line = uocr_upconv2x_* (1 -> 1 and 4 -> 4), the 5x5 stride-2 kernels (conv_dgrad_s2,
+    conv_wgrad_s2_tiled), the Line output conv (conv_fwd_t542 / conv_wgrad_t542 / conv_dgrad_px) and the Dice kernel
+    with the folded Sigmoid at 8 x 256 x 512; Char = conv_1 (5x3 stride (2,1), 64 channels), the MFMA convs, the
+    windows + flatten + dense_1 implicit GEMM (ops.windows_dense_*), the dense block and softmax cross-entropy at
+    8 strips of 32 x 64.  One train step with SGD: prediction, losses, every parameter after the update."""
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    from univer_ocr_amd.nn import CP
+    data = make_page_batch(8, 256, 512, 64, seed=13)
+    net, model = build(name, data[tag_x].shape)
+    ref_losses, ref_pred = net.train_step(data[tag_x], data[tag_y], O.MomentumState(0.01, 0.0))
+    losses = model.train(CP.copy(data[tag_x]), CP.copy(data[tag_y]))
+    assert len(model._ups_used) == (2 if name != 'Char' else 0) and len(model._wins_used) == (name == 'Char')
+    err = rel_linf(CP.asnumpy(model.layers_outputs[0]), ref_pred)
+    assert err <= 1e-5, f'{name}: prediction {err:.2e}'
+    ref = ref_losses['output_losses'][0]
+    assert abs(float(losses['output_losses'][0]) - ref) <= 1e-5 * abs(ref)
+    assert abs(float(losses['regularization_loss']) - ref_losses['regularization_loss']) <= \
+        1e-5 * max(1.0, ref_losses['regularization_loss'])
+    for pn, p in model.params().items():
+        err = rel_linf(CP.asnumpy(p.value), net.params[pn])
+        assert err <= 5e-5, f'{pn}: {err:.2e}'
+
+
 FULL = [  # (cin, cout, kernel, stride, padding): the production kernels at 32 x 256 x 512
     (1, 16, (3, 3), (1, 1), (1, 1)), (16, 1, (3, 3), (1, 1), (1, 1)), (1, 1, (5, 5), (1, 1), (2, 2)),
     (4, 4, (5, 5), (1, 1), (2, 2)), (4, 2, (5, 5), (1, 1), (2, 2)), (1, 4, (5, 5), (2, 2), (2, 2)),

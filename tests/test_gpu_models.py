@@ -61,8 +61,11 @@ def losses_row(losses):
 
 
 @pytest.mark.parametrize('net_name', ['Monochrome', 'Paragraph', 'Line', 'Char'])
-@pytest.mark.parametrize('opt_tag', ['adam', 'sgd'])
-def test_my_model_net(net_name, opt_tag, dt):
+@pytest.mark.parametrize('opt_tag,fused', [('adam', False), ('sgd', False), ('adam', True)])
+def test_my_model_net(net_name, opt_tag, fused, dt):
+    """fused=True: the production graph (Model.enable_fusion: pair / upsample+conv / windows kernels, folded
+    activations, fused optimizer tail) with Adam, the reference trainer's optimizer, against the same golden
+    vectors (the SGD leg of the fused graph: test_fused_activation_graph_matches_reference)."""
     from univer_ocr_amd.my_model.model import NET_MAKERS
     from univer_ocr_amd.nn import CP
     from univer_ocr_amd.nn.optimizers import Adam, Momentum
@@ -71,6 +74,8 @@ def test_my_model_net(net_name, opt_tag, dt):
     model = NET_MAKERS[net_name](tuple(int(v) for v in g['in_shape']), opt)
     assert sorted(model.layers) == [str(s) for s in g['layer_names']]
     assert sorted(model.params()) == [str(s) for s in g['param_names']]
+    if fused:
+        model.enable_fusion()
     set_analytic_weights(model)
     X, y = CP.copy(g[f'{opt_tag}/X']), CP.copy(g[f'{opt_tag}/y'])
     close(model.predict(X)[0], g[f'{opt_tag}/pred0'], PASS_TOL[dt], 'pred0')
@@ -395,3 +400,51 @@ def test_graph_replay_follows_learning_rate_changes(optimizer):
         assert changed > 10
     finally:
         CP.lazy_losses = lazy
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_model_system_lists_of_differently_sized_crops(fused, dt):
+    """ModelSystem.train / test / predict with IterableSelector over LISTS of crops of different sizes -- the way
+    the reference feeds its Line and Char nets (nn/model_system.py:76-167, my_model/model.py:353-400) -- against the
+    reference's own run (golden model_system_lists.npz): per-entry train steps, accumulated losses
+    (`output_losses` concatenated, `regularization_loss` summed), one prediction per entry, final weights.
+    Every entry has another shape, so every kernel is launched with several geometries on one model."""
+    from univer_ocr_amd.my_model.model import make_char, make_line
+    from univer_ocr_amd.nn import CP
+    from univer_ocr_amd.nn.model_system import IterableSelector, ModelComponent, ModelSystem
+    from univer_ocr_amd.nn.optimizers import Momentum
+    g = load_golden('model_system_lists')
+    opt = Momentum(lr=0.01, momentum=0)
+    line = make_line(tuple(int(v) for v in g['crop_shapes'][0]), opt)
+    char = make_char(tuple(int(v) for v in g['strip_shapes'][0]), opt)
+    for model in (line, char):
+        if fused:
+            model.enable_fusion()
+        set_analytic_weights(model)
+    system = ModelSystem([
+        ModelComponent('Line', line, IterableSelector('line_X', 'line_y', 'line_pred'), delist_result=True),
+        ModelComponent('Char', char, IterableSelector('char_X', 'char_y', 'char_pred'), delist_result=True)])
+    counts = {'line': len(g['crop_shapes']), 'char': len(g['strip_shapes'])}
+
+    def fresh_context():
+        return {f'{tag}_{k}': [CP.copy(g[f'{tag}_{k}{i}']) for i in range(n)] for tag, n in counts.items() for k in 'Xy'}
+    tol = STEP_TOL[dt]
+    for mode in ('train1', 'train2', 'test', 'predict'):
+        context = fresh_context()
+        getattr(system, mode.rstrip('12'))(context)
+        if mode != 'predict':
+            for name in ('Line', 'Char'):
+                entry = context['losses'][name]
+                assert len(entry['output_losses']) == 3
+                close(np.array([float(v) for v in entry['output_losses']]), g[f'{mode}/{name}/output_losses'], tol)
+                if mode != 'test':
+                    close(np.array(float(entry['regularization_loss'])), g[f'{mode}/{name}/regularization_loss'], tol)
+        else:
+            assert set(context['prediction']) == {'Line', 'Char'}
+        for tag, n in counts.items():
+            assert len(context[f'{tag}_pred']) == n
+            for i in range(n):
+                close(context[f'{tag}_pred'][i], g[f'{mode}/{tag}_pred{i}'], tol, f'{mode}/{tag}_pred{i}')
+    for model in (line, char):
+        for pn, p in model.params().items():
+            check_sampled(pn, p.value, g, 'final', tol)

@@ -240,3 +240,35 @@ def test_fcn_chain_with_pool_and_upsample():
         close(dx, g[f'fcn_{tag}/input_grad'], 1e-11)
         for pn in net.param_names():
             close(net.grads[pn], g[f'fcn_{tag}/grad/{pn}'], 1e-11)
+
+
+def test_model_system_list_path_oracle():
+    """nn/model_system.py:104-118 over lists of differently sized crops (golden model_system_lists.npz, made by the
+    reference's ModelSystem + IterableSelector): the oracle's chains, stepped entry by entry, reproduce the
+    accumulated losses, every prediction and the final weights."""
+    g = load_golden('model_system_lists')
+    nets = {'Line': O.make_net('Line'), 'Char': O.make_net('Char')}
+    opts = {n: O.MomentumState(0.01, 0.0) for n in nets}
+    feeds = {'Line': ('line', len(g['crop_shapes'])), 'Char': ('char', len(g['strip_shapes']))}
+    for mode in ('train1', 'train2', 'test'):
+        for name, (tag, count) in feeds.items():
+            out_losses, reg = [], 0.0
+            for i in range(count):
+                X, y = g[f'{tag}_X{i}'], g[f'{tag}_y{i}']
+                if mode == 'test':
+                    losses, pred = nets[name].test(X, y)
+                else:
+                    losses, pred = nets[name].train_step(X, y, opts[name])
+                    reg += losses['regularization_loss']
+                out_losses += losses['output_losses']
+                close(pred, g[f'{mode}/{tag}_pred{i}'], 1e-10)
+            close(np.array(out_losses), g[f'{mode}/{name}/output_losses'], 1e-10)
+            if mode != 'test':
+                close(np.array(reg), g[f'{mode}/{name}/regularization_loss'], 1e-10)
+    for name, net in nets.items():
+        for pn, value in net.params.items():
+            key = f'final/{pn}'
+            if key in g.files:
+                close(value, g[key], 1e-10)
+            else:
+                close(value.reshape(-1)[::97], g[key + '@stride97'], 1e-10)
