@@ -210,7 +210,7 @@ def test_conv_pair_f16(shape, f16):
 
 @pytest.mark.parametrize('c,fold', [(1, True), (2, True), (1, False)])
 def test_seg_loss_f16_scaled_gradient(c, fold, f16):
-    """Dice on binary16 predictions: the loss itself (float64 sums of exact inputs) matches to 1e-9, the gradient
+    """Dice on binary16 predictions: the loss itself (sums of exact inputs) matches to 1e-7, the gradient
     is written times 2^k (k chosen from the page size) and matches after removing the factor."""
     from univer_ocr_amd.nn import ops
     CP = f16
@@ -225,7 +225,7 @@ def test_seg_loss_f16_scaled_gradient(c, fold, f16):
     loss, grad = ops.seg_loss('dice', CP.copy(pred), CP.copy(gt), True, out_act='sigmoid' if fold else None)
     k = grad.gscale
     assert k == ops.f16_grad_scale_log2('seg', h * w) == 8          # floor(log2(6144)) - 4
-    assert abs(float(loss) - ref_loss) <= 1e-9 * abs(ref_loss)
+    assert abs(float(loss) - ref_loss) <= 1e-7 * abs(ref_loss)
     got = CP.asnumpy(grad).astype(np.float64) / 2 ** k
     assert rel_linf(got, ref_grad) <= TOL_STORE
 

@@ -23,6 +23,8 @@
 // these kernels was issue-bound at 4 cycles per vector instruction (97 / 241 us; this one: see DESIGN.md).
 // hipcc-flags: -mllvm -amdgpu-mfma-vgpr-form=1
 // (MFMA accumulators in VGPRs: no v_accvgpr copies between the MFMAs and the VALU code that consumes them)
+#include <type_traits>
+
 #include "uocr_common.h"
 
 namespace {
@@ -234,53 +236,67 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const TA* __restrict
         __syncthreads();
         if (y0 + TH < row_end) prefetch(y0 + TH);
         const int ry = y0, rx = x0;                      // region origin; xs / gs origin one further out
+        // FULL: every position of the region lies inside the image and inside this block's band (true for all
+        // tiles but the last partial one of a band / row): the per-element masks vanish from the loop body --
+        // 12 v_cndmask and as many scalar ANDs per group of 16 positions
+        auto groups = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll 2
-        for (int k = 0; k < 8; ++k) {
-            const int gi = wv * 8 + k, r = gi >> 1, c0 = (gi & 1) * 16;
-            const float* xr = xs + r * XW + c0;
-            const float* gr = gs + r * XW + c0;
-            f32x4 z = {bias, bias, bias, bias}, s = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < 8; ++k) {
+                const int gi = wv * 8 + k, r = gi >> 1, c0 = (gi & 1) * 16;
+                const float* xr = xs + r * XW + c0;
+                const float* gr = gs + r * XW + c0;
+                f32x4 z = {bias, bias, bias, bias}, s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kc = 0; kc < 3; ++kc) {
-                z = mfma(xr[n + xoff[kc]], w1b[kc], z);
-                s = mfma(gr[n + goff[kc]], w2b[kc], s);
-            }
-            // results: channel n at positions (r, c0 + 4kq + i)
-            const int ay = ry + r;
-            const bool row_in = ay >= 0 && ay < h, row_own = row_in && ay < row_end;
-            float a[4], d[4], dn[4];
+                for (int kc = 0; kc < 3; ++kc) {
+                    z = mfma(xr[n + xoff[kc]], w1b[kc], z);
+                    s = mfma(gr[n + goff[kc]], w2b[kc], s);
+                }
+                // results: channel n at positions (r, c0 + 4kq + i)
+                const int ay = ry + r;
+                const bool row_in = ay >= 0 && ay < h, row_own = row_in && ay < row_end;
+                float a[4], d[4], dn[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = c0 + 4 * kq + i, ax = rx + c;
-                const bool inside = row_in && ax >= 0 && ax < wd;
-                const bool owned = row_own && ax >= 0 && ax < wd;
-                const float slope = z[i] >= 0.f ? 1.f : alpha;
-                a[i] = owned ? z[i] * slope : 0.f;
-                d[i] = inside ? s[i] * slope : 0.f;
-                dn[i] = owned ? d[i] : 0.f;
-                db1acc += dn[i];
-            }
+                for (int i = 0; i < 4; ++i) {
+                    const float slope = z[i] >= 0.f ? 1.f : alpha;
+                    if constexpr (FULL) {
+                        a[i] = z[i] * slope;
+                        d[i] = dn[i] = s[i] * slope;
+                    } else {
+                        const int c = c0 + 4 * kq + i, ax = rx + c;
+                        const bool inside = row_in && ax >= 0 && ax < wd;
+                        const bool owned = row_own && ax >= 0 && ax < wd;
+                        a[i] = owned ? z[i] * slope : 0.f;
+                        d[i] = inside ? s[i] * slope : 0.f;
+                        dn[i] = owned ? d[i] : 0.f;
+                    }
+                    db1acc += dn[i];
+                }
+                // (lanes n >= 9 feed rows 9..15 of the two dW^T tiles, which nobody reads: their operand is whatever
+                // the clamped tap address holds -- no select needed)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float gv = gr[i + gA], xv = xr[i + xA];
-                acc2 = mfma(tap_ok ? gv : 0.f, a[i], acc2);
-                acc1 = mfma(tap_ok ? xv : 0.f, dn[i], acc1);
-            }
-            if constexpr (DX) {
-                float* t = tr + wv * 16 * TS;
+                for (int i = 0; i < 4; ++i) {
+                    acc2 = mfma(gr[i + gA], a[i], acc2);
+                    acc1 = mfma(xr[i + xA], dn[i], acc1);
+                }
+                if constexpr (DX) {
+                    float* t = tr + wv * 16 * TS;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) t[(4 * kq + i) * TS + n] = d[i];
-                __builtin_amdgcn_wave_barrier();         // same wave: LDS executes its instructions in order
-                f32x4 u = {0.f, 0.f, 0.f, 0.f};
+                    for (int i = 0; i < 4; ++i) t[(4 * kq + i) * TS + n] = d[i];
+                    __builtin_amdgcn_wave_barrier();     // same wave: LDS executes its instructions in order
+                    f32x4 u = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kc = 0; kc < 4; ++kc) u = mfma(t[n * TS + 4 * kc + kq], w1u[kc], u);
-                __builtin_amdgcn_wave_barrier();
-                if (tap_ok) {
+                    for (int kc = 0; kc < 4; ++kc) u = mfma(t[n * TS + 4 * kc + kq], w1u[kc], u);
+                    __builtin_amdgcn_wave_barrier();
+                    if (tap_ok) {
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) us[(r * RW + c0 + 4 * kq + v) * 9 + n] = u[v];
+                        for (int v = 0; v < 4; ++v) us[(r * RW + c0 + 4 * kq + v) * 9 + n] = u[v];
+                    }
                 }
             }
-        }
+        };
+        if (y0 + RH <= row_end && x0 + RW <= wd) groups(std::true_type{});
+        else groups(std::false_type{});
         for (int p = tid; p < TH * TW; p += 256) {
             const int pr = p / TW, pc = p - pr * TW;
             if (y0 + pr < row_end && x0 + pc < wd) db2acc += gs[(pr + 1) * XW + pc + 1];
@@ -289,8 +305,34 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const TA* __restrict
             __syncthreads();
             const int tiles_y = (h + RH - 1) / RH;
             const size_t tile_id = ((size_t)blockIdx.z * tiles_y + y0 / RH) * gridDim.x + blockIdx.x;
-            for (int e = tid; e < XH * XW; e += 256) {   // the tile and the ring around it
-                const int er = e / XW - 1, ec = e - (er + 1) * XW - 1;
+            // dx[e] = sum_s U[e - s + 1, s].  Inner pixels (rows 1..RH-2, columns 1..RW-2): all nine sources lie in
+            // the tile -- nine LDS reads at compile-time offsets, no tests
+            constexpr int IH = RH - 2, IW = RW - 2;
+            for (int e = tid; e < IH * IW; e += 256) {
+                const int er = e / IW + 1, ec = e - (er - 1) * IW + 1;
+                const float* u0 = us + ((er + 1) * RW + ec + 1) * 9;       // source of s = (0, 0)
+                float v = 0.f;
+#pragma unroll
+                for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) v += u0[-(sy * RW + sx) * 9 + sy * 3 + sx];
+                const int gy = y0 + er, gx = x0 + ec;
+                if (gy < h && gx < wd) st1(dx + img + (size_t)gy * wd + gx, v);
+            }
+            // the two outer pixel frames: the tile's edge pixels (to dx, still lacking the neighbours' rings) and
+            // the ring around the tile (to the border buffer): 4 rows of XW + (RH - 2) rows of 4 = 192 elements
+            constexpr int NFRAME = 4 * XW + 4 * (RH - 2);
+            for (int k = tid; k < NFRAME; k += 256) {
+                int er, ec;
+                if (k < 4 * XW) {
+                    const int rr = k / XW;
+                    er = rr == 0 ? -1 : rr == 1 ? 0 : rr == 2 ? RH - 1 : RH;
+                    ec = k - rr * XW - 1;
+                } else {
+                    const int kk = k - 4 * XW, j = kk & 3;
+                    er = (kk >> 2) + 1;
+                    ec = j == 0 ? -1 : j == 1 ? 0 : j == 2 ? RW - 1 : RW;
+                }
                 float v = 0.f;
 #pragma unroll
                 for (int sy = 0; sy < 3; ++sy)
@@ -317,8 +359,9 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const TA* __restrict
     if (lane == 0) redb2[wv] = db2acc;
     __syncthreads();
     const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    float* out = partial + (size_t)blk * 4 * NA;
-    for (int i = tid; i < 4 * NA; i += 256) {
+    const int nblk = gridDim.x * gridDim.y * gridDim.z;
+    float* out = partial + blk;                          // partial[(q * NA + k) * nblk + blk]: the finish kernel
+    for (int i = tid; i < 4 * NA; i += 256) {            // then reads every sum's block partials contiguously
         const int q = i / NA, k = i - q * NA;
         float v = 0.f;
         if (k < 72) {
@@ -333,7 +376,7 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const TA* __restrict
         } else {
             v = redb2[0] + redb2[1] + redb2[2] + redb2[3];
         }
-        out[i] = v;
+        out[(size_t)i * nblk] = v;
     }
 }
 
@@ -345,7 +388,8 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_finish(const float* __restr
     __shared__ double smem[16];
     const int k = blockIdx.x, q = blockIdx.y;
     double s = 0.0;
-    for (int blk = threadIdx.x; blk < nblocks; blk += blockDim.x) s += (double)partial[((size_t)blk * 4 + q) * NA + k];
+    const float* src = partial + (size_t)(q * NA + k) * nblocks;
+    for (int blk = threadIdx.x; blk < nblocks; blk += blockDim.x) s += (double)src[blk];
     s = block_reduce_sum(s, smem);
     if (threadIdx.x != 0) return;
     float* dst;
@@ -366,38 +410,35 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_finish(const float* __restr
 }
 
 // dx of the tile-edge pixels += what the 8 neighbouring tiles wrote on their rings (fixed order: N, S, W, E,
-// NW, NE, SW, SE).  One thread per (tile, edge pixel): 2 * RW + 2 * (RH - 2) = 92 per tile.
+// NW, NE, SW, SE).  One block of 128 threads per tile (grid = tiles_x, tiles_y, images), thread k < 92 = edge
+// pixel k: 2 * RW + 2 * (RH - 2) per tile; tile coordinates come from the block index (the first version
+// decoded a flat index with five integer divisions per pixel and ran 19 us for 15 MB of traffic).
 template <typename TA>
-__global__ __launch_bounds__(256) void conv_pair_dx_border(const float* __restrict__ border, TA* __restrict__ dx,
+__global__ __launch_bounds__(128) void conv_pair_dx_border(const float* __restrict__ border, TA* __restrict__ dx,
                                                            int n, int h, int wd, int tiles_y, int tiles_x) {
     constexpr int EDGE = 2 * RW + 2 * (RH - 2);
-    const size_t total = (size_t)n * tiles_y * tiles_x * EDGE;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(idx % EDGE);
-        const size_t tile = idx / EDGE;
-        const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y), b = (int)(tile / ((size_t)tiles_x * tiles_y));
-        int pr, pc;
-        if (k < RW) { pr = 0; pc = k; }
-        else if (k < 2 * RW) { pr = RH - 1; pc = k - RW; }
-        else if (k < 2 * RW + RH - 2) { pr = k - 2 * RW + 1; pc = 0; }
-        else { pr = k - 2 * RW - (RH - 2) + 1; pc = RW - 1; }
-        const int gy = ty * RH + pr, gx = tx * RW + pc;
-        if (gy >= h || gx >= wd) continue;
-        const int dys[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, dxs[8] = {0, 0, -1, 1, -1, 1, -1, 1};
-        float add = 0.f;
+    const int k = threadIdx.x;
+    if (k >= EDGE) return;
+    const int tx = blockIdx.x, ty = blockIdx.y, b = blockIdx.z;
+    int pr, pc;
+    if (k < RW) { pr = 0; pc = k; }
+    else if (k < 2 * RW) { pr = RH - 1; pc = k - RW; }
+    else if (k < 2 * RW + RH - 2) { pr = k - 2 * RW + 1; pc = 0; }
+    else { pr = k - 2 * RW - (RH - 2) + 1; pc = RW - 1; }
+    const int gy = ty * RH + pr, gx = tx * RW + pc;
+    if (gy >= h || gx >= wd) return;
+    const int dys[8] = {-1, 1, 0, 0, -1, -1, 1, 1}, dxs[8] = {0, 0, -1, 1, -1, 1, -1, 1};
+    float add = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int ny = ty + dys[j], nx = tx + dxs[j];
-            if (ny < 0 || ny >= tiles_y || nx < 0 || nx >= tiles_x) continue;
-            const int er = pr - RH * dys[j], ec = pc - RW * dxs[j];          // this pixel seen from tile (ny, nx)
-            if (er < -1 || er > RH || ec < -1 || ec > RW) continue;
-            if (er >= 0 && er < RH && ec >= 0 && ec < RW) continue;          // (cannot happen for a neighbour)
-            add += border[(((size_t)b * tiles_y + ny) * tiles_x + nx) * RING + ring_index(er, ec)];
-        }
-        TA* p = dx + ((size_t)b * h + gy) * wd + gx;
-        st1(p, ld1(p) + add);
+    for (int j = 0; j < 8; ++j) {
+        const int ny = ty + dys[j], nx = tx + dxs[j];
+        const int er = pr - RH * dys[j], ec = pc - RW * dxs[j];              // this pixel seen from tile (ny, nx)
+        const bool touches = er >= -1 && er <= RH && ec >= -1 && ec <= RW && ny >= 0 && ny < tiles_y && nx >= 0 &&
+                             nx < tiles_x;
+        if (touches) add += border[(((size_t)b * tiles_y + ny) * tiles_x + nx) * RING + ring_index(er, ec)];
     }
+    TA* p = dx + ((size_t)b * h + gy) * wd + gx;
+    st1(p, ld1(p) + add);
 }
 
 // rows per block = a multiple of the tile height th giving at most max_blocks blocks (measured at
@@ -472,9 +513,8 @@ extern "C" int uocr_conv_pair_bwd(uocr_ctx* ctx, int dtype, const void* x, const
         else launch(conv_pair_bwd_kernel<false, false, TA>);
         UOCR_LAUNCH_CHECK(ctx);
         if (dx) {
-            const size_t edge_px = (size_t)n * tiles_y * strips * (2 * RW + 2 * (RH - 2));
-            hipLaunchKernelGGL((conv_pair_dx_border<TA>), dim3(uocr_blocks_for(edge_px, 256, UOCR_MAX_GRID)), dim3(256),
-                               0, ctx->stream, (const float*)border, (TA*)dx, n, h, w, tiles_y, strips);
+            hipLaunchKernelGGL((conv_pair_dx_border<TA>), dim3(strips, tiles_y, n), dim3(128), 0, ctx->stream,
+                               (const float*)border, (TA*)dx, n, h, w, tiles_y, strips);
             UOCR_LAUNCH_CHECK(ctx);
         }
     });

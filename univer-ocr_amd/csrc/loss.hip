@@ -5,6 +5,8 @@
 //   SegmentationDice2D / SegmentationJaccard2D ... losses.py:9-42
 //   SigmoidCrossEntropy .......................... losses.py:45-57
 //   SoftmaxCrossEntropy .......................... losses.py:60-73
+#include <type_traits>
+
 #include "uocr_common.h"
 
 namespace {
@@ -168,35 +170,184 @@ __global__ __launch_bounds__(256) void seg_grad_kernel(const T* __restrict__ pre
     }
 }
 
-// one wave per row: max, sum exp, grad = (p - gt)/m, row loss = -sum gt * log p
-template <typename T>
+// ---- c = 1 / 2 / 4 channels (all my_model nets): one block walks a contiguous pixel range of image b with
+// 16-byte accesses (4 float / 8 binary16 elements = V / C pixels x C channels) and keeps the three sums of every
+// channel in registers; partial[(b*C + ch)][chunk][3] as above.  The generic kernels read one channel of an
+// interleaved tensor with stride C: a quarter of every line for the Line net's two maps.
+template <typename T, int C>
+__global__ __launch_bounds__(256) void seg_partial_vec_kernel(const T* __restrict__ pred, const T* __restrict__ gt,
+                                                              double* __restrict__ partial, int hw, int nchunks) {
+    constexpr int V = 16 / (int)sizeof(T);
+    __shared__ double smem[16];
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const size_t nvec = (size_t)hw * C / V;                          // vectors per image (hw * C % V == 0: launcher)
+    const size_t per = (nvec + nchunks - 1) / nchunks;
+    const size_t v0 = (size_t)chunk * per, v1 = min(nvec, v0 + per);
+    const VecOf<T, V>* p4 = reinterpret_cast<const VecOf<T, V>*>(pred + (size_t)b * hw * C);
+    const VecOf<T, V>* g4 = reinterpret_cast<const VecOf<T, V>*>(gt + (size_t)b * hw * C);
+    // float partial sums per thread (<= 64 terms of |x| <= 1 each per trip batch), double across trips
+    double s_pg[C], s_p[C], s_g[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) s_pg[ch] = s_p[ch] = s_g[ch] = 0.0;
+    for (size_t q = v0 + threadIdx.x; q < v1; q += blockDim.x) {
+        const VecOf<T, V> pv = p4[q], gv = g4[q];
+        float a_pg[C], a_p[C], a_g[C];
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) a_pg[ch] = a_p[ch] = a_g[ch] = 0.f;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float pf = (float)pv.v[k], gf = (float)gv.v[k];
+            a_pg[k % C] += pf * gf;
+            a_p[k % C] += pf;
+            a_g[k % C] += gf;
+        }
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            s_pg[ch] += (double)a_pg[ch];
+            s_p[ch] += (double)a_p[ch];
+            s_g[ch] += (double)a_g[ch];
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+        const double t_pg = block_reduce_sum(s_pg[ch], smem);
+        const double t_p = block_reduce_sum(s_p[ch], smem);
+        const double t_g = block_reduce_sum(s_g[ch], smem);
+        if (threadIdx.x == 0) {
+            double* o = partial + ((size_t)(b * C + ch) * nchunks + chunk) * 3;
+            o[0] = t_pg;
+            o[1] = t_p;
+            o[2] = t_g;
+        }
+    }
+}
+
+template <typename T, int C, int KIND>
+__global__ __launch_bounds__(256) void seg_grad_vec_kernel(const T* __restrict__ pred, const T* __restrict__ gt,
+                                                           const double* __restrict__ partial, T* __restrict__ grad,
+                                                           double* __restrict__ loss_out, int hw, int nchunks,
+                                                           int npairs, int out_act, double gscale) {
+    constexpr int V = 16 / (int)sizeof(T);
+    __shared__ double smem[16];
+    __shared__ float coef[C][2];
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    if (chunk == 0 && b == 0) {                          // the loss: sum over all (image, channel) pairs
+        double loss = 0.0;
+        for (int q = threadIdx.x; q < npairs; q += blockDim.x) {
+            double s_pg = 0.0, s_p = 0.0, s_g = 0.0;
+            for (int k = 0; k < nchunks; ++k) {
+                const double* o = partial + ((size_t)q * nchunks + k) * 3;
+                s_pg += o[0];
+                s_p += o[1];
+                s_g += o[2];
+            }
+            double num, den;
+            seg_num_den<KIND>(s_pg, s_p, s_g, num, den);
+            loss += KIND == UOCR_LOSS_DICE ? 1.0 - 2.0 * num / den : 1.0 - num / den;   // losses.py:22,40
+        }
+        loss = block_reduce_sum(loss, smem);
+        if (threadIdx.x == 0) *loss_out = loss;
+        __syncthreads();
+    }
+    if (!grad) return;
+    if (threadIdx.x < C) {                               // nchunks <= 64: a serial sum in chunk order
+        const int ch = threadIdx.x;
+        double s_pg = 0.0, s_p = 0.0, s_g = 0.0;
+        for (int k = 0; k < nchunks; ++k) {
+            const double* o = partial + ((size_t)(b * C + ch) * nchunks + k) * 3;
+            s_pg += o[0];
+            s_p += o[1];
+            s_g += o[2];
+        }
+        double num, den, ca, cb;
+        seg_num_den<KIND>(s_pg, s_p, s_g, num, den);
+        if (KIND == UOCR_LOSS_DICE) {
+            ca = -2.0 / den;
+            cb = 2.0 * num / (den * den);
+        } else {
+            ca = -(den + num) / (den * den);
+            cb = num / (den * den);
+        }
+        // the gradient is linear in the label with these two coefficients (computed in float64, applied in
+        // float32: the label is 0 / 1 and the result is stored in float32 or binary16 anyway)
+        coef[ch][0] = (float)(ca * gscale);
+        coef[ch][1] = (float)(cb * gscale);
+    }
+    __syncthreads();
+    float ca[C], cb[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+        ca[ch] = coef[ch][0];
+        cb[ch] = coef[ch][1];
+    }
+    const size_t nvec = (size_t)hw * C / V;
+    const size_t per = (nvec + nchunks - 1) / nchunks;
+    const size_t v0 = (size_t)chunk * per, v1 = min(nvec, v0 + per);
+    const size_t base = (size_t)b * hw * C;
+    const VecOf<T, V>* p4 = reinterpret_cast<const VecOf<T, V>*>(pred + base);
+    const VecOf<T, V>* g4 = reinterpret_cast<const VecOf<T, V>*>(gt + base);
+    VecOf<T, V>* o4 = reinterpret_cast<VecOf<T, V>*>(grad + base);
+    const bool sig = out_act == UOCR_ACT_SIGMOID;
+    for (size_t q = v0 + threadIdx.x; q < v1; q += blockDim.x) {
+        const VecOf<T, V> gv = g4[q];
+        float r[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) r[k] = ca[k % C] * (float)gv.v[k] + cb[k % C];
+        if (sig) {
+            const VecOf<T, V> pv = p4[q];
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float pf = (float)pv.v[k];
+                r[k] *= pf * (1.f - pf);
+            }
+        }
+        VecOf<T, V> out;
+#pragma unroll
+        for (int k = 0; k < V; ++k) out.v[k] = (T)r[k];
+        o4[q] = out;
+    }
+}
+
+// SoftmaxCrossEntropy (losses.py:60-73).  A row of the Char net has 162 classes: one wave per row leaves 2/3 of
+// the third trip idle and, worse, did all its transcendental work in float64 (~50 instructions per exp).  Here a
+// row is handled by RL = 16 / 32 / 64 lanes (the smallest that covers it in <= 4 trips), so a wave works on
+// 64 / RL rows at once, and float32 / binary16 tensors are exponentiated in float32 (relative error 1e-7, the
+// tolerance of the float32 mode is 1e-5); the row losses are still summed in float64.  float64 tensors keep
+// float64 arithmetic throughout.
+template <typename T, typename CT, int RL>
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const T* __restrict__ pred, const T* __restrict__ gt,
                                                          T* __restrict__ grad, double* __restrict__ row_loss, int m,
                                                          int c, double gscale) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= m) return;
-    const T* x = pred + (size_t)row * c;
-    const T* g = gt + (size_t)row * c;
-    double mx = -INFINITY;
-    for (int j = lane; j < c; j += 64) mx = fmax(mx, (double)x[j]);
+    constexpr int RPW = 64 / RL;                          // rows per wave
+    const int lane = threadIdx.x & 63, sub = lane % RL;
+    const int row = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + lane / RL;
+    const bool live = row < m;
+    const int rr = live ? row : m - 1;
+    const T* x = pred + (size_t)rr * c;
+    const T* g = gt + (size_t)rr * c;
+    CT mx = -INFINITY;
+    for (int j = sub; j < c; j += RL) mx = fmax(mx, (CT)x[j]);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
-    double se = 0.0;
-    for (int j = lane; j < c; j += 64) se += exp((double)x[j] - mx);
+    for (int off = RL / 2; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off, 64));
+    CT se = 0;
+    for (int j = sub; j < c; j += RL) se += std::is_same<CT, float>::value ? (CT)expf((float)((CT)x[j] - mx)) : (CT)exp((double)((CT)x[j] - mx));
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) se += __shfl_xor(se, off, 64);
-    const double lse = log(se);
+    for (int off = RL / 2; off > 0; off >>= 1) se += __shfl_xor(se, off, 64);
+    const CT lse = std::is_same<CT, float>::value ? (CT)logf((float)se) : (CT)log((double)se);
+    const CT inv = CT(1) / se, scale = (CT)(gscale / (double)m);
     double loss = 0.0;
-    for (int j = lane; j < c; j += 64) {
-        const double z = (double)x[j] - mx;
-        const double gv = (double)g[j];
-        if (gv != 0.0) loss -= gv * (z - lse);
-        if (grad) grad[(size_t)row * c + j] = (T)((exp(z) / se - gv) / (double)m * gscale);
+    for (int j = sub; j < c; j += RL) {
+        const CT z = (CT)x[j] - mx;
+        const CT gv = (CT)g[j];
+        if (gv != CT(0)) loss -= (double)(gv * (z - lse));
+        if (grad && live) {
+            const CT e = std::is_same<CT, float>::value ? (CT)expf((float)z) : (CT)exp((double)z);
+            grad[(size_t)row * c + j] = (T)((e * inv - gv) * scale);
+        }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) loss += __shfl_xor(loss, off, 64);
-    if (lane == 0) row_loss[row] = loss;
+    for (int off = RL / 2; off > 0; off >>= 1) loss += __shfl_xor(loss, off, 64);
+    if (sub == 0 && live) row_loss[row] = loss;
 }
 
 template <typename T>
@@ -235,6 +386,39 @@ int uocr_seg_loss(uocr_ctx* ctx, int dtype, int kind, const void* pred, const vo
     double* partial = (double*)ctx->workspace;
     UOCR_REQUIRE(ctx, (size_t)hw * c < (size_t)INT32_MAX && npairs <= 65535);
     const double gscale = uocr_grad_scale(dtype);
+    const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const int elem = UOCR_DTYPE_BASE(dtype) == UOCR_F16 ? 2 : UOCR_DTYPE_BASE(dtype) == UOCR_F32 ? 4 : 8;
+    const bool vec = elem <= 4 && (c == 1 || c == 2 || c == 4) && ((size_t)hw * c * elem) % 16 == 0 && al16(pred) &&
+                     al16(gt) && (!grad || al16(grad)) && n <= 65535;
+    if (vec) {
+        // channel-interleaved 16-byte kernels; the partial layout and the order of the final sums are those of
+        // the generic kernels (only the order of additions inside a chunk differs)
+        const dim3 grid(nchunks, n);
+        auto run = [&](auto tag, auto ctag) {
+            using T = decltype(tag);
+            constexpr int C = decltype(ctag)::value;
+            hipLaunchKernelGGL((seg_partial_vec_kernel<T, C>), grid, dim3(256), 0, ctx->stream, (const T*)pred,
+                               (const T*)gt, partial, hw, nchunks);
+            const dim3 ggrid = grad ? grid : dim3(1, 1);
+            if (kind == UOCR_LOSS_DICE)
+                hipLaunchKernelGGL((seg_grad_vec_kernel<T, C, UOCR_LOSS_DICE>), ggrid, dim3(256), 0, ctx->stream,
+                                   (const T*)pred, (const T*)gt, (const double*)partial, (T*)grad, loss_out, hw, nchunks,
+                                   npairs, out_act, gscale);
+            else
+                hipLaunchKernelGGL((seg_grad_vec_kernel<T, C, UOCR_LOSS_JACCARD>), ggrid, dim3(256), 0, ctx->stream,
+                                   (const T*)pred, (const T*)gt, (const double*)partial, (T*)grad, loss_out, hw, nchunks,
+                                   npairs, out_act, gscale);
+        };
+        auto by_c = [&](auto tag) {
+            if (c == 1) run(tag, std::integral_constant<int, 1>{});
+            else if (c == 2) run(tag, std::integral_constant<int, 2>{});
+            else run(tag, std::integral_constant<int, 4>{});
+        };
+        if (elem == 4) by_c(float{});
+        else by_c(_Float16{});
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
     UOCR_DISPATCH_STORAGE(ctx, dtype, {
         hipLaunchKernelGGL((seg_partial_kernel<T>), dim3(nchunks, npairs), dim3(256), 0, ctx->stream, (const T*)pred,
                            (const T*)gt, partial, hw, c, nchunks);
@@ -261,9 +445,17 @@ int uocr_softmax_ce(uocr_ctx* ctx, int dtype, const void* pred, const void* gt, 
     int rc = uocr_need_workspace(ctx, (size_t)m * sizeof(double));
     if (rc) return rc;
     double* row_loss = (double*)ctx->workspace;
-    UOCR_DISPATCH_STORAGE(ctx, dtype, {
-        hipLaunchKernelGGL((softmax_ce_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, ctx->stream, (const T*)pred,
-                           (const T*)gt, (T*)grad, row_loss, m, c, uocr_grad_scale(dtype));
+    const double gscale = uocr_grad_scale(dtype);
+    UOCR_DISPATCH_ACT(ctx, dtype, {
+        auto launch = [&](auto rl_tag) {
+            constexpr int RL = decltype(rl_tag)::value;
+            const int rows_per_block = 4 * (64 / RL);
+            hipLaunchKernelGGL((softmax_ce_kernel<TS, T, RL>), dim3((m + rows_per_block - 1) / rows_per_block), dim3(256),
+                               0, ctx->stream, (const TS*)pred, (const TS*)gt, (TS*)grad, row_loss, m, c, gscale);
+        };
+        if (c <= 64) launch(std::integral_constant<int, 16>{});
+        else if (c <= 128) launch(std::integral_constant<int, 32>{});
+        else launch(std::integral_constant<int, 64>{});
         UOCR_LAUNCH_CHECK(ctx);
     });
     return uocr_finish_sum(ctx, row_loss, m, 1.0 / (double)m, loss_out, 0);
