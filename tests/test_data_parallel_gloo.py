@@ -111,3 +111,39 @@ def test_flat_gradient_allreduce_world2(coalesce):
         assert out['char_grad'] == 15.0 and out['para_grad'] == 15.0 and out['mono_grad2'] == 3.0
         assert out['drained']
         assert out['sync1'] is False
+
+
+def _rank_mean_worker(rank, world, port, results):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from univer_ocr_amd.my_model.trainer import Losses, Trainer
+
+        class DP:
+            pass
+        dp = DP()
+        dp.rank, dp.world = rank, world
+        trainer = Trainer(None, None, {}, [], [0], data_parallel=dp)
+        losses = Losses(['A', 'B'], {'A': 1, 'B': 2})
+        losses.reset()
+        losses.train({'A': {'output_losses': [1.0 + rank]}, 'B': {'output_losses': [10.0 * (rank + 1), 2.0]}})
+        losses.validation({'A': {'output_losses': [3.0 - rank]}, 'B': {'output_losses': [4.0, 8.0 * rank]}})
+        losses.normalize(1, 1)
+        trainer._rank_mean(losses)
+        results[rank] = (losses.train_losses, losses.val_losses)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_averages_epoch_losses_over_ranks():
+    """Trainer(data_parallel=...)._rank_mean: every rank ends an epoch with the SAME loss tables (the mean over the
+    ranks), so `get_better_weights` and the NaN rollback take the same decisions everywhere."""
+    world, port = 2, _free_port()
+    with mp.Manager() as manager:
+        results = manager.dict()
+        mp.spawn(_rank_mean_worker, args=(world, port, results), nprocs=world, join=True)
+        results = dict(results)
+    assert results[0] == results[1]
+    train, val = results[0]
+    assert train == {'A': [1.5], 'B': [15.0, 2.0]} and val == {'A': [2.5], 'B': [4.0, 4.0]}

@@ -123,3 +123,33 @@ def test_page_feeder_into_static_graph_inputs():
         assert results[0] == results[1]
     finally:
         CP.lazy_losses = lazy
+
+
+def test_train_py_data_parallel_two_ranks(tmp_path):
+    """`torchrun --nproc-per-node 2 train.py`: the reference's step loop (my_model/trainer.py:213-233 ->
+    nn/model_system.py:104-118 -> nn/models.py:250-254) trained data-parallel -- every rank its own pages, the
+    gradients all-reduced inside Model.train, epoch losses averaged over the ranks, rank 0 writing
+    model_weights.json.  Two ranks share the one card here, so the gradient exchange goes through gloo
+    (UOCR_DP_BACKEND=gloo); on a node with one GPU per rank the same code path runs the RCCL entry points."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    weights_path = tmp_path / 'model_weights.json'
+    env = dict(os.environ, UOCR_DP_BACKEND='gloo', UOCR_WEIGHTS=str(weights_path), UOCR_EPOCHS_SCALE='0.011',
+               UOCR_TRAIN_PAGE='32x64', UOCR_DUMP_FINAL_WEIGHTS=str(tmp_path / 'final'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(root, 'train.py'), 'True']
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    weights = json.loads(weights_path.read_text())
+    assert 'Monochrome/conv_1' in weights and 'Char/dense_block/dense_3' in weights
+    # the replicas ended with identical weights (each rank dumps its final ones)
+    finals = [np.load(str(tmp_path / f'final.rank{r}.npz')) for r in (0, 1)]
+    assert set(finals[0].files) == set(finals[1].files) and len(finals[0].files) > 20
+    for key in finals[0].files:
+        assert np.array_equal(finals[0][key], finals[1][key]), key

@@ -50,10 +50,15 @@ def _init_data_parallel():
 
 
 def train_model(use_gpu=True, show_progress_bar=False, save_train_progress=False, epochs_scale=None,
-                batch=1, height=256, width=512, dp_backend=None):
+                batch=1, height=None, width=None, dp_backend=None):
     if not use_gpu:
         CP.use_cpu()          # raises: the NumPy path is the reference itself
     rank, world, local_rank = _init_data_parallel()
+    if height is None or width is None:              # UOCR_TRAIN_PAGE=HxW: page size of the synthetic data set
+        height, width = (int(v) for v in os.environ.get('UOCR_TRAIN_PAGE', '256x512').split('x'))
+    if local_rank is not None and os.environ.get('UOCR_DP_BACKEND') == 'gloo':
+        import torch
+        local_rank %= max(1, torch.cuda.device_count())      # rehearsal: the ranks share the cards there are
     CP.use_gpu(local_rank)
     info = CP.runtime().device_info()
     message(f'Using GPU\nname = {info["name"]}\nmultiProcessorCount = {info["cu_count"]}\n'
@@ -77,7 +82,7 @@ def train_model(use_gpu=True, show_progress_bar=False, save_train_progress=False
         message(f'Input shape: {input_shape}; parameters: {sum(m.count_parameters() for m in models.values())}')
 
         def save_weights(better, models=models):
-            merged = load_weights()
+            merged = load_weights() if os.path.exists(MODEL_WEIGHTS_FILE_PATH) else {}
             for name, model in models.items():
                 if name in better:
                     merged.update(model.get_weights())
@@ -86,10 +91,17 @@ def train_model(use_gpu=True, show_progress_bar=False, save_train_progress=False
         dp = None
         if world > 1:
             from ..parallel import DataParallel
-            dp = DataParallel(models, overlap=False, backend=dp_backend)    # rank 0's weights everywhere
+            # rank 0's weights everywhere; UOCR_DP_BACKEND=gloo: several ranks on one card (rehearsal)
+            dp = DataParallel(models, overlap=False, backend=dp_backend or os.environ.get('UOCR_DP_BACKEND'))
         trainer = Trainer(model_system, make_context_maker(mode), models, train_set, val_set, tracker,
                           show_progress_bar, optimizer, lr_step, save_weights, data_parallel=dp)
         results[mode.name] = trainer.train(epochs)
         if dp is not None:
             dp.close()
+        final_models = models
+    dump = os.environ.get('UOCR_DUMP_FINAL_WEIGHTS')     # tests: every rank's final weights, to compare replicas
+    if dump:
+        import numpy as np
+        np.savez(f'{dump}.rank{rank}.npz', **{n: p.value.numpy() for m in final_models.values()
+                                              for n, p in m.params().items()})
     return results
