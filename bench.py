@@ -379,12 +379,26 @@ def main():
     timer = EventTimer(rt)
 
     use_dp = train and (world > 1 or force_dp)
-    trainer = PageTrainer(cfg['batch'], cfg['height'], cfg['width'], args.char_width, args.optimizer, args.lr,
-                          seed=0, nets=cfg['nets'], overlap=not args.no_overlap,
-                          input_grads=not args.skip_input_grads, graphs=graphs,
-                          eager_nets=('Monochrome',),    # the probed kernel's net stays eager (events in a graph are refused)
-                          pipelined=not args.no_pipeline, data_parallel=use_dp,
-                          dp_coalesce=args.dp_single_collective, dp_backend='gloo' if rehearsal else None)
+    def build_trainer(dp_backend):
+        return PageTrainer(cfg['batch'], cfg['height'], cfg['width'], args.char_width, args.optimizer, args.lr,
+                           seed=0, nets=cfg['nets'], overlap=not args.no_overlap,
+                           input_grads=not args.skip_input_grads, graphs=graphs,
+                           eager_nets=('Monochrome',),    # the probed kernel's net stays eager (events in a graph are refused)
+                           pipelined=not args.no_pipeline, data_parallel=use_dp,
+                           dp_coalesce=args.dp_single_collective, dp_backend=dp_backend)
+    dp_fallback = None
+    try:
+        trainer = build_trainer('gloo' if rehearsal else None)
+    except Exception as exc:       # noqa: BLE001
+        if not (use_dp and world > 1 and not rehearsal):
+            raise
+        # The RCCL communicator could not be created (library missing, ncclCommInitRank failed ...): a number with
+        # the gradients staged through the host (gloo) and a LOUD flag beats no number -- config.grad_allreduce
+        # says so and the JSON line carries the error.  All ranks take the same branch (the failure is collective).
+        dp_fallback = f'{type(exc).__name__}: {exc}'
+        print(f'[bench] rank {rank}: RCCL data-parallel setup failed ({dp_fallback}); FALLING BACK to gloo staging',
+              file=sys.stderr, flush=True)
+        trainer = build_trainer('gloo')
     watchdog.beat('trainer built')
     initial = flat_weights(trainer.models) if rank == 0 and not args.no_cpu_baseline and world == 1 else None
     layers = make_page_batch(cfg['batch'], cfg['height'], cfg['width'], args.char_width, seed=1234 + rank)
@@ -499,6 +513,15 @@ def main():
             traffic_source = ('NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this '
                               'command, committed as profiles/dominant_kernel_traffic.json (' +
                               str(rec.get('source', 'see profiles/README.md')) + ')')
+        if dp_fallback:
+            allreduce_desc = f'FALLBACK: gloo through the host, RCCL setup failed: {dp_fallback}'
+        elif world > 1 and rehearsal:
+            allreduce_desc = 'gloo (REHEARSAL on one card)'
+        elif world > 1:
+            allreduce_desc = 'rccl through the C ABI (uocr_dp_allreduce_sum), ' + (
+                'ONE collective per step' if args.dp_single_collective else 'one collective per net, fixed order')
+        else:
+            allreduce_desc = 'rccl through the C ABI, ONE rank (REHEARSAL)' if force_dp else None
         images = cfg['batch'] * world * args.steps
         what = 'fwd+bwd' if train else 'fwd only'
         out = {
@@ -523,10 +546,7 @@ def main():
                 'batch_per_gpu': cfg['batch'], 'global_batch': cfg['batch'] * world,
                 'page': [cfg['height'], cfg['width']], 'optimizer': args.optimizer if train else None,
                 'parallelism': f'dp{world}',
-                'grad_allreduce': (('gloo (REHEARSAL on one card)' if rehearsal else
-                                    'rccl through the C ABI (uocr_dp_allreduce_sum), ' +
-                                    ('ONE collective per step' if args.dp_single_collective else 'one collective per net, fixed order'))
-                                   if world > 1 else ('rccl through the C ABI, ONE rank (REHEARSAL)' if force_dp else None)),
+                'grad_allreduce': allreduce_desc,
                 'final_losses': final,
                 'h2d_inclusive': bool(args.h2d), 'input_grads': not args.skip_input_grads, 'hip_graphs': bool(graphs),
                 'pipelined_lanes': not args.no_pipeline,

@@ -148,3 +148,45 @@ def test_dp_entry_points_fail_loudly_without_init():
     buf = CP.zeros((16,), np.float32)
     with pytest.raises(HipError, match='before uocr_dp_init'):
         CP.runtime().call('uocr_dp_allreduce_sum', buf.ptr, buf.size, buf.code)
+
+
+def _one_rank_group_worker(rank, world, port, results):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from univer_ocr_amd.my_model.synthetic import make_page_batch
+        from univer_ocr_amd.my_model.trainer import PageTrainer
+        from univer_ocr_amd.nn import CP
+        CP.use_gpu(0)
+        CP.set_dtype('float32')
+        CP.lazy_losses = True
+        # data_parallel=True + an initialised torch.distributed group: the RCCL id goes through
+        # parallel.torch_rendezvous (broadcast_object_list over gloo), exactly as under torch.distributed.run
+        trainer = PageTrainer(2, 32, 64, 16, optimizer='sgd', lr=0.01, seed=3, graphs=True, pipelined=True,
+                              data_parallel=True, dp_backend='rccl')
+        context = trainer.make_context(make_page_batch(2, 32, 64, 16, seed=9))
+        for _ in range(4):
+            losses = trainer.step(context)
+        trainer.join()
+        results[rank] = (trainer.dp.backend, trainer.dp.world, trainer.dp.collectives,
+                         {n: float(l['output_losses'][0]) for n, l in losses.items()})
+        trainer.dp.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_id_rendezvous_through_torch_distributed():
+    """The launch path of `torch.distributed.run`: gloo process group for the host side, the RCCL id broadcast
+    over it, the communicator created from it -- with the one rank a single GPU allows."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    with ctx.Manager() as manager:
+        results = manager.dict()
+        mp.spawn(_one_rank_group_worker, args=(1, port, results), nprocs=1, join=True)
+        results = dict(results)
+    backend, world, collectives, losses = results[0]
+    assert (backend, world, collectives) == ('rccl', 1, 16)
+    assert all(np.isfinite(v) for v in losses.values()) and set(losses) == {'Monochrome', 'Paragraph', 'Line', 'Char'}

@@ -89,6 +89,7 @@ class PageTrainer:
             order += [n for n in self.models if n not in order]
             self.dp = DataParallel({n: self.models[n] for n in order}, overlap=overlap, coalesce=dp_coalesce,
                                    backend=dp_backend)
+            self.dp_backend = self.dp.backend
             for model in self.models.values():
                 model.defer_grad_sync = overlap
 
