@@ -8,7 +8,10 @@ import json
 import os
 import shutil
 
+import sys
+
 R, P = 'gpurun_out/refresh', 'profiles'
+TAG = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 
 
 def latest(pattern):
@@ -23,8 +26,8 @@ def part(name):
 
 
 def main():
-    shutil.copy(latest(f'{R}/stats/*/*_kernel_stats.csv'), f'{P}/r01_rocprofv3_kernel_stats.csv')
-    rows = list(csv.DictReader(open(f'{P}/r01_rocprofv3_kernel_stats.csv')))
+    shutil.copy(latest(f'{R}/stats/*/*_kernel_stats.csv'), f'{P}/{TAG}_rocprofv3_kernel_stats.csv')
+    rows = list(csv.DictReader(open(f'{P}/{TAG}_rocprofv3_kernel_stats.csv')))
     steps = 25
     total = sum(float(r['TotalDurationNs']) for r in rows)
     calls = sum(int(r['Calls']) for r in rows)
@@ -33,9 +36,9 @@ def main():
         name = r['Name'].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '')
         out.append(f"{name[:88]:88s} n/step={int(r['Calls']) / steps:5.1f} avg_us={float(r['AverageNs']) / 1e3:8.1f} "
                    f"ms/step={float(r['TotalDurationNs']) / 1e6 / steps:7.3f} {float(r['Percentage']):5.1f}%")
-    open(f'{P}/r01_rocprofv3_summary.txt', 'w').write('\n'.join(out) + '\n')
-    shutil.copy(f'{R}/bench_n1.json', f'{P}/r01_bench_n1.json')
-    shutil.copy(f'{R}/bench_under_rocprofv3.json', f'{P}/r01_bench_n1_under_rocprofv3.json')
+    open(f'{P}/{TAG}_rocprofv3_summary.txt', 'w').write('\n'.join(out) + '\n')
+    shutil.copy(f'{R}/bench_n1.json', f'{P}/{TAG}_bench_n1.json')
+    shutil.copy(f'{R}/bench_under_rocprofv3.json', f'{P}/{TAG}_bench_n1_under_rocprofv3.json')
     for src, dst in (('conv_microbench.txt', 'r01_conv_microbench.txt'), ('membw.txt', 'r01_membw.txt')):
         open(f'{P}/{dst}', 'w').write(''.join(line for line in open(f'{R}/{src}') if 'amdgpu.ids' not in line))
     picked, agg = [], {'FETCH_SIZE': collections.defaultdict(list), 'WRITE_SIZE': collections.defaultdict(list)}
@@ -46,22 +49,23 @@ def main():
                 continue
             picked.append((r['Counter_Name'], r['Kernel_Name'], r['Dispatch_Id'], float(r['Counter_Value'])))
             agg[r['Counter_Name']][tag].append(float(r['Counter_Value']))
-    with open(f'{P}/r01_pmc_dominant_kernel.csv', 'w', newline='') as f:
+    with open(f'{P}/{TAG}_pmc_dominant_kernel.csv', 'w', newline='') as f:
         w = csv.writer(f)
         w.writerow(['Counter_Name', 'Kernel_Name', 'Dispatch_Id', 'Counter_Value'])
         for r in picked:
             w.writerow([r[0], r[1], r[2], f'{r[3]:.6f}'])
     traffic = json.load(open(f'{P}/dominant_kernel_traffic.json'))
+    traffic['source'] = f'profiles/{TAG}_pmc_dominant_kernel.csv, bench.py --steps 3 --warmup 1, batch 32, 256x512' 
     fetch = {k: sum(v) / len(v) for k, v in agg['FETCH_SIZE'].items()}
     write = {k: sum(v) / len(v) for k, v in agg['WRITE_SIZE'].items()}
     fb, wb = sum(fetch.values()) * 1024, sum(write.values()) * 1024
     traffic.update(FETCH_SIZE_KB_avg=fetch, WRITE_SIZE_KB_avg=write, fetch_bytes=fb, write_bytes=wb,
                    hbm_bytes_per_launch=fb + wb)
     json.dump(traffic, open(f'{P}/dominant_kernel_traffic.json', 'w'), indent=1)
-    b, u = json.load(open(f'{P}/r01_bench_n1.json')), json.load(open(f'{P}/r01_bench_n1_under_rocprofv3.json'))
-    print('bench', b['value'], b['ms_per_step'], b['roofline']['avg_launch_us'], b['roofline']['frac'],
+    b, u = json.load(open(f'{P}/{TAG}_bench_n1.json')), json.load(open(f'{P}/{TAG}_bench_n1_under_rocprofv3.json'))
+    print('bench', b['value'], b['ms_per_step'], b['roofline']['solo_launch_us'], b['roofline']['frac'],
           b['cpu_baseline']['value'])
-    print('under rocprofv3', u['value'], u['ms_per_step'], u['roofline']['avg_launch_us'])
+    print('under rocprofv3', u['value'], u['ms_per_step'], u['roofline']['solo_launch_us'], u['roofline']['in_loop_launch_us'])
     print('traffic MB', fb / 1e6, wb / 1e6, (fb + wb) / 1e6)
     for r in rows:
         if part(r['Name']):
