@@ -41,6 +41,8 @@ CONFIGS = {
                       nets=('Monochrome', 'Paragraph', 'Line', 'Char'), baseline='configs[2]'),
     'highres-fp16': dict(batch=8, height=1024, width=2048, dtype='float16', train=True,
                          nets=('Monochrome', 'Paragraph', 'Line'), baseline='configs[4]'),
+    'highres-f32': dict(batch=8, height=1024, width=2048, dtype='float32', train=True,          # (diagnostic: what
+                        nets=('Monochrome', 'Paragraph', 'Line'), baseline='configs[4] in float32'),   # float16 buys)
     'infer-b8': dict(batch=8, height=256, width=512, dtype='float32', train=False,
                      nets=('Monochrome', 'Paragraph', 'Line', 'Char'), baseline='configs[1]'),
 }
@@ -320,7 +322,10 @@ def main():
     ap.add_argument('--h2d', action='store_true',
                     help='upload every batch as uint8 from pinned host memory on a copy stream and convert on the '
                          'device (PCIe-inclusive rate; flagged in metric and config, never the headline value)')
-    ap.add_argument('--step-timeout', type=float, default=120.0,
+    ap.add_argument('--option', action='append', default=[],
+                    help='kernel selection knob of the C ABI, key=value (uocr_ctx_set_option: split_blocks, split_min, '
+                         'gemm_bm, mfma, tiled, xcd_remap); experiments only')
+    ap.add_argument('--step-timeout', type=float, default=300.0,
                     help='watchdog: exit with code 3 when no step / phase completes for this many seconds')
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
@@ -399,6 +404,9 @@ def main():
         print(f'[bench] rank {rank}: RCCL data-parallel setup failed ({dp_fallback}); FALLING BACK to gloo staging',
               file=sys.stderr, flush=True)
         trainer = build_trainer('gloo')
+    for opt in args.option:
+        key, value = opt.split('=')
+        rt.set_option(key, int(value))          # (every lane)
     watchdog.beat('trainer built')
     initial = flat_weights(trainer.models) if rank == 0 and not args.no_cpu_baseline and world == 1 else None
     layers = make_page_batch(cfg['batch'], cfg['height'], cfg['width'], args.char_width, seed=1234 + rank)

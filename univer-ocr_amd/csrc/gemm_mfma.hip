@@ -20,6 +20,9 @@
 // hipcc-flags: -mllvm -amdgpu-mfma-vgpr-form=1
 // (accumulators stay in VGPRs: with the AGPR form the compiler copies all 32 of them in and out of the
 // AGPRs around every depth tile -- 64 v_accvgpr moves against 32 MFMAs)
+#include <array>
+#include <type_traits>
+
 #include "conv_dims.h"
 #include "gemm.h"
 
@@ -367,6 +370,47 @@ struct AConvWgrad {
         code = (!live || r.kind == 2) ? LD_ZERO : (r.kind == 1 ? LD_E0 : (inside ? LD_KEEP : LD_PAD));
         return *reinterpret_cast<const F4*>(code == LD_KEEP ? x + (((long)b * d.h + iy) * d.w + ix) * d.cin + r.ic0 : x);
     }
+    // The same load from a CURSOR: the output pixel (b, oy, ox) of a depth index and the element offset of its
+    // window origin are carried from depth tile to depth tile (+BD pixels: at most one row wrap when ow >= BD)
+    // instead of being rebuilt with two divisions and a 64-bit multiply chain per 16-byte load -- on gfx950 f32
+    // MFMAs and vector instructions do not overlap, so every VALU instruction of the loader
+    // is paid in MFMA time.  Usable when ow >= BD and the tensor has < 2^31 elements (`cursor_ok`).
+    struct Cursor {
+        int ox, oy, b;
+        int base;          // ((b*h + oy*sh) * w + ox*sw) * cin
+    };
+    int cursor_ok;
+    __device__ __forceinline__ Cursor cursor_at(int p) const {
+        Cursor c;
+        const int q = min(p, depth);       // (beyond the depth: b == n, which `load_at` reads as "not live")
+        const int t = by_ow.div(q);
+        c.ox = q - t * d.ow;
+        c.b = by_oh.div(t);
+        c.oy = t - c.b * d.oh;
+        c.base = ((c.b * d.h + c.oy * d.sh) * d.w + c.ox * d.sw) * d.cin;
+        return c;
+    }
+    __device__ __forceinline__ void advance(Cursor& c) const {          // += BD pixels
+        c.ox += BD;
+        c.base += BD * d.sw * d.cin;
+        if (c.ox >= d.ow) {
+            c.ox -= d.ow;
+            c.oy += 1;
+            c.base += (d.sh * d.w - d.ow * d.sw) * d.cin;
+            if (c.oy == d.oh) {
+                c.oy = 0;
+                c.b += 1;
+                c.base += (d.h - d.oh * d.sh) * d.w * d.cin;
+            }
+        }
+    }
+    __device__ __forceinline__ F4 load_at(const Row& r, const Cursor& c, int& code) const {
+        const int iy = c.oy * d.sh - d.ph + r.ky, ix = c.ox * d.sw - d.pw + r.kx;
+        const bool inside = (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w;
+        code = (c.b >= d.n || r.kind == 2) ? LD_ZERO : (r.kind == 1 ? LD_E0 : (inside ? LD_KEEP : LD_PAD));
+        const int off = c.base + ((r.ky - d.ph) * d.w + (r.kx - d.pw)) * d.cin + r.ic0;
+        return *reinterpret_cast<const F4*>(x + (code == LD_KEEP ? off : 0));
+    }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -427,6 +471,20 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BLoader B, Ep
     int acode[A_REGS], bcode[2];
     bool a_slow = false;
     if constexpr (ALoader::HAS_SLOW) a_slow = !A.vec_ok;
+    constexpr bool HAS_CURSOR = requires { typename ALoader::Cursor; };
+    struct NoCursor {};
+    auto cursors = [&] {
+        if constexpr (HAS_CURSOR) return std::array<typename ALoader::Cursor, AM_PASSES>{};
+        else return NoCursor{};
+    }();
+    bool use_cursor = false;
+    if constexpr (HAS_CURSOR) {
+        use_cursor = A.cursor_ok != 0;
+        if (use_cursor) {
+#pragma unroll
+            for (int sidx = 0; sidx < AM_PASSES; ++sidx) cursors[sidx] = A.cursor_at(t_begin * BD + a_pr + AM_ROWS * sidx);
+        }
+    }
     auto load_tile = [&](int t) {
         if (a_slow) {             // unaligned rows or ragged groups: element loads (block-uniform choice)
             if constexpr (ALoader::HAS_SLOW) {
@@ -441,8 +499,21 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BLoader B, Ep
 #pragma unroll
             for (int s = 0; s < A_PASSES; ++s) areg[s] = A.load(rows[s], t, a_kq, acode[s]);
         } else {
+            bool done = false;
+            if constexpr (HAS_CURSOR) {
+                if (use_cursor) {           // tiles are visited in order from t_begin (no tile skipping for this loader)
 #pragma unroll
-            for (int s = 0; s < AM_PASSES; ++s) areg[s] = A.load(rows[0], t * BD + a_pr + AM_ROWS * s, acode[s]);
+                    for (int s = 0; s < AM_PASSES; ++s) {
+                        areg[s] = A.load_at(rows[0], cursors[s], acode[s]);
+                        A.advance(cursors[s]);
+                    }
+                    done = true;
+                }
+            }
+            if (!done) {
+#pragma unroll
+                for (int s = 0; s < AM_PASSES; ++s) areg[s] = A.load(rows[0], t * BD + a_pr + AM_ROWS * s, acode[s]);
+            }
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -492,7 +563,10 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BLoader B, Ep
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 
-    const int wm = wave % WM, wn = wave / WM;
+    // which 32-row band of the tile a wave owns rotates with the slab index: in the last M tile of a ragged GEMM
+    // (dw of a 64-channel 3x3 conv: 577 rows = 4.5 tiles) some bands lie beyond M and do no MFMAs; without the
+    // rotation those idle waves always sit on the same SIMDs of every CU (wave w runs on SIMD w)
+    const int wm = (wave % WM + bz) % WM, wn = wave / WM;
     const int fi = wm * 32 + (lane & 31);        // A fragment row of this lane
     const int fk = lane >> 5;                    // depth offset inside a 2-deep MFMA step
     const int fj = wn * (BN / WN) + (lane & 31); // B fragment column (first 32x32 block)
@@ -519,9 +593,18 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BLoader B, Ep
         const float* bs = Bs[buf];
         if (band_live) {
             // fragments of depth step k+2 are read from LDS while the MFMAs of step k run
-            auto frag_a = [&](int k) { return ALoader::DEPTH_CONTIG ? as[fi * LDA + k + fk] : as[(k + fk) * BM + fi]; };
+            // one base address per operand and tile (buffer + lane part), made opaque so that the compiler keeps it in
+            // a VGPR and addresses the 16 depth steps with immediate offsets (it otherwise re-adds the buffer offset
+            // to sixteen hoisted per-step registers: a v_add3 in front of every ds_read, i.e. VALU time taken from
+            // the MFMAs, section 5a of DESIGN.md)
+            // (indices into the __shared__ arrays, not pointers: a pointer through the asm loses its address space and
+            // the reads become flat loads)
+            int ia = buf * (BM * LDA) + (ALoader::DEPTH_CONTIG ? fi * LDA + fk : fk * BM + fi);
+            int ib = buf * (BLoader::DEPTH_CONTIG ? BN * LDA : BD * BN) + (BLoader::DEPTH_CONTIG ? fj * LDA + fk : fk * BN + fj);
+            asm volatile("" : "+v"(ia), "+v"(ib));
+            auto frag_a = [&](int k) { return (&As[0][0])[ia + (ALoader::DEPTH_CONTIG ? k : k * BM)]; };
             auto frag_b = [&](int k, int nb) {
-                return BLoader::DEPTH_CONTIG ? bs[(fj + nb * 32) * LDA + k + fk] : bs[(k + fk) * BN + fj + nb * 32];
+                return (&Bs[0][0])[ib + (BLoader::DEPTH_CONTIG ? nb * 32 * LDA + k : k * BN + nb * 32)];
             };
             float a = frag_a(0), b[NB];
 #pragma unroll
@@ -616,9 +699,12 @@ int launch_mfma(uocr_ctx* ctx, const ALoader& A, const BLoader& B, const Epilogu
     // load round trip), so aim for ~4 resident blocks per CU: split the depth until there are ~1024 blocks
     // (a fused reduction by the last-arriving block was tried: the agent-scope release/acquire it needs
     // writes back and invalidates the XCD's L2 per block -- the Char net went from 0.57 to 2.55 ms/step)
-    const int target = ctx->opt_split;
+    // "split_blocks" = 1024 (the default) means: as many blocks as are RESIDENT at once -- 3 per CU with 128-row
+    // tiles (50 KB of LDS each), 4 with 64-row tiles (33 KB).  A grid of 1025 blocks of the 128-row kernel ran as
+    // one full round of 768 plus a second round a third full: dw of the wide conv 59 -> see DESIGN.md section 5.
+    const int target = ctx->opt_split == 1024 ? ctx->cu_count * (bm == 128 ? 3 : 4) : ctx->opt_split;
     if (allow_split && target > 0 && gm * gn < target && ntiles >= 4) {
-        nsplit = (target + gm * gn - 1) / (gm * gn);
+        nsplit = ctx->opt_split == 1024 ? max(1, target / (gm * gn)) : (target + gm * gn - 1) / (gm * gn);
         // at most 32 slabs of >= 2 depth tiles, or up to 256 when every slab still has >= 32 tiles (very deep
         // GEMMs with few output tiles: dw of a wide conv, 5 tiles x 131072 depth tiles -- ~4 blocks per CU
         // keep the CUs evenly loaded where 2.5 would not)
@@ -746,7 +832,8 @@ int uocr_conv_wgrad_mfma(uocr_ctx* ctx, const void* x, const void* dy, void* dw,
                          double pad_value, int use_bias, int accumulate) {
     const int K = d.kh * d.kw * d.cin, P = d.n * d.oh * d.ow;
     const int M = K + (use_bias ? 1 : 0);
-    AConvWgrad A{(const float*)x, d, (float)pad_value, K, use_bias, P, FastDiv(d.ow), FastDiv(d.oh)};
+    const int cursor_ok = d.ow >= BD && (long)(d.n + 1) * d.h * d.w * d.cin < (1l << 31) - (long)d.kh * d.w * d.cin;
+    AConvWgrad A{(const float*)x, d, (float)pad_value, K, use_bias, P, FastDiv(d.ow), FastDiv(d.oh), cursor_ok};
     BRowMajor B{(const float*)dy, d.cout, P, d.cout, aligned16(dy) ? 1 : 0};
     Epilogue ep{(float*)dw, d.cout, nullptr, UOCR_ACT_NONE, 0.f, accumulate, use_bias ? K : -1, (float*)db,
                 nullptr,    UOCR_ACT_NONE, 0.f};
