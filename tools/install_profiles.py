@@ -25,22 +25,38 @@ def part(name):
     return None
 
 
-def main():
-    shutil.copy(latest(f'{R}/stats/*/*_kernel_stats.csv'), f'{P}/{TAG}_rocprofv3_kernel_stats.csv')
-    rows = list(csv.DictReader(open(f'{P}/{TAG}_rocprofv3_kernel_stats.csv')))
-    steps = 25
+def summarise(stats_dir, stem, marker, steps=25):
+    """kernel stats of one profiled bench command -> profiles/<TAG>_<stem>_kernel_stats.csv + a per-step summary.
+    (rocprofv3 also writes a file for the profiler's helper process: take the one that holds `marker`.)"""
+    paths = [p for p in glob.glob(f'{R}/{stats_dir}/*/*_kernel_stats.csv') if marker in open(p).read()]
+    shutil.copy(max(paths, key=os.path.getmtime), f'{P}/{TAG}_{stem}_kernel_stats.csv')
+    rows = list(csv.DictReader(open(f'{P}/{TAG}_{stem}_kernel_stats.csv')))
     total = sum(float(r['TotalDurationNs']) for r in rows)
     calls = sum(int(r['Calls']) for r in rows)
     out = [f'kernel time {total / 1e6 / steps:.3f} ms/step, {calls / steps:.1f} kernels/step']
-    for r in rows[:40]:
+    for r in rows[:45]:
         name = r['Name'].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '')
         out.append(f"{name[:88]:88s} n/step={int(r['Calls']) / steps:5.1f} avg_us={float(r['AverageNs']) / 1e3:8.1f} "
                    f"ms/step={float(r['TotalDurationNs']) / 1e6 / steps:7.3f} {float(r['Percentage']):5.1f}%")
-    open(f'{P}/{TAG}_rocprofv3_summary.txt', 'w').write('\n'.join(out) + '\n')
-    shutil.copy(f'{R}/bench_n1.json', f'{P}/{TAG}_bench_n1.json')
-    shutil.copy(f'{R}/bench_under_rocprofv3.json', f'{P}/{TAG}_bench_n1_under_rocprofv3.json')
-    for src, dst in (('conv_microbench.txt', 'r01_conv_microbench.txt'), ('membw.txt', 'r01_membw.txt')):
-        open(f'{P}/{dst}', 'w').write(''.join(line for line in open(f'{R}/{src}') if 'amdgpu.ids' not in line))
+    open(f'{P}/{TAG}_{stem}_summary.txt', 'w').write('\n'.join(out) + '\n')
+    return rows, out
+
+
+def main():
+    rows, out = summarise('stats', 'rocprofv3', 'conv_pair_bwd_kernel')
+    summarise('stats_hr', 'rocprofv3_highres_fp16', 'conv_pair_bwd_kernel')
+    for src, dst in (('bench_n1.json', 'bench_n1.json'), ('bench_under_rocprofv3.json', 'bench_n1_under_rocprofv3.json'),
+                     ('bench_hr_n1.json', 'bench_highres_fp16_n1.json'),
+                     ('bench_hr_under_rocprofv3.json', 'bench_highres_fp16_under_rocprofv3.json'),
+                     ('bench_infer_n1.json', 'bench_infer_b8_n1.json'),
+                     ('bench_dp1_rehearsal.json', 'bench_one_rank_rccl_rehearsal.json')):
+        shutil.copy(f'{R}/{src}', f'{P}/{TAG}_{dst}')
+    for src, dst in (('conv_microbench.txt', f'{TAG}_conv_microbench.txt'), ('membw.txt', f'{TAG}_membw.txt'),
+                     ('ubench_coexec.txt', f'{TAG}_ubench_mfma_valu_coexec.txt'),
+                     ('ubench_switch.txt', f'{TAG}_ubench_mfma_switch.txt'),
+                     ('pmc_pair_summary.txt', f'{TAG}_pmc_pair_kernels.txt')):
+        if os.path.exists(f'{R}/{src}'):
+            open(f'{P}/{dst}', 'w').write(''.join(line for line in open(f'{R}/{src}') if 'amdgpu.ids' not in line))
     picked, agg = [], {'FETCH_SIZE': collections.defaultdict(list), 'WRITE_SIZE': collections.defaultdict(list)}
     for d in ('pmc_fetch', 'pmc_write'):
         for r in csv.DictReader(open(latest(f'{R}/{d}/*/*counter_collection.csv'))):
