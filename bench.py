@@ -356,7 +356,7 @@ def main():
             sys.exit('--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
         args.gpus = world
     watchdog = Watchdog(args.step_timeout, rank)
-    graphs = not args.no_graphs and train
+    graphs = not args.no_graphs
     # UOCR_BENCH_REHEARSAL=1: several ranks on ONE card, gradients through gloo staged over the host
     # (parallel.DataParallel(backend='gloo')) -- exercises this file's multi-rank path where RCCL would refuse
     # two ranks on one device; never a measurement
@@ -462,7 +462,7 @@ def main():
         feeder.stage(layers_u8)         # start the upload of batch i+1
         return trainer.step(ctx)
 
-    if graphs:
+    if graphs and train:
         try:
             trainer.capture(context)
         except Exception as exc:                   # keep measuring: eager launches are the same computation

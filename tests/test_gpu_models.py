@@ -448,3 +448,29 @@ def test_model_system_lists_of_differently_sized_crops(fused, dt):
     for model in (line, char):
         for pn, p in model.params().items():
             check_sampled(pn, p.value, g, 'final', tol)
+
+
+@pytest.mark.parametrize('graphs', [False, True])
+def test_page_trainer_forward_lanes_and_graphs(graphs):
+    """PageTrainer.forward (configs[1]: forward only): every net on its lane, optionally replayed from HIP graphs --
+    the predictions equal Model.predict on the main stream, also after the inputs changed."""
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    from univer_ocr_amd.my_model.trainer import PageTrainer
+    from univer_ocr_amd.nn import CP
+    CP.use_gpu(0)
+    CP.set_dtype('float32')
+    lazy, CP.lazy_losses = CP.lazy_losses, True
+    try:
+        trainer = PageTrainer(2, 32, 64, 16, optimizer='sgd', lr=0.01, seed=4, graphs=graphs)
+        for seed in (1, 2):
+            layers = make_page_batch(2, 32, 64, 16, seed=seed)
+            context = trainer.make_context(layers)
+            out = trainer.forward(dict(context))
+            CP.runtime().synchronize()
+            import torch
+            torch.cuda.synchronize()
+            for comp in trainer.model_system.components:
+                ref = comp.model.predict(CP.copy(layers[{'Monochrome': 'image', 'Char': 'char_lines'}.get(comp.name, 'monochrome')]))[0]
+                assert np.array_equal(CP.asnumpy(out[comp.selector.pred_label]), CP.asnumpy(ref)), comp.name
+    finally:
+        CP.lazy_losses = lazy
