@@ -171,9 +171,17 @@ def test_upconv2x_f16(ch, hl, wl, f16):
     assert rel_linf(CP.asnumpy(db), ref_db / 4) <= TOL_EXACT
 
 
-@pytest.mark.parametrize('shape', [(2, 32, 64), (3, 45, 70)])
+@pytest.mark.parametrize('shape', [(2, 32, 64), (3, 45, 70), (1, 16, 32), (2, 14, 30), (1, 5, 3)])
 def test_conv_pair_f16(shape, f16):
-    """The fused Monochrome block (uocr_conv_pair_*) with binary16 x / y / dy / dx."""
+    """The fused Monochrome block (uocr_conv_pair_*) with binary16 x / y / dy / dx on binary16 MFMAs: the weights,
+    a1 = lrelu(conv_1) and d_a1 enter the matrix cores rounded to binary16 (a1 / d_a1 are what a layer-by-layer
+    run in this mode stores; the float32 master weights are rounded as operands), accumulation is float32.
+    Two checkers: (1) the float64 oracle with exactly those roundings -- what is left is float32 accumulation and
+    rare 1-ulp ties: stored tensors 1e-3 (their own rounding), dw / db 2e-4; (2) the unrounded float64 oracle:
+    y within 4e-3 (a few operand roundings of 2^-11 each); the backward is only piecewise continuous in the
+    weights (a z1 within rounding of 0 switches its LeakyReLU slope between 1 and 0.01), so there 99 % of the
+    dx pixels must lie within 4e-3 and the parameter gradients (sums of ~10^4 random-sign terms, where ONE switched
+    position is ~1 % of the sum) within 5e-2: a sanity bound, (1) is the parity check."""
     from univer_ocr_amd.hip import lib as hiplib
     from univer_ocr_amd.nn import ops
     CP = f16
@@ -184,28 +192,35 @@ def test_conv_pair_f16(shape, f16):
     w2, b2 = rng.standard_normal((3, 3, 16, 1)) * 0.2, rng.standard_normal(1) * 0.1
     x16 = r16(x)
     f = lambda a: a.astype(np.float32).astype(np.float64)
-    z1 = O.conv2d_fwd(x16, f(w1), f(b1), 1, 1, 0.0, True)
-    a1 = O.leaky_relu_fwd(z1, 0.01)
-    z2 = O.conv2d_fwd(a1, f(w2), f(b2), 1, 1, 0.0, True)
-    ref_y = O.sigmoid_fwd(z2)
-    g16 = r16(rng.standard_normal(ref_y.shape))
+    g16 = r16(rng.standard_normal((n, h, w_, 1)))
     xd, gd = CP.copy(x), CP.copy(g16)
     p = params32(CP, w1, b1, w2, b2)
     y = ops.conv_pair_fwd(xd, *p, act2=hiplib.ACT_SIGMOID)
-    assert y.dtype == np.float16 and rel_linf(CP.asnumpy(y), ref_y) <= TOL_STORE
-    # backward from the STORED (binary16) output, as the kernel sees it
-    y16 = CP.asnumpy(y).astype(np.float64)
-    gz2 = g16 * y16 * (1 - y16)
-    ga1, ref_dw2, ref_db2 = O.conv2d_bwd(a1, f(w2), gz2, 1, 1, 0.0, True)
-    gz1 = O.leaky_relu_bwd(z1, ga1, 0.01)
-    ref_dx, ref_dw1, ref_db1 = O.conv2d_bwd(x16, f(w1), gz1, 1, 1, 0.0, True)
+    assert y.dtype == np.float16
+    y16 = CP.asnumpy(y).astype(np.float64)           # backward from the STORED (binary16) output, as the kernel sees it
     grads = [CP.zeros(a.shape, np.float32) for a in (w1, b1, w2, b2)]
     gd.gscale = 6
     dx = ops.conv_pair_bwd(xd, y, gd, p[0], p[1], p[2], *grads, act2=hiplib.ACT_SIGMOID, accumulate=False)
     assert dx.dtype == np.float16 and dx.gscale == 6
-    assert rel_linf(CP.asnumpy(dx), ref_dx) <= TOL_STORE
-    for got, ref in zip(grads, (ref_dw1, ref_db1, ref_dw2, ref_db2)):
-        assert rel_linf(CP.asnumpy(got), ref / 64) <= TOL_EXACT
+    for rounded, tol_store, tol_sum in ((True, TOL_STORE, 2e-4), (False, 4e-3, 4e-3)):
+        q = r16 if rounded else (lambda a: a)
+        z1 = O.conv2d_fwd(x16, q(f(w1)), f(b1), 1, 1, 0.0, True)
+        a1 = q(O.leaky_relu_fwd(z1, 0.01))
+        z2 = O.conv2d_fwd(a1, q(f(w2)), f(b2), 1, 1, 0.0, True)
+        assert rel_linf(y16, O.sigmoid_fwd(z2)) <= tol_store, rounded
+        gz2 = q(g16 * y16 * (1 - y16))
+        ga1, ref_dw2, ref_db2 = O.conv2d_bwd(a1, q(f(w2)), gz2, 1, 1, 0.0, True)
+        gz1 = q(O.leaky_relu_bwd(z1, ga1, 0.01))
+        ref_dx, ref_dw1, ref_db1 = O.conv2d_bwd(x16, q(f(w1)), gz1, 1, 1, 0.0, True)
+        if rounded:
+            assert rel_linf(CP.asnumpy(dx), ref_dx) <= tol_store
+        else:
+            err = np.abs(CP.asnumpy(dx).astype(np.float64) - ref_dx) / np.abs(ref_dx).max()
+            assert np.quantile(err, 0.99) <= tol_store
+            tol_sum = 5e-2
+        # (db1 sums d_a1 BEFORE its rounding to binary16 -- closer to the unrounded oracle than to the rounded one)
+        for name, got, ref in zip(('dw1', 'db1', 'dw2', 'db2'), grads, (ref_dw1, ref_db1, ref_dw2, ref_db2)):
+            assert rel_linf(CP.asnumpy(got), ref / 64) <= (4e-3 if name == 'db1' and rounded else tol_sum), (name, rounded)
 
 
 @pytest.mark.parametrize('c,fold', [(1, True), (2, True), (1, False)])

@@ -40,9 +40,11 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--filter', default='')
     ap.add_argument('--option', action='append', default=[])
+    ap.add_argument('--dtype', default='float32', help='activation storage (float16: pair rows only)')
     args = ap.parse_args()
     from univer_ocr_amd.nn import CP, ops
     CP.use_gpu(0)
+    CP.set_dtype(args.dtype)
     rt = CP.runtime()
     for opt in args.option:
         k, v = opt.split('=')
@@ -70,11 +72,11 @@ def main():
         from univer_ocr_amd.hip import lib as hiplib
         n, h, w = args.batch, 256, 512
         x = CP.copy(rng.standard_normal((n, h, w, 1)).astype(np.float32))
-        w1 = CP.copy((rng.standard_normal((3, 3, 1, 16)) * 0.3).astype(np.float32))
-        w2 = CP.copy((rng.standard_normal((3, 3, 16, 1)) * 0.1).astype(np.float32))
-        b1, b2 = CP.zeros((16,)), CP.zeros((1,))
+        w1 = CP.copy((rng.standard_normal((3, 3, 1, 16)) * 0.3), np.float32)
+        w2 = CP.copy((rng.standard_normal((3, 3, 16, 1)) * 0.1), np.float32)
+        b1, b2 = CP.zeros((16,), np.float32), CP.zeros((1,), np.float32)
         g = CP.copy(rng.standard_normal((n, h, w, 1)).astype(np.float32))
-        grads = [CP.zeros(w1.shape), CP.zeros((16,)), CP.zeros(w2.shape), CP.zeros((1,))]
+        grads = [CP.zeros(a, np.float32) for a in (w1.shape, (16,), w2.shape, (1,))]
         sig = hiplib.ACT_SIGMOID
         y = ops.conv_pair_fwd(x, w1, b1, w2, b2, act2=sig)
         px, conv = n * h * w, 2.0 * 9 * 16

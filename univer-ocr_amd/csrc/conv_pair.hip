@@ -164,6 +164,91 @@ __device__ __forceinline__ int ring_index(int er, int ec) {      // (er, ec) in 
     if (ec == -1) return 2 * XW + er;
     return 2 * XW + RH + er;
 }
+// dx[e] = sum_s U[e - s + 1, s] from the tile's U in LDS (us[pos][tap]): the inside of the tile goes to dx, the
+// ring around it to border[tile_id] (see above).  dxb = dx of this image.
+template <typename TA>
+__device__ __forceinline__ void pair_dx_scatter(const float* us, TA* dxb, float* border, int tid, int y0, int x0,
+                                                int h, int wd, size_t tile_id) {
+    // Inner pixels (rows 1..RH-2, columns 1..RW-2): all nine sources lie in the tile -- nine LDS reads at
+    // compile-time offsets, no tests
+    constexpr int IH = RH - 2, IW = RW - 2;
+    for (int e = tid; e < IH * IW; e += 256) {
+        const int er = e / IW + 1, ec = e - (er - 1) * IW + 1;
+        const float* u0 = us + ((er + 1) * RW + ec + 1) * 9;       // source of s = (0, 0)
+        float v = 0.f;
+#pragma unroll
+        for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) v += u0[-(sy * RW + sx) * 9 + sy * 3 + sx];
+        const int gy = y0 + er, gx = x0 + ec;
+        if (gy < h && gx < wd) st1(dxb + (size_t)gy * wd + gx, v);
+    }
+    // the two outer pixel frames: the tile's edge pixels (to dx, still lacking the neighbours' rings) and
+    // the ring around the tile (to the border buffer): 4 rows of XW + (RH - 2) rows of 4 = 192 elements
+    constexpr int NFRAME = 4 * XW + 4 * (RH - 2);
+    for (int k = tid; k < NFRAME; k += 256) {
+        int er, ec;
+        if (k < 4 * XW) {
+            const int rr = k / XW;
+            er = rr == 0 ? -1 : rr == 1 ? 0 : rr == 2 ? RH - 1 : RH;
+            ec = k - rr * XW - 1;
+        } else {
+            const int kk = k - 4 * XW, j = kk & 3;
+            er = (kk >> 2) + 1;
+            ec = j == 0 ? -1 : j == 1 ? 0 : j == 2 ? RW - 1 : RW;
+        }
+        float v = 0.f;
+#pragma unroll
+        for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) {
+                const int qr = er + 1 - sy, qc = ec + 1 - sx;      // q = e - s + 1
+                if (qr >= 0 && qr < RH && qc >= 0 && qc < RW) v += us[(qr * RW + qc) * 9 + sy * 3 + sx];
+            }
+        const int gy = y0 + er, gx = x0 + ec;
+        if (gy < 0 || gy >= h || gx < 0 || gx >= wd) continue;
+        if (er >= 0 && er < RH && ec >= 0 && ec < RW) st1(dxb + (size_t)gy * wd + gx, v);
+        else border[tile_id * RING + ring_index(er, ec)] = v;
+    }
+}
+
+// block reduction through LDS of the two dW^T accumulator tiles ([tap 4kq+v][ch n] per wave), db1 (channel n per
+// lane) and db2 -> partial[(q * NA + k) * nblk + blk], the layout conv_pair_bwd_finish sums
+__device__ __forceinline__ void pair_block_reduce(float (*red)[2][16][16], float (*reddb)[4][16], float* redb2,
+                                                  f32x4 acc1, f32x4 acc2, float db1acc, float db2acc,
+                                                  float* __restrict__ partial) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        red[wv][0][4 * kq + v][n] = acc1[v];
+        red[wv][1][4 * kq + v][n] = acc2[v];
+    }
+    reddb[wv][kq][n] = db1acc;
+    db2acc = wave_reduce_sum(db2acc);
+    if (lane == 0) redb2[wv] = db2acc;
+    __syncthreads();
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int nblk = gridDim.x * gridDim.y * gridDim.z;
+    float* out = partial + blk;                          // partial[(q * NA + k) * nblk + blk]: the finish kernel
+    for (int i = tid; i < 4 * NA; i += 256) {            // then reads every sum's block partials contiguously
+        const int q = i / NA, k = i - q * NA;
+        float v = 0.f;
+        if (k < 72) {
+            const int which = k / 36, kk = k - which * 36, tap = kk >> 2, ch = q * 4 + (kk & 3);
+            v = red[0][which][tap][ch] + red[1][which][tap][ch] + red[2][which][tap][ch] + red[3][which][tap][ch];
+        } else if (k < 76) {
+            const int ch = q * 4 + (k - 72);
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) v += reddb[w][g4][ch];
+        } else {
+            v = redb2[0] + redb2[1] + redb2[2] + redb2[3];
+        }
+        out[(size_t)i * nblk] = v;
+    }
+}
+
 template <bool DX, bool SIG, typename TA>
 __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const TA* __restrict__ x, const TA* __restrict__ yout,
                                                             const TA* __restrict__ dy,
@@ -303,81 +388,289 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const TA* __restrict
         }
         if constexpr (DX) {
             __syncthreads();
-            const int tiles_y = (h + RH - 1) / RH;
-            const size_t tile_id = ((size_t)blockIdx.z * tiles_y + y0 / RH) * gridDim.x + blockIdx.x;
-            // dx[e] = sum_s U[e - s + 1, s].  Inner pixels (rows 1..RH-2, columns 1..RW-2): all nine sources lie in
-            // the tile -- nine LDS reads at compile-time offsets, no tests
-            constexpr int IH = RH - 2, IW = RW - 2;
-            for (int e = tid; e < IH * IW; e += 256) {
-                const int er = e / IW + 1, ec = e - (er - 1) * IW + 1;
-                const float* u0 = us + ((er + 1) * RW + ec + 1) * 9;       // source of s = (0, 0)
-                float v = 0.f;
+            pair_dx_scatter(us, dx + img, border, tid, y0, x0, h, wd,
+                            ((size_t)blockIdx.z * ((h + RH - 1) / RH) + y0 / RH) * gridDim.x + blockIdx.x);
+        }
+    }
+    pair_block_reduce(red, reddb, redb2, acc1, acc2, db1acc, db2acc, partial);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// binary16 storage (UOCR_F16): the same two kernels on v_mfma_f32_16x16x16_f16 -- 16 K-values per MFMA
+// instead of 4, so a whole 3x3 window (or all 16 channels) is ONE instruction: forward 2 MFMAs per group of
+// 16 positions instead of 7, backward 5 instead of 18.  Operands are binary16 (x / dy / y are stored that way;
+// the float32 master weights, a1 and d_a1 are rounded to binary16 as operands -- what a layer-by-layer run
+// in this mode stores in HBM for a1 / d_a1 anyway); accumulation stays float32.
+// LDS tiles hold PAIR WORDS: word[r][c] = (x[r][c], x[r][c+1]) as two halves, so the 4-half operand
+// x[r][c..c+3] of any column c is one ds_read2_b32 (words c and c+2), no packing VALU.
+// K permutation of a 3x3 window: k = 4*kq + j  <->  tap row kq (kq = 3: zero weights, row clamped),
+// tap column j (j = 3: zero weight; the value read there lies outside the window and must only be finite).
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+constexpr int TSH = 24;                    // row stride (halves) of the per-wave d_a1 transpose scratch
+
+__device__ __forceinline__ f32x4 mfma16(f16x4 a, f16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t pair_word(float lo, float hi) {
+    const f16x2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ f16x4 pack4(float a, float b, float c, float d) {
+    const f32x4 v = {a, b, c, d};
+    return __builtin_convertvector(v, f16x4);
+}
+__device__ __forceinline__ f16x4 window(const uint32_t* p) {      // halves c .. c+3 of a pair-word row
+    const u32x2 v = {p[0], p[2]};
+    return __builtin_bit_cast(f16x4, v);
+}
+
+// pair-word staging of the XH x XW tile with origin (ys, xs0): two clamped offsets per word + the in-image
+// bits of its two halves (outside the image the LDS write substitutes the padding value)
+struct StageH {
+    int off[NPF], off2[NPF];
+    uint32_t mask[NPF];
+    __device__ __forceinline__ void locate(int tid, int ys, int xs0, int h, int wd) {
 #pragma unroll
-                for (int sy = 0; sy < 3; ++sy)
+        for (int k = 0; k < NPF; ++k) {
+            const int i = tid + k * 256;
+            const int r = i / XW, c = i - r * XW;
+            const int gy = ys + r, gx = xs0 + c;
+            const bool row_ok = i < XH * XW && gy >= 0 && gy < h;
+            const int base = min(max(gy, 0), h - 1) * wd;
+            off[k] = base + min(max(gx, 0), wd - 1);
+            off2[k] = base + min(max(gx + 1, 0), wd - 1);
+            mask[k] = (row_ok && gx >= 0 && gx < wd ? 0xFFFFu : 0u) | (row_ok && gx + 1 >= 0 && gx + 1 < wd ? 0xFFFF0000u : 0u);
+        }
+    }
+};
+__device__ __forceinline__ uint32_t load_pair(const _Float16* p, int o0, int o1) {
+    const f16x2 v = {p[o0], p[o1]};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ uint32_t select_bits(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+
+__global__ __launch_bounds__(256) void conv_pair_fwd_h_kernel(const _Float16* __restrict__ x, const float* __restrict__ w1,
+                                                              const float* __restrict__ b1,
+                                                              const float* __restrict__ w2,
+                                                              const float* __restrict__ b2, _Float16* __restrict__ y,
+                                                              int h, int wd, int rows_per_block, float pad1,
+                                                              int use_b1, int use_b2, float alpha, int act2) {
+    constexpr int TH = RH - 2, TW = RW - 2;
+    __shared__ uint32_t xs2[XH * XW];
+    __shared__ float ps[RH * RW * 9];                    // P[pos][tap]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
+    const int x0 = blockIdx.x * TW;
+    const int row_begin = blockIdx.y * rows_per_block, row_end = min(h, row_begin + rows_per_block);
+    const _Float16* xb = x + (size_t)blockIdx.z * h * wd;
+    _Float16* yb = y + (size_t)blockIdx.z * h * wd;
+    // Z[ch, pos]: A = W1^T (m = ch = n, k = (tap row kq, tap column j)), B = window of x at pos n.
+    // P[pos, tap]: A = a1 (m = pos = n, k = ch 4kq+j: this lane's four Z results), B = W2^T (k = ch, n = tap)
+    f16x4 w1a, w2b;
+    f32x4 bias4;
 #pragma unroll
-                    for (int sx = 0; sx < 3; ++sx) v += u0[-(sy * RW + sx) * 9 + sy * 3 + sx];
-                const int gy = y0 + er, gx = x0 + ec;
-                if (gy < h && gx < wd) st1(dx + img + (size_t)gy * wd + gx, v);
-            }
-            // the two outer pixel frames: the tile's edge pixels (to dx, still lacking the neighbours' rings) and
-            // the ring around the tile (to the border buffer): 4 rows of XW + (RH - 2) rows of 4 = 192 elements
-            constexpr int NFRAME = 4 * XW + 4 * (RH - 2);
-            for (int k = tid; k < NFRAME; k += 256) {
-                int er, ec;
-                if (k < 4 * XW) {
-                    const int rr = k / XW;
-                    er = rr == 0 ? -1 : rr == 1 ? 0 : rr == 2 ? RH - 1 : RH;
-                    ec = k - rr * XW - 1;
-                } else {
-                    const int kk = k - 4 * XW, j = kk & 3;
-                    er = (kk >> 2) + 1;
-                    ec = j == 0 ? -1 : j == 1 ? 0 : j == 2 ? RW - 1 : RW;
+    for (int j = 0; j < 4; ++j) {
+        w1a[j] = kq < 3 && j < 3 ? (_Float16)w1[(min(kq, 2) * 3 + min(j, 2)) * C + n] : (_Float16)0.f;
+        w2b[j] = n < 9 ? (_Float16)w2[min(n, 8) * C + 4 * kq + j] : (_Float16)0.f;
+        bias4[j] = use_b1 ? b1[4 * kq + j] : 0.f;
+    }
+    const int xoff = min(kq, 2) * XW + n;
+    const float bias2 = use_b2 ? b2[0] : 0.f;
+    const uint32_t padword = pair_word(pad1, pad1);
+
+    StageH st;
+    uint32_t px[NPF];
+    st.locate(tid, row_begin - 2, x0 - 2, h, wd);
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) px[k] = load_pair(xb, st.off[k], st.off2[k]);
+    for (int y0 = row_begin; y0 < row_end; y0 += TH) {
+        __syncthreads();                                 // the previous tile's LDS reads are over
+#pragma unroll
+        for (int k = 0; k < NPF; ++k)
+            if (tid + k * 256 < XH * XW) xs2[tid + k * 256] = select_bits(st.mask[k], px[k], padword);
+        __syncthreads();
+        if (y0 + TH < row_end) {                         // next tile: loads overlap this tile's math
+            st.locate(tid, y0 + TH - 2, x0 - 2, h, wd);
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) px[k] = load_pair(xb, st.off[k], st.off2[k]);
+        }
+        // region origin = (y0 - 1, x0 - 1), tile origin one further out.  FULL: the whole region lies inside the
+        // image, conv_2's zero padding of a1 never applies
+        auto groups = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll 2
+            for (int k = 0; k < 8; ++k) {
+                const int gi = wv * 8 + k, r = gi >> 1, c0 = (gi & 1) * 16;
+                const f32x4 z = mfma16(w1a, window(xs2 + r * XW + c0 + xoff), bias4);
+                bool inside = true;
+                if constexpr (!FULL) {
+                    const int ay = y0 - 1 + r, ax = x0 - 1 + c0 + n;
+                    inside = ay >= 0 && ay < h && ax >= 0 && ax < wd;
                 }
-                float v = 0.f;
+                float a[4];
 #pragma unroll
-                for (int sy = 0; sy < 3; ++sy)
+                for (int j = 0; j < 4; ++j) a[j] = inside ? (z[j] >= 0.f ? z[j] : alpha * z[j]) : 0.f;
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 p = mfma16(pack4(a[0], a[1], a[2], a[3]), w2b, zero);
+                if (n < 9) {
 #pragma unroll
-                    for (int sx = 0; sx < 3; ++sx) {
-                        const int qr = er + 1 - sy, qc = ec + 1 - sx;      // q = e - s + 1
-                        if (qr >= 0 && qr < RH && qc >= 0 && qc < RW) v += us[(qr * RW + qc) * 9 + sy * 3 + sx];
-                    }
-                const int gy = y0 + er, gx = x0 + ec;
-                if (gy < 0 || gy >= h || gx < 0 || gx >= wd) continue;
-                if (er >= 0 && er < RH && ec >= 0 && ec < RW) st1(dx + img + (size_t)gy * wd + gx, v);
-                else border[tile_id * RING + ring_index(er, ec)] = v;
+                    for (int v = 0; v < 4; ++v) ps[(r * RW + c0 + 4 * kq + v) * 9 + n] = p[v];
+                }
             }
+        };
+        if (y0 >= 1 && y0 - 1 + RH <= h && x0 >= 1 && x0 - 1 + RW <= wd) groups(std::true_type{});
+        else groups(std::false_type{});
+        __syncthreads();
+        for (int p = tid; p < TH * TW; p += 256) {
+            const int pr = p / TW, pc = p - pr * TW;
+            const int gy = y0 + pr, gx = x0 + pc;
+            float v = bias2;
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) v += ps[((pr + ty) * RW + pc + tx) * 9 + ty * 3 + tx];
+            if (gy < row_end && gx < wd) st1(yb + (size_t)gy * wd + gx, out_act(v, act2));
         }
     }
-    // block reduction through LDS
+}
+
+// backward, binary16: Z^T / S^T [pos, ch] one MFMA each (A = window of x / of g mirrored, B = W1 / W2 rows),
+// dW2^T / dW1^T [tap, ch] one each (A = g / x at the group's 4kq..4kq+3 positions seen from tap n, B = this
+// lane's a / d_a1), U [pos, tap] one (A = d_a1 transposed through a binary16 LDS scratch, one ds_read_b64).
+template <bool DX, bool SIG>
+__global__ __launch_bounds__(256) void conv_pair_bwd_h_kernel(const _Float16* __restrict__ x,
+                                                              const _Float16* __restrict__ yout,
+                                                              const _Float16* __restrict__ dy,
+                                                              const float* __restrict__ w1,
+                                                              const float* __restrict__ b1,
+                                                              const float* __restrict__ w2,
+                                                              float* __restrict__ partial, _Float16* __restrict__ dx,
+                                                              float* __restrict__ border, int h, int wd,
+                                                              int rows_per_block, float pad1, int use_b1, float alpha) {
+    constexpr int TH = RH, TW = RW;
+    __shared__ uint32_t xs2[XH * XW];
+    __shared__ uint32_t gs2[XH * XW];
+    __shared__ float us[DX ? RH * RW * 9 : 1];           // U[pos][tap]
+    __shared__ __attribute__((aligned(8))) _Float16 tr[DX ? 4 * 16 * TSH : 4];   // per wave: d_a1[pos][ch]
+    __shared__ float red[4][2][16][16];
+    __shared__ float reddb[4][4][16];
+    __shared__ float redb2[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
+    const int x0 = blockIdx.x * TW;
+    const int row_begin = blockIdx.y * rows_per_block, row_end = min(h, row_begin + rows_per_block);
+    const size_t img = (size_t)blockIdx.z * h * wd;
+    const _Float16 *xb = x + img, *gb = dy + img, *yb = yout + img;
+    // constant operands.  S: g[pos - tap + 1] read left to right is tap column 2, 1, 0
+    f16x4 w1b, w2b, w1u;
+    const bool tap_ok = n < 9;
+    const int tn = tap_ok ? n : 8;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        red[wv][0][4 * kq + v][n] = acc1[v];
-        red[wv][1][4 * kq + v][n] = acc2[v];
+    for (int j = 0; j < 4; ++j) {
+        const bool live = kq < 3 && j < 3;
+        w1b[j] = live ? (_Float16)w1[(min(kq, 2) * 3 + min(j, 2)) * C + n] : (_Float16)0.f;
+        w2b[j] = live ? (_Float16)w2[(min(kq, 2) * 3 + 2 - min(j, 2)) * C + n] : (_Float16)0.f;
+        w1u[j] = tap_ok ? (_Float16)w1[tn * C + 4 * kq + j] : (_Float16)0.f;
     }
-    reddb[wv][kq][n] = db1acc;
-    db2acc = wave_reduce_sum(db2acc);
-    if (lane == 0) redb2[wv] = db2acc;
-    __syncthreads();
-    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const int nblk = gridDim.x * gridDim.y * gridDim.z;
-    float* out = partial + blk;                          // partial[(q * NA + k) * nblk + blk]: the finish kernel
-    for (int i = tid; i < 4 * NA; i += 256) {            // then reads every sum's block partials contiguously
-        const int q = i / NA, k = i - q * NA;
-        float v = 0.f;
-        if (k < 72) {
-            const int which = k / 36, kk = k - which * 36, tap = kk >> 2, ch = q * 4 + (kk & 3);
-            v = red[0][which][tap][ch] + red[1][which][tap][ch] + red[2][which][tap][ch] + red[3][which][tap][ch];
-        } else if (k < 76) {
-            const int ch = q * 4 + (k - 72);
+    const int xoff = min(kq, 2) * XW + n, goff = (2 - min(kq, 2)) * XW + n;
+    const int xA = (tn / 3) * XW + tn % 3 + 4 * kq, gA = (2 - tn / 3) * XW + 2 - tn % 3 + 4 * kq;
+    const float bias = use_b1 ? b1[n] : 0.f;
+    const uint32_t padword = pair_word(pad1, pad1);
+    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // dW1^T, dW2^T [tap 4kq+v][ch n]
+    float db1acc = 0.f, db2acc = 0.f;
+
+    StageH st;
+    uint32_t px[NPF], pg[NPF], py[SIG ? NPF : 1];
+    auto prefetch = [&](int y0) {
+        st.locate(tid, y0 - 1, x0 - 1, h, wd);
 #pragma unroll
-            for (int w = 0; w < 4; ++w)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) v += reddb[w][g4][ch];
-        } else {
-            v = redb2[0] + redb2[1] + redb2[2] + redb2[3];
+        for (int k = 0; k < NPF; ++k) {
+            px[k] = load_pair(xb, st.off[k], st.off2[k]);
+            pg[k] = load_pair(gb, st.off[k], st.off2[k]);
+            if constexpr (SIG) py[k] = load_pair(yb, st.off[k], st.off2[k]);
         }
-        out[(size_t)i * nblk] = v;
+    };
+    prefetch(row_begin);
+    for (int y0 = row_begin; y0 < row_end; y0 += TH) {
+        __syncthreads();                                 // the previous tile's LDS reads are over
+#pragma unroll
+        for (int k = 0; k < NPF; ++k)
+            if (tid + k * 256 < XH * XW) {
+                uint32_t g = pg[k];
+                if constexpr (SIG) {                     // g *= y (1 - y) in float32, one rounding back to binary16
+                    const f16x2 gh = __builtin_bit_cast(f16x2, pg[k]), yh = __builtin_bit_cast(f16x2, py[k]);
+                    const float y0f = (float)yh[0], y1f = (float)yh[1];
+                    g = pair_word((float)gh[0] * (y0f * (1.f - y0f)), (float)gh[1] * (y1f * (1.f - y1f)));
+                }
+                xs2[tid + k * 256] = select_bits(st.mask[k], px[k], padword);
+                gs2[tid + k * 256] = g & st.mask[k];
+            }
+        __syncthreads();
+        if (y0 + TH < row_end) prefetch(y0 + TH);
+        const int ry = y0, rx = x0;                      // region origin; tile origin one further out
+        auto groups = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll 2
+            for (int k = 0; k < 8; ++k) {
+                const int gi = wv * 8 + k, r = gi >> 1, c0 = (gi & 1) * 16;
+                const uint32_t* xr = xs2 + r * XW + c0;
+                const uint32_t* gr = gs2 + r * XW + c0;
+                const f32x4 zinit = {bias, bias, bias, bias}, zero = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 z = mfma16(window(xr + xoff), w1b, zinit);
+                const f32x4 s = mfma16(window(gr + goff), w2b, zero);
+                // results: channel n at positions (r, c0 + 4kq + i)
+                const int ay = ry + r;
+                const bool row_in = ay >= 0 && ay < h, row_own = row_in && ay < row_end;
+                float a[4], d[4], dn[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float slope = z[i] >= 0.f ? 1.f : alpha;
+                    if constexpr (FULL) {
+                        a[i] = z[i] * slope;
+                        d[i] = dn[i] = s[i] * slope;
+                    } else {
+                        const int c = c0 + 4 * kq + i, ax = rx + c;
+                        const bool inside = row_in && ax >= 0 && ax < wd;
+                        const bool owned = row_own && ax >= 0 && ax < wd;
+                        a[i] = owned ? z[i] * slope : 0.f;
+                        d[i] = inside ? s[i] * slope : 0.f;
+                        dn[i] = owned ? d[i] : 0.f;
+                    }
+                    db1acc += dn[i];
+                }
+                const f16x4 dn4 = pack4(dn[0], dn[1], dn[2], dn[3]);
+                acc2 = mfma16(window(gr + gA), pack4(a[0], a[1], a[2], a[3]), acc2);
+                acc1 = mfma16(window(xr + xA), dn4, acc1);
+                if constexpr (DX) {
+                    _Float16* t = tr + wv * 16 * TSH;
+                    const f16x4 d4 = FULL ? dn4 : pack4(d[0], d[1], d[2], d[3]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) t[(4 * kq + i) * TSH + n] = d4[i];
+                    __builtin_amdgcn_wave_barrier();     // same wave: LDS executes its instructions in order
+                    const f16x4 dt = *reinterpret_cast<const f16x4*>(t + n * TSH + 4 * kq);
+                    const f32x4 u = mfma16(dt, w1u, zero);
+                    __builtin_amdgcn_wave_barrier();
+                    if (tap_ok) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) us[(r * RW + c0 + 4 * kq + v) * 9 + n] = u[v];
+                    }
+                }
+            }
+        };
+        if (y0 + RH <= row_end && x0 + RW <= wd) groups(std::true_type{});
+        else groups(std::false_type{});
+        for (int p = tid; p < TH * TW; p += 256) {
+            const int pr = p / TW, pc = p - pr * TW;
+            if (y0 + pr < row_end && x0 + pc < wd)
+                db2acc += (float)__builtin_bit_cast(f16x2, gs2[(pr + 1) * XW + pc + 1])[0];
+        }
+        if constexpr (DX) {
+            __syncthreads();
+            pair_dx_scatter(us, dx + img, border, tid, y0, x0, h, wd,
+                            ((size_t)blockIdx.z * ((h + RH - 1) / RH) + y0 / RH) * gridDim.x + blockIdx.x);
+        }
     }
+    pair_block_reduce(red, reddb, redb2, acc1, acc2, db1acc, db2acc, partial);
 }
 
 // block (k, q): float64 sum of the block partials -> dw1 / dw2 [tap*16 + q*4 + j], db1[q*4 + j], db2
@@ -449,6 +742,18 @@ int pair_rows_per_block(int strips, int h, int n, int th, unsigned max_blocks) {
     return rows;
 }
 
+// the backward kernel of a storage type: float32 MFMAs for float, binary16 MFMAs for _Float16
+template <typename TA>
+auto pair_bwd_kernel_for(bool dx, bool sig) {
+    if constexpr (std::is_same<TA, _Float16>::value) {
+        return dx ? (sig ? conv_pair_bwd_h_kernel<true, true> : conv_pair_bwd_h_kernel<true, false>)
+                  : (sig ? conv_pair_bwd_h_kernel<false, true> : conv_pair_bwd_h_kernel<false, false>);
+    } else {
+        return dx ? (sig ? conv_pair_bwd_kernel<true, true, TA> : conv_pair_bwd_kernel<true, false, TA>)
+                  : (sig ? conv_pair_bwd_kernel<false, true, TA> : conv_pair_bwd_kernel<false, false, TA>);
+    }
+}
+
 int check_pair(uocr_ctx* ctx, int dtype, int n, int h, int w, int cmid, int act2) {
     if (UOCR_DTYPE_BASE(dtype) != UOCR_F32 && UOCR_DTYPE_BASE(dtype) != UOCR_F16)
         UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "conv_pair: float32 / float16 only");
@@ -471,11 +776,14 @@ extern "C" int uocr_conv_pair_fwd(uocr_ctx* ctx, int dtype, const void* x, const
     const int strips = (w + RW - 3) / (RW - 2);
     const int rows_per_block = pair_rows_per_block(strips, h, n, RH - 2, 8192u);
     const dim3 grid(strips, (h + rows_per_block - 1) / rows_per_block, n);
-    UOCR_DISPATCH_TA(ctx, dtype, {
-        hipLaunchKernelGGL((conv_pair_fwd_kernel<TA>), grid, dim3(256), 0, ctx->stream, (const TA*)x, (const float*)w1,
-                           (const float*)b1, (const float*)w2, (const float*)b2, (TA*)y, h, w, rows_per_block,
+    if (UOCR_DTYPE_BASE(dtype) == UOCR_F16)
+        hipLaunchKernelGGL(conv_pair_fwd_h_kernel, grid, dim3(256), 0, ctx->stream, (const _Float16*)x, (const float*)w1,
+                           (const float*)b1, (const float*)w2, (const float*)b2, (_Float16*)y, h, w, rows_per_block,
                            (float)pad_value1, use_bias1, use_bias2, (float)alpha1, act2);
-    });
+    else
+        hipLaunchKernelGGL(conv_pair_fwd_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float*)x,
+                           (const float*)w1, (const float*)b1, (const float*)w2, (const float*)b2, (float*)y, h, w,
+                           rows_per_block, (float)pad_value1, use_bias1, use_bias2, (float)alpha1, act2);
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
 }
@@ -501,16 +809,10 @@ extern "C" int uocr_conv_pair_bwd(uocr_ctx* ctx, int dtype, const void* x, const
     const dim3 grid(strips, bands, n);
     const bool sig = act2 == UOCR_ACT_SIGMOID;
     UOCR_DISPATCH_TA(ctx, dtype, {
-        auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, grid, dim3(256), 0, ctx->stream, (const TA*)x, (const TA*)y, (const TA*)dy,
-                               (const float*)w1, (const float*)b1, (const float*)w2, partial, (TA*)dx,
-                               dx ? border : (float*)nullptr, h, w, rows_per_block, (float)pad_value1, use_bias1,
-                               (float)alpha1);
-        };
-        if (dx && sig) launch(conv_pair_bwd_kernel<true, true, TA>);
-        else if (dx) launch(conv_pair_bwd_kernel<true, false, TA>);
-        else if (sig) launch(conv_pair_bwd_kernel<false, true, TA>);
-        else launch(conv_pair_bwd_kernel<false, false, TA>);
+        hipLaunchKernelGGL(pair_bwd_kernel_for<TA>(dx != nullptr, sig), grid, dim3(256), 0, ctx->stream, (const TA*)x,
+                           (const TA*)y, (const TA*)dy, (const float*)w1, (const float*)b1, (const float*)w2, partial,
+                           (TA*)dx, dx ? border : (float*)nullptr, h, w, rows_per_block, (float)pad_value1, use_bias1,
+                           (float)alpha1);
         UOCR_LAUNCH_CHECK(ctx);
         if (dx) {
             hipLaunchKernelGGL((conv_pair_dx_border<TA>), dim3(strips, tiles_y, n), dim3(128), 0, ctx->stream,
