@@ -99,6 +99,8 @@ CONVS = [
     ((2, 40, 72, 4), (5, 5), 4, (1, 1), (2, 2), 0.0),     # 4 -> 4 stride 1 (LDS-tiled forward)
     ((2, 40, 72, 4), (5, 5), 2, (1, 1), (2, 2), 0.0),     # Line end (t542 kernels)
     ((2, 33, 47, 4), (5, 5), 2, (1, 1), (2, 2), 0.0),     # ... ragged tiles, odd width
+    ((1, 70, 130, 4), (5, 5), 2, (1, 1), (2, 2), 0.75),   # ... several 32 x 64 tiles per strip, padding value
+    ((2, 37, 66, 4), (5, 5), 4, (1, 1), (2, 2), 0.0),     # 4 -> 4 stride 1, ragged
     ((2, 21, 35, 1), (3, 3), 16, (1, 1), (1, 1), 0.5),    # Monochrome conv_1 unfused, padding value
     ((2, 21, 35, 16), (3, 3), 1, (1, 1), (1, 1), 0.0),    # Monochrome conv_2 unfused
     ((3, 11, 13, 6), (4, 4), 7, (2, 1), (1, 2), 0.25),    # generic kernels
@@ -116,6 +118,9 @@ def test_conv_kernels_f16(case, f16):
     b = rng.standard_normal(cout)
     X16 = r16(X)
     w32, b32 = w.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64)
+    if xs[3] == 4 and ks == (5, 5) and st == (1, 1):
+        # binary16-MFMA kernels (conv_h16.hip): the float32 master weights enter the matrix cores rounded to binary16
+        w32 = r16(w32)
     ref_y = O.conv2d_fwd(X16, w32, b32, st, pd, pv, True)
     g = rng.standard_normal(ref_y.shape)
     g16 = r16(g)
@@ -142,7 +147,7 @@ def test_conv_kernels_f16(case, f16):
     assert rel_linf(CP.asnumpy(db), ref_db / 16 + 0.25) <= TOL_EXACT
 
 
-@pytest.mark.parametrize('ch,hl,wl', [(4, 24, 40), (1, 24, 40), (4, 17, 33), (1, 19, 21)])
+@pytest.mark.parametrize('ch,hl,wl', [(4, 24, 40), (1, 24, 40), (4, 17, 33), (1, 19, 21), (4, 40, 70)])
 def test_upconv2x_f16(ch, hl, wl, f16):
     """Upsample2D(2) + conv5x5 on the low-res tensor (uocr_upconv2x_*) against the two layers of the oracle."""
     from univer_ocr_amd.nn import ops
@@ -164,7 +169,12 @@ def test_upconv2x_f16(ch, hl, wl, f16):
     assert y.dtype == np.float16 and rel_linf(CP.asnumpy(y), ref_y) <= TOL_STORE
     gd.gscale = 2
     dx = ops.upconv2x_bwd_data(gd, wd, xd.shape, (2, 2))
-    assert dx.gscale == 2 and rel_linf(CP.asnumpy(dx), ref_dx) <= TOL_STORE
+    # 4 channels: binary16 MFMAs over dy with the phase-summed weights rounded to binary16 (conv_h16.hip): 3e-3
+    assert dx.gscale == 2 and rel_linf(CP.asnumpy(dx), ref_dx) <= (3e-3 if ch == 4 else TOL_STORE)
+    mask_src = CP.copy(np.where(rng.random(xl.shape) < 0.5, -1.0, 1.0) * np.abs(xl))
+    dxm = ops.upconv2x_bwd_data(gd, wd, xd.shape, (2, 2), x_act=mask_src, act='leaky', alpha=0.01)
+    slope = np.where(CP.asnumpy(mask_src).astype(np.float64) >= 0, 1.0, 0.01)
+    assert rel_linf(CP.asnumpy(dxm), ref_dx * slope) <= (3e-3 if ch == 4 else TOL_STORE)
     dw, db = CP.zeros(w.shape, np.float32), CP.zeros(b.shape, np.float32)
     ops.upconv2x_bwd_weight(xd, gd, dw, db, (2, 2), True, accumulate=False)
     assert rel_linf(CP.asnumpy(dw), ref_dw / 4) <= TOL_EXACT

@@ -29,6 +29,8 @@ int uocr_conv2d_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, cons
     if (rc) return rc;
     UOCR_REQUIRE(ctx, x && w && y && (b || !use_bias));
     UOCR_REQUIRE(ctx, act >= UOCR_ACT_NONE && act <= UOCR_ACT_SIGMOID);
+    if (uocr_conv_h16_eligible(ctx, dtype, d, 0) && uocr_aligned_act(x, dtype) && uocr_aligned_act(y, dtype))
+        return uocr_conv_fwd_h16(ctx, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
     if (uocr_conv_tiled_eligible(ctx, dtype, d) && uocr_aligned_act(x, dtype) && uocr_aligned_act(y, dtype))
         return uocr_conv_fwd_tiled(ctx, dtype, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
     if (uocr_conv_fast_eligible(ctx, dtype, d, x, y, w))
@@ -48,6 +50,9 @@ int uocr_conv2d_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, const void* w
     UOCR_REQUIRE(ctx, dy && w && dx);
     UOCR_REQUIRE(ctx, act == UOCR_ACT_NONE || (x_act && (act == UOCR_ACT_SIGMOID || (act == UOCR_ACT_LEAKY && act_alpha > 0))));
     const ActMask mask{act == UOCR_ACT_NONE ? nullptr : x_act, act, act_alpha};
+    if (uocr_conv_h16_eligible(ctx, dtype, d, 1) && uocr_aligned_act(dy, dtype) && uocr_aligned_act(dx, dtype) &&
+        (!mask.y || uocr_aligned_act(mask.y, dtype)))
+        return uocr_conv_dgrad_h16(ctx, dy, w, dx, d, mask);
     if (uocr_conv_fast_eligible(ctx, dtype, d, dy, dx, w)) return uocr_conv_dgrad_fast(ctx, dtype, dy, w, dx, d, mask);
     if (uocr_conv_mfma_eligible(ctx, dtype, d, 1)) return uocr_conv_dgrad_mfma(ctx, dy, w, dx, d, mask);
     return uocr_conv_dgrad_generic(ctx, dtype, dy, w, dx, d, mask);

@@ -23,6 +23,14 @@ int uocr_conv_dgrad_mfma(uocr_ctx* ctx, const void* dy, const void* w, void* dx,
                          const ActMask& mask);
 int uocr_conv_wgrad_mfma(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
                          double pad_value, int use_bias, int accumulate);
+// binary16-MFMA kernels of the small-channel convs (conv_h16.hip), UOCR_F16 only; which: 0 fwd, 1 dgrad
+bool uocr_conv_h16_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d, int which);
+int uocr_conv_fwd_h16(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
+                      double pad_value, int use_bias, int act, double act_alpha);
+int uocr_conv_dgrad_h16(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d, const ActMask& mask);
+bool uocr_upconv_h16_eligible(uocr_ctx* ctx, int dtype, int cin, int cout);
+int uocr_upconv_dgrad_h16(uocr_ctx* ctx, const void* dy, const void* w, void* dx_low, int n, int hl, int wl,
+                          const void* mask_y, int mask_act, double mask_alpha);
 // LDS-tiled forward for the 5x5 stride-1 4-channel convs (conv_tiled.hip), f32 / f16 storage
 bool uocr_conv_tiled_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d);
 int uocr_conv_fwd_tiled(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* b, void* y, const ConvDims& d,

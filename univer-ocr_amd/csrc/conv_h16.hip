@@ -1,0 +1,364 @@
+// Small-channel convolutions of the page nets for binary16 storage (UOCR_F16) on v_mfma_f32_16x16x16_f16
+// (reference layers: nn/layers/convolutional.py:62-145, nn/layers/upsample.py:21-39 as chained by
+// my_model/model.py:194-247).
+//
+// With 1-4 channels a 5x5 convolution is vector-ALU bound (200-400 FMAs per pixel for 12-16 bytes) and as an
+// im2col GEMM it wastes the matrix cores: 2 or 4 result columns out of 16.  Here the 16 result rows of an MFMA
+// are (vertical shift dy, output channel): a VERTICAL TOEPLITZ operand.  For an output block of 16 columns x DY
+// rows (DY = 16 / channels) the window is the (DY-1)*S + KH input rows the block touches; row m = (dy, co) of
+// the weight operand holds w[ty' - dy*S][tx][ci][co] (zero outside the kernel), so ONE chain of MFMAs over the
+// window produces all DY rows and every lane of the result is a real output:
+//       D[(dy, co), col] = sum_{ty', tx, ci} Wt[(dy, co), (ty', tx, ci)] * X[row0*S + ty', col*S + tx, ci]
+// The K index of an MFMA is (k-group kq = lane / 16, j = 0..3) = 4 consecutive binary16 values of one window
+// row: with channels-last storage that is one pixel (C = 4), two pixels (C = 2) -- a single 8-byte LDS read of
+// the staged input tile, no packing instructions.  k-group kq of MFMA (ib, q) is window row 4*ib + kq, halves
+// 4q..4q+3 of the row segment that starts at the output column: the LDS address is lane base + immediate.
+// Result layout D[m = 4*kq + i][n = column]: lane (column, kq) holds 4 values that are contiguous in memory
+// (the channels of a pixel, or two 2-channel pixels rows apart): 8- / 4-byte stores, 16 lanes = 128 / 64 bytes.
+//
+// MFMAs per output pixel (executed / 16 cycles each): 5x5 4->2: 15 per 128 px; 5x5 2->4 (its backward-data): 6
+// per 64; upsample+5x5 backward-data as a stride-2 6x6 window over dy (4->4): 18 per 64 low-res = 256 high-res
+// pixels.  The float32 master weights are rounded to binary16 as operands; accumulation is float32.
+// A zero weight still multiplies what the tile holds there: inputs must be finite.
+// hipcc-flags: -mllvm -amdgpu-mfma-vgpr-form=1
+#include <type_traits>
+
+#include "conv_dims.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+
+enum Mode {
+    M_FWD = 0,       // forward conv, w[ky][kx][ci][co]
+    M_DGRAD = 1,     // backward-data of a stride-1 conv: input dy (C = cout), flipped taps, w[ky][kx][co_out][ci_in]
+    M_UPDGRAD = 2,   // backward-data of upsample2x + 5x5: stride-2 6x6 window over dy, taps summed per parity phase
+};
+
+__device__ __forceinline__ f32x4 mfma16(f16x4 a, f16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float act_apply(float v, int act, float alpha) {
+    switch (act) {
+        case UOCR_ACT_RELU: return v * (v >= 0.f ? 1.f : 0.f);
+        case UOCR_ACT_LEAKY: return v * ((v >= 0.f ? 1.f : 0.f) + alpha * (v < 0.f ? 1.f : 0.f));
+        case UOCR_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+// taps k of one axis of the 5x5 kernel that land on source offset mi - 1 for output parity `phase`: [lo, hi)
+// (upsample2x + conv, see conv_up.hip)
+__device__ __forceinline__ void tap_group(int phase, int mi, int& lo, int& hi) {
+    if (phase == 0) {
+        lo = 2 * mi;
+        hi = mi == 2 ? 5 : 2 * mi + 2;
+    } else {
+        lo = mi == 0 ? 0 : 2 * mi - 1;
+        hi = mi == 0 ? 1 : 2 * mi + 1;
+    }
+}
+
+constexpr int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// smallest row stride (halves, a multiple of 4) >= need whose dword count is == target (mod mod)
+constexpr int pick_stride(int need, int mod, int target) {
+    int rs = round_up(need, 4);
+    while ((rs / 2) % mod != target) rs += 4;
+    return rs;
+}
+
+template <int C_, int COUT_, int KH_, int KW_, int S_, int MODE_>
+struct Geo {
+    static constexpr int C = C_, COUT = COUT_, KH = KH_, KW = KW_, S = S_, MODE = MODE_;
+    static constexpr int DY = 16 / COUT;                       // output rows of one MFMA chain
+    static constexpr int ROWS = (DY - 1) * S + KH;             // window rows of one chain
+    static constexpr int IB = (ROWS + 3) / 4;                  // row quads
+    static constexpr int Q = (KW * C + 3) / 4;                 // 4-half chunks per window row
+    static constexpr int NM = IB * Q;                          // MFMAs per chain
+    static constexpr int BC = 64;                              // output columns of a block tile (4 chains)
+    static constexpr int RPW = S == 1 ? 32 / (4 * DY) : 16 / (4 * DY);   // chains (row bands) per wave
+    static constexpr int BR = 4 * RPW * DY;                    // output rows of a block tile
+    static constexpr int IH = (BR - 1) * S + KH;               // staged input rows
+    static constexpr int IHA = (BR - DY) * S + 4 * IB;         // rows a chain may address (the rest stays zero)
+    static constexpr int PXU = 8 / C;                          // pixels per 16-byte staging unit
+    static constexpr int UW = ((BC - 1) * S * C + Q * 4 + 7) / 8;        // staging units per tile row
+    // row stride in halves.  A chain's ds_read_b64 takes 2 LDS passes at best (64 lanes x 8 bytes); the rows kq and
+    // kq + 1 of a half wave must then fall on complementary banks: lanes are 2 dwords apart (C = 4), 1 (C = 2),
+    // 4 (stride 2)
+    static constexpr int RS = S == 2 ? pick_stride(UW * 8, 4, 2) : pick_stride(UW * 8, 64, C == 4 ? 32 : 16);
+    static constexpr int RPP = 256 / UW;                       // tile rows staged per pass of the block
+    static constexpr int NPASS = (IH + RPP - 1) / RPP;
+    static constexpr int NW = (MODE == M_UPDGRAD ? 25 : KH * KW) * C * COUT;   // float32 weights of the layer
+    static_assert(RPW >= 1 && 16 % COUT == 0 && (C == 2 || C == 4) && UW <= 256, "unsupported geometry");
+};
+
+// weight of window position (ty, tx), input channel ci, output channel co, from the layer's float32 weights
+// (w = their copy in LDS: every lane builds its NM x 4 operand values from it once per block)
+template <class G>
+__device__ __forceinline__ float weight_of(const float* w, int ty, int tx, int ci, int co) {
+    if constexpr (G::MODE == M_FWD) {
+        return w[((ty * G::KW + tx) * G::C + ci) * G::COUT + co];
+    } else if constexpr (G::MODE == M_DGRAD) {
+        // dx[p][co] = sum dy[p + t - pad'][ci] w[K-1-t][co][ci]
+        return w[(((G::KH - 1 - ty) * G::KW + (G::KW - 1 - tx)) * G::COUT + co) * G::C + ci];
+    } else {
+        // dxl[Q][co] = sum_{a,b in 0..5} dy[2Q - 2 + (a,b)][ci] Weff[phase (a%2, b%2)][o = (4 - a + py) / 2, ..][co][ci],
+        // Weff = the 5x5 taps of the phase that share a source pixel (at most 2 x 2 of them), summed
+        const int py = ty & 1, px = tx & 1;
+        int ylo, yhi, xlo, xhi;
+        tap_group(py, (4 - ty + py) >> 1, ylo, yhi);
+        tap_group(px, (4 - tx + px) >> 1, xlo, xhi);
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ky = min(ylo + a, 4), kx = min(xlo + b, 4);
+                const float v = w[((ky * 5 + kx) * G::COUT + co) * G::C + ci];
+                s += (ylo + a < yhi && xlo + b < xhi) ? v : 0.f;
+            }
+        return s;
+    }
+}
+
+template <class G>
+__device__ __forceinline__ f16x4 read_chunk(const _Float16* p) {
+    if constexpr (G::C == 4) {
+        return *reinterpret_cast<const f16x4*>(p);                       // 8-byte aligned: one pixel
+    } else {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(p);        // 4-byte aligned: two 2-channel pixels
+        const u32x2 v = {q[0], q[1]};
+        return __builtin_bit_cast(f16x4, v);
+    }
+}
+
+__device__ __forceinline__ float fast_act(float v, int act, float alpha) {
+    // binary16 results: v_exp_f32 / v_rcp_f32 (1 ulp of float32) are exact enough by a factor of 2^12
+    if (act == UOCR_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.f + __expf(-v));
+    if (act == UOCR_ACT_LEAKY) return v >= 0.f ? v : alpha * v;
+    if (act == UOCR_ACT_RELU) return v >= 0.f ? v : 0.f;
+    return v;
+}
+
+// Persistent blocks over a flat tile index (image, tile row, column strip): block b takes tiles b, b + grid, ...
+// (all tiles cost the same, so the chip is balanced to within one tile).  A tile is BR x BC outputs; wave w owns
+// its row bands w*RPW .. w*RPW + RPW - 1 (DY rows each), four chains of 16 columns per band.
+//   in      [n][h_in][w_in][C]     binary16
+//   out     [n][h_out][w_out][COUT] binary16;  mask_y (backward-data: the activation OUTPUT of the layer below,
+//           same shape as out) multiplies the result by act'(y)
+template <class G>
+__global__ __launch_bounds__(256) void conv_h16_kernel(const _Float16* __restrict__ in, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, _Float16* __restrict__ out,
+                                                       const _Float16* __restrict__ mask_y, int h_in, int w_in,
+                                                       int h_out, int w_out, int ph, int pw, int tiles_x, int tiles_y,
+                                                       int ntiles, float pad, int use_bias, int act, float alpha,
+                                                       int mask_act, float mask_alpha) {
+    constexpr int C = G::C, COUT = G::COUT, S = G::S, RS = G::RS;
+    __shared__ __attribute__((aligned(16))) _Float16 tile[G::IHA * RS];
+    __shared__ float wl[G::NW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
+
+    // the rows / halves no load ever writes must read as zero (their weights are zero, 0 * garbage is not)
+    for (int i = tid; i < G::IHA * RS / 4; i += 256) reinterpret_cast<uint64_t*>(tile)[i] = 0;
+    for (int i = tid; i < G::NW; i += 256) wl[i] = w[i];
+    __syncthreads();
+
+    // weight operand: row m = lane % 16 = (dy, co), k-group kq = window row 4*ib + kq, j = half 4q + j of the row
+    f16x4 wa[G::NM];
+    {
+        const int m = n, dyi = m / COUT, co = m % COUT;
+#pragma unroll
+        for (int ib = 0; ib < G::IB; ++ib)
+#pragma unroll
+            for (int q = 0; q < G::Q; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ty = 4 * ib + kq - dyi * S, hh = 4 * q + j, tx = hh / C, ci = hh % C;
+                    const bool live = ty >= 0 && ty < G::KH && tx < G::KW;
+                    wa[ib * G::Q + q][j] =
+                        live ? (_Float16)weight_of<G>(wl, min(max(ty, 0), G::KH - 1), min(tx, G::KW - 1), ci, co)
+                             : (_Float16)0.f;
+                }
+    }
+    float bias4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias4[i] = use_bias ? bias[(4 * kq + i) % COUT] : 0.f;
+    const uint32_t padw = __builtin_bit_cast(uint32_t, f16x2{(_Float16)pad, (_Float16)pad});
+    // staging role of this thread: 16-byte unit su of tile rows sr, sr + RPP, ...
+    const int sr = tid / G::UW, su = tid - sr * G::UW;
+    const bool stager = sr < G::RPP;
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int strip = t % tiles_x, trow = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+        const int c_begin = strip * G::BC, r0 = trow * G::BR;
+        const _Float16* inb = in + (size_t)img * h_in * w_in * C;
+        const size_t out_img = (size_t)img * h_out * w_out * COUT;
+        __syncthreads();                                 // the previous tile's reads are over (and the zero fill)
+        // ---- stage the input tile: pixel (iy0 + r, ix0 + c) -> tile[r][c*C ..], padding outside the image.
+        // The column part of a thread's address and its in-image bits are the same for all its rows.
+        if (stager) {
+            const int iy0 = r0 * S - ph, gx0 = c_begin * S - pw + su * G::PXU;
+            bool in_px[G::PXU];
+            bool all_in = true, any_in = false;
+#pragma unroll
+            for (int k = 0; k < G::PXU; ++k) {
+                in_px[k] = (unsigned)(gx0 + k) < (unsigned)w_in;
+                all_in = all_in && in_px[k];
+                any_in = any_in || in_px[k];
+            }
+            const int col_off = min(max(gx0, 0), w_in - 1) * C;
+            uint4 v[G::NPASS];
+#pragma unroll
+            for (int k = 0; k < G::NPASS; ++k) {
+                const int gy = iy0 + sr + k * G::RPP;
+                const bool row_ok = (unsigned)gy < (unsigned)h_in;
+                const _Float16* src = inb + (size_t)min(max(gy, 0), h_in - 1) * w_in * C;
+                v[k] = uint4{padw, padw, padw, padw};
+                if (row_ok && all_in) {
+                    v[k] = *reinterpret_cast<const uint4*>(src + col_off);      // (4-byte aligned at least)
+                } else if (row_ok && any_in) {                                   // the image edge cuts the unit
+                    uint32_t* vw = reinterpret_cast<uint32_t*>(&v[k]);
+#pragma unroll
+                    for (int px = 0; px < G::PXU; ++px)
+                        if (in_px[px]) {
+                            const uint32_t* sp = reinterpret_cast<const uint32_t*>(src + (size_t)(gx0 + px) * C);
+#pragma unroll
+                            for (int d = 0; d < C / 2; ++d) vw[px * (C / 2) + d] = sp[d];
+                        }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < G::NPASS; ++k) {
+                const int r = sr + k * G::RPP;
+                if (r < G::IH) {
+                    uint64_t* dst = reinterpret_cast<uint64_t*>(tile + r * RS + su * 8);
+                    dst[0] = (uint64_t)v[k].x | ((uint64_t)v[k].y << 32);
+                    dst[1] = (uint64_t)v[k].z | ((uint64_t)v[k].w << 32);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- chains
+#pragma unroll
+        for (int s = 0; s < G::RPW; ++s) {
+            const int rb = (wv * G::RPW + s) * G::DY;    // first output row of the band, relative to the tile
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) {
+                const _Float16* base = tile + (rb * S + kq) * RS + (cg * 16 + n) * S * C;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ib = 0; ib < G::IB; ++ib)
+#pragma unroll
+                    for (int q = 0; q < G::Q; ++q)
+                        acc = mfma16(wa[ib * G::Q + q], read_chunk<G>(base + ib * 4 * RS + 4 * q), acc);
+                // lane (column n, kq): rows m = 4kq + i of the result = (dy, co)
+                const int col = c_begin + cg * 16 + n;
+                if (col >= w_out) continue;
+                if constexpr (COUT == 4) {
+                    const int row = r0 + rb + kq;
+                    if (row >= h_out) continue;
+                    const size_t off = out_img + ((size_t)row * w_out + col) * 4;
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = fast_act(acc[i] + bias4[i], act, alpha);
+                    if (mask_act != UOCR_ACT_NONE) {
+                        const float4 my = ld4(mask_y + off);
+                        v[0] *= act_grad_from_output<float>(my.x, mask_act, mask_alpha);
+                        v[1] *= act_grad_from_output<float>(my.y, mask_act, mask_alpha);
+                        v[2] *= act_grad_from_output<float>(my.z, mask_act, mask_alpha);
+                        v[3] *= act_grad_from_output<float>(my.w, mask_act, mask_alpha);
+                    }
+                    st4(out + off, make_float4(v[0], v[1], v[2], v[3]));
+                } else {                                 // COUT == 2: rows 2kq, 2kq + 1, both channels each
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int row = r0 + rb + 2 * kq + hh;
+                        if (row >= h_out) continue;
+                        const size_t off = out_img + ((size_t)row * w_out + col) * 2;
+                        float v0 = fast_act(acc[2 * hh] + bias4[2 * hh], act, alpha);
+                        float v1 = fast_act(acc[2 * hh + 1] + bias4[2 * hh + 1], act, alpha);
+                        if (mask_act != UOCR_ACT_NONE) {
+                            const float2 my = ld2(mask_y + off);
+                            v0 *= act_grad_from_output<float>(my.x, mask_act, mask_alpha);
+                            v1 *= act_grad_from_output<float>(my.y, mask_act, mask_alpha);
+                        }
+                        st2(out + off, make_float2(v0, v1));
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <class G>
+int launch_h16(uocr_ctx* ctx, const void* in, const void* w, const void* bias, void* out, const void* mask_y, int n,
+               int h_in, int w_in, int h_out, int w_out, int ph, int pw, float pad, int use_bias, int act, float alpha,
+               int mask_act, float mask_alpha) {
+    static int resident = 0;                             // blocks of this kernel one CU holds
+    if (resident == 0) {
+        int nb = 0;
+        UOCR_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_h16_kernel<G>, 256, 0));
+        resident = nb > 0 ? nb : 1;
+    }
+    const int tiles_x = (w_out + G::BC - 1) / G::BC, tiles_y = (h_out + G::BR - 1) / G::BR;
+    const long ntiles = (long)n * tiles_y * tiles_x;
+    UOCR_REQUIRE(ctx, ntiles < (1l << 31) && (long)h_in * w_in * G::C < (1l << 31));
+    const int grid = (int)(ntiles < (long)ctx->cu_count * resident ? ntiles : (long)ctx->cu_count * resident);
+    hipLaunchKernelGGL(conv_h16_kernel<G>, dim3(grid), dim3(256), 0, ctx->stream, (const _Float16*)in, (const float*)w,
+                       (const float*)bias, (_Float16*)out, (const _Float16*)mask_y, h_in, w_in, h_out, w_out, ph, pw,
+                       tiles_x, tiles_y, (int)ntiles, pad, use_bias, act, alpha, mask_act, mask_alpha);
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
+}
+
+inline bool same5x5(const ConvDims& d) {
+    return d.kh == 5 && d.kw == 5 && d.sh == 1 && d.sw == 1 && d.ph == 2 && d.pw == 2 && d.oh == d.h && d.ow == d.w;
+}
+
+}  // namespace
+
+// which: 0 forward, 1 backward-data
+bool uocr_conv_h16_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d, int which) {
+    if (UOCR_DTYPE_BASE(dtype) != UOCR_F16 || !ctx->opt_fast || !ctx->opt_h16 || d.n > 65535) return false;
+    if (!same5x5(d)) return false;
+    return d.cin == 4 && (d.cout == 2 || d.cout == 4);
+    (void)which;
+}
+
+int uocr_conv_fwd_h16(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
+                      double pad_value, int use_bias, int act, double act_alpha) {
+    if (d.cout == 2)
+        return launch_h16<Geo<4, 2, 5, 5, 1, M_FWD>>(ctx, x, w, b, y, nullptr, d.n, d.h, d.w, d.oh, d.ow, d.ph, d.pw,
+                                                     (float)pad_value, use_bias, act, (float)act_alpha, UOCR_ACT_NONE,
+                                                     0.f);
+    return launch_h16<Geo<4, 4, 5, 5, 1, M_FWD>>(ctx, x, w, b, y, nullptr, d.n, d.h, d.w, d.oh, d.ow, d.ph, d.pw,
+                                                 (float)pad_value, use_bias, act, (float)act_alpha, UOCR_ACT_NONE, 0.f);
+}
+
+int uocr_conv_dgrad_h16(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d,
+                        const ActMask& mask) {
+    // a forward conv over dy with flipped taps: padding kh - 1 - ph
+    if (d.cout == 2)
+        return launch_h16<Geo<2, 4, 5, 5, 1, M_DGRAD>>(ctx, dy, w, nullptr, dx, mask.y, d.n, d.oh, d.ow, d.h, d.w,
+                                                       d.kh - 1 - d.ph, d.kw - 1 - d.pw, 0.f, 0, UOCR_ACT_NONE, 0.f,
+                                                       mask.y ? mask.act : UOCR_ACT_NONE, (float)mask.alpha);
+    return launch_h16<Geo<4, 4, 5, 5, 1, M_DGRAD>>(ctx, dy, w, nullptr, dx, mask.y, d.n, d.oh, d.ow, d.h, d.w,
+                                                   d.kh - 1 - d.ph, d.kw - 1 - d.pw, 0.f, 0, UOCR_ACT_NONE, 0.f,
+                                                   mask.y ? mask.act : UOCR_ACT_NONE, (float)mask.alpha);
+}
+
+// backward-data of Upsample2D(2) + conv 5x5 / padding 2, 4 -> 4 channels, on the low-res grid (conv_up.hip)
+bool uocr_upconv_h16_eligible(uocr_ctx* ctx, int dtype, int cin, int cout) {
+    return UOCR_DTYPE_BASE(dtype) == UOCR_F16 && ctx->opt_fast && ctx->opt_h16 && cin == 4 && cout == 4;
+}
+
+int uocr_upconv_dgrad_h16(uocr_ctx* ctx, const void* dy, const void* w, void* dx_low, int n, int hl, int wl,
+                          const void* mask_y, int mask_act, double mask_alpha) {
+    return launch_h16<Geo<4, 4, 6, 6, 2, M_UPDGRAD>>(ctx, dy, w, nullptr, dx_low, mask_y, n, 2 * hl, 2 * wl, hl, wl, 2, 2,
+                                                     0.f, 0, UOCR_ACT_NONE, 0.f, mask_y ? mask_act : UOCR_ACT_NONE,
+                                                     (float)mask_alpha);
+}

@@ -556,6 +556,9 @@ extern "C" int uocr_upconv2x_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, 
     UOCR_REQUIRE(ctx, act == UOCR_ACT_NONE || x_act != nullptr);
     int rc = check_up(ctx, dtype, n, hl, wl, cin, cout, kh, kw, ph, pw);
     if (rc != UOCR_OK) return rc;
+    if (uocr_upconv_h16_eligible(ctx, dtype, cin, cout) && uocr_aligned_act(dy, dtype) &&
+        uocr_aligned_act(dx_low, dtype) && (act == UOCR_ACT_NONE || uocr_aligned_act(x_act, dtype)))
+        return uocr_upconv_dgrad_h16(ctx, dy, w, dx_low, n, hl, wl, act == UOCR_ACT_NONE ? nullptr : x_act, act, act_alpha);
     float* weff = nullptr;
     if (cin != 1) {
         rc = uocr_need_workspace(ctx, NWEFF * sizeof(float));

@@ -25,6 +25,7 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->opt_split = 1024;
     ctx->opt_split_min = 3;
     ctx->opt_bm = 0;
+    ctx->opt_h16 = 1;
     ctx->opt_xcd = 1;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -76,6 +77,7 @@ int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "split_min")) ctx->opt_split_min = value;
     else if (!strcmp(key, "gemm_bm")) ctx->opt_bm = value;
     else if (!strcmp(key, "xcd_remap")) ctx->opt_xcd = value;
+    else if (!strcmp(key, "h16")) ctx->opt_h16 = value;
     else UOCR_FAIL(ctx, UOCR_ERR_ARG, "unknown option '%s'", key);
     return UOCR_OK;
 }

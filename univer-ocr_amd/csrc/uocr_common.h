@@ -21,6 +21,7 @@ struct uocr_ctx {
     int opt_split_min;   // ... but only when that takes at least this many slabs (a 2-way split rarely pays its reduce)
     int opt_xcd;         // 1 = MFMA GEMM blocks are renumbered so that neighbours share an XCD (L2)
     int opt_bm;          // 0 = choose the MFMA GEMM row tile automatically, 64 / 128 = force it (experiments)
+    int opt_h16;         // 1 = binary16-MFMA kernels for the small-channel convs in UOCR_F16 mode (default)
     char err[512];
 };
 
