@@ -31,6 +31,12 @@ int uocr_conv_dgrad_h16(uocr_ctx* ctx, const void* dy, const void* w, void* dx, 
 bool uocr_upconv_h16_eligible(uocr_ctx* ctx, int dtype, int cin, int cout);
 int uocr_upconv_dgrad_h16(uocr_ctx* ctx, const void* dy, const void* w, void* dx_low, int n, int hl, int wl,
                           const void* mask_y, int mask_act, double mask_alpha);
+// ... their weight gradients (conv_h16w.hip)
+bool uocr_conv_wgrad_h16_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d);
+int uocr_conv_wgrad_h16(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
+                        double pad_value, int use_bias, int accumulate);
+int uocr_upconv_wgrad_h16(uocr_ctx* ctx, const void* x_low, const void* dy, float* partial, size_t partial_floats,
+                          int n, int hl, int wl, int* nblocks);
 // LDS-tiled forward for the 5x5 stride-1 4-channel convs (conv_tiled.hip), f32 / f16 storage
 bool uocr_conv_tiled_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d);
 int uocr_conv_fwd_tiled(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* b, void* y, const ConvDims& d,

@@ -1,0 +1,405 @@
+// Weight gradients of the Line net's 4-channel convolutions for binary16 storage (UOCR_F16) on
+// v_mfma_f32_16x16x16_f16 (reference: nn/layers/convolutional.py:101-145; upsample.py:21-39 for the decoder).
+//
+// dw contracts over POSITIONS, so the K index of an MFMA (4 consecutive binary16 values per lane) must run along
+// image columns for a fixed channel -- the transpose of channels-last storage.  The staging step therefore writes
+// channel PLANES into LDS (a 4x4 binary16 transpose in registers per 4 pixels, 64-bit LDS writes); an operand
+// that is read at arbitrary column shifts is stored as PAIR WORDS (word[c] = (v[c], v[c+1])) so that any 4
+// consecutive values are one ds_read2_b32.
+//
+// (1) 5x5, 4 -> 2, stride 1, padding 2 (the Line output conv):  with col = (dy column) - sx
+//         dw[ty][4 - sx][ci][co] = sum_{row, col} xpad[row + ty - 2][col + 2][ci] * dy[row][col + sx][co]
+//     i.e. the column shift of the tap lives on the dy operand (N = (co, sx): 10 of 16 columns), x is read at a
+//     fixed, 8-byte aligned offset, M = (ty, ci) = 20 rows -> 2 MFMAs per 16 positions (a plain im2col GEMM needs
+//     7 with 2 of 16 columns used).  Row 4 of the second M tile is all ones: its results are db.
+// (2) Upsample2D(2) + 5x5 4 -> 4 on the low-res grid (conv_up.hip): dWeff[(my, mx, ci), (phase, co)]
+//         = sum_pos xl[pos + m - 1][ci] * dy[2 pos + phase][co]:  N = (phase, co) = 16 columns exactly,
+//     M = (mx, ci) per source row my -> 3 MFMAs per 16 low-res positions = 64 dy pixels; the phase sums are folded
+//     back into the 5x5 kernel by conv_up.hip's finish kernel.
+// Blocks are persistent over a flat tile index; one reduction per block, float64 finish.
+// hipcc-flags: -mllvm -amdgpu-mfma-vgpr-form=1
+#include "conv_dims.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+
+__device__ __forceinline__ f32x4 mfma16(f16x4 a, f16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t lo_pair(uint32_t a, uint32_t b) { return (a & 0xFFFFu) | (b << 16); }
+__device__ __forceinline__ uint32_t hi_pair(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xFFFF0000u); }
+__device__ __forceinline__ f16x4 read8(const _Float16* p) { return *reinterpret_cast<const f16x4*>(p); }
+__device__ __forceinline__ f16x4 read_words(const uint32_t* p) {          // values c .. c+3 of a pair-word row
+    const u32x2 v = {p[0], p[2]};
+    return __builtin_bit_cast(f16x4, v);
+}
+constexpr uint32_t ONES = 0x3C003C00u;                                     // (1.0, 1.0) binary16
+
+// ------------------------------------------------------------------------------------------------------------
+// (1) 5x5 4 -> 2
+// ------------------------------------------------------------------------------------------------------------
+namespace e42 {
+constexpr int BR = 32, BC = 64;                  // positions per tile
+constexpr int XR = BR + 4;                       // x rows of a tile
+constexpr int XRS = 72;                          // x plane row stride (halves): 36 dwords, with XP = 16 (mod 64) dwords
+constexpr int XP = XR * XRS;                     //   the 16 (ty, ci) rows of an A read fall on disjoint banks
+constexpr int DRS = 72;                          // dy plane row stride (pair words): 64 + 4 shifts + 2, 16-byte rows
+constexpr int DP = BR * DRS + 32;                // dy plane stride (words): = 32 (mod 64)
+constexpr int NV = 202;                          // 200 dw + 2 db
+static_assert((XP / 2) % 64 == 16 && DP % 64 == 32, "bank layout");
+}  // namespace e42
+
+__global__ __launch_bounds__(256) void wgrad_h16_e42_kernel(const _Float16* __restrict__ x,
+                                                            const _Float16* __restrict__ dy,
+                                                            float* __restrict__ partial, int h, int wd, int tiles_x,
+                                                            int tiles_y, int ntiles, float pad) {
+    using namespace e42;
+    __shared__ __attribute__((aligned(16))) _Float16 xs[4 * XP + 8];      // [ci][row][col] (+ the ones)
+    __shared__ __attribute__((aligned(16))) uint32_t ds[2 * DP];          // [co][row][pair word]
+    __shared__ float red[4][NV];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
+    if (tid < 4) reinterpret_cast<uint32_t*>(xs + 4 * XP)[tid] = ONES;
+    // operand addresses of this lane inside a tile (group (r, c0) adds r * stride + c0)
+    const int m_ty = n >> 2, m_ci = n & 3;
+    const int a0 = m_ci * XP + m_ty * XRS + 4 * kq;                        // tile 0: ty = m / 4
+    const int a1 = m_ci * XP + 4 * XRS + 4 * kq;                           // tile 1: ty = 4 (rows 0..3), row 4 = ones
+    const bool ones_row = n == 4;
+    const int sx = min(n & 7, 4), co = n >> 3;
+    const int b0 = co * DP + 4 * kq + sx;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const uint32_t padw = __builtin_bit_cast(uint32_t, f16x2{(_Float16)pad, (_Float16)pad});
+    // staging roles: x unit = 4 columns x 4 channels (32 bytes), 16 units per row; dy unit = 4 pixels (16 bytes) +
+    // the next one, 18 units per row
+    const int xu = tid & 15, xr0 = tid >> 4;
+    const int du = tid % 18, dr0 = tid / 18;
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int strip = t % tiles_x, trow = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+        const int C0 = strip * BC - 4, R0 = trow * BR;
+        const _Float16* xb = x + (size_t)img * h * wd * 4;
+        const _Float16* gb = dy + (size_t)img * h * wd * 2;
+        __syncthreads();                                 // the previous tile's reads are over
+        {   // ---- x: image (R0 - 2 + r, C0 + 2 + 4 xu + p) -> planes
+            const int gx0 = C0 + 2 + 4 * xu;
+            const bool all_in = gx0 >= 0 && gx0 + 3 < wd, any_in = gx0 + 3 >= 0 && gx0 < wd;
+            uint4 v[3][2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int r = xr0 + 16 * k, gy = R0 - 2 + r;
+                const bool row_ok = r < XR && (unsigned)gy < (unsigned)h;
+                const _Float16* src = xb + ((size_t)min(max(gy, 0), h - 1) * wd) * 4;
+                v[k][0] = v[k][1] = uint4{padw, padw, padw, padw};
+                if (row_ok && all_in) {
+                    v[k][0] = *reinterpret_cast<const uint4*>(src + (size_t)gx0 * 4);
+                    v[k][1] = *reinterpret_cast<const uint4*>(src + (size_t)gx0 * 4 + 8);
+                } else if (row_ok && any_in) {
+                    uint32_t* vw = reinterpret_cast<uint32_t*>(&v[k][0]);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        if ((unsigned)(gx0 + p) < (unsigned)wd) {
+                            const uint32_t* sp = reinterpret_cast<const uint32_t*>(src + (size_t)(gx0 + p) * 4);
+                            vw[2 * p] = sp[0];
+                            vw[2 * p + 1] = sp[1];
+                        }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int r = xr0 + 16 * k;
+                if (r >= XR) continue;
+                // pixel p = dwords (2p, 2p+1) = (c0 | c1 << 16, c2 | c3 << 16); plane ci gets (P0.ci, P1.ci, P2.ci, P3.ci)
+                const uint32_t* d = reinterpret_cast<const uint32_t*>(&v[k][0]);
+                _Float16* row = xs + r * XRS + 4 * xu;
+                *reinterpret_cast<u32x2*>(row + 0 * XP) = u32x2{lo_pair(d[0], d[2]), lo_pair(d[4], d[6])};
+                *reinterpret_cast<u32x2*>(row + 1 * XP) = u32x2{hi_pair(d[0], d[2]), hi_pair(d[4], d[6])};
+                *reinterpret_cast<u32x2*>(row + 2 * XP) = u32x2{lo_pair(d[1], d[3]), lo_pair(d[5], d[7])};
+                *reinterpret_cast<u32x2*>(row + 3 * XP) = u32x2{hi_pair(d[1], d[3]), hi_pair(d[5], d[7])};
+            }
+        }
+        {   // ---- dy: image (R0 + r, C0 + 4 du + p), p = 0..4 -> pair-word planes, zero outside the image
+            const int gx0 = C0 + 4 * du;
+            const bool all_in = gx0 >= 0 && gx0 + 4 < wd, any_in = gx0 + 4 >= 0 && gx0 < wd;
+            uint32_t g[3][5];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int r = dr0 + 14 * k, gy = R0 + r;
+                const bool row_ok = r < BR && dr0 < 14 && gy < h;
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(gb + (size_t)min(gy, h - 1) * wd * 2);
+#pragma unroll
+                for (int p = 0; p < 5; ++p) g[k][p] = 0u;
+                if (row_ok && all_in) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(src + gx0);
+                    g[k][0] = q.x, g[k][1] = q.y, g[k][2] = q.z, g[k][3] = q.w;
+                    g[k][4] = src[gx0 + 4];
+                } else if (row_ok && any_in) {
+#pragma unroll
+                    for (int p = 0; p < 5; ++p)
+                        if ((unsigned)(gx0 + p) < (unsigned)wd) g[k][p] = src[gx0 + p];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int r = dr0 + 14 * k;
+                if (r >= BR || dr0 >= 14) continue;
+                uint32_t* row = ds + r * DRS + 4 * du;
+                *reinterpret_cast<uint4*>(row) = uint4{lo_pair(g[k][0], g[k][1]), lo_pair(g[k][1], g[k][2]),
+                                                       lo_pair(g[k][2], g[k][3]), lo_pair(g[k][3], g[k][4])};
+                *reinterpret_cast<uint4*>(row + DP) = uint4{hi_pair(g[k][0], g[k][1]), hi_pair(g[k][1], g[k][2]),
+                                                            hi_pair(g[k][2], g[k][3]), hi_pair(g[k][3], g[k][4])};
+            }
+        }
+        __syncthreads();
+        // ---- wave wv: rows wv, wv + 4, ...; 4 groups of 16 positions per row
+#pragma unroll 2
+        for (int r = wv; r < BR; r += 4) {
+#pragma unroll
+            for (int c0 = 0; c0 < BC; c0 += 16) {
+                const f16x4 b = read_words(ds + b0 + r * DRS + c0);
+                const f16x4 x0 = read8(xs + a0 + r * XRS + c0);
+                const f16x4 x1 = read8(xs + (ones_row ? 4 * XP : a1 + r * XRS + c0));
+                acc0 = mfma16(x0, b, acc0);
+                acc1 = mfma16(x1, b, acc1);
+            }
+        }
+    }
+    // ---- block reduction: lane (n = (co, sx), kq) holds dw[ty = kq][tx = 4 - sx][ci = i][co] (acc0),
+    // dw[4][4 - sx][i][co] (acc1, kq = 0) and db[co] (acc1[0] at kq = 1, sx = 0)
+    const bool col_ok = (n & 7) <= 4;
+    for (int i = tid; i < 4 * NV; i += 256) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+    if (col_ok) {
+        const int tx = 4 - (n & 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            red[wv][((kq * 5 + tx) * 4 + i) * 2 + co] = acc0[i];
+            if (kq == 0) red[wv][((4 * 5 + tx) * 4 + i) * 2 + co] = acc1[i];
+        }
+        if (kq == 1 && (n & 7) == 0) red[wv][200 + co] = acc1[0];
+    }
+    __syncthreads();
+    if (tid < NV) partial[(size_t)blockIdx.x * NV + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// block a: out[a] (+)= unscale * sum over blocks of partial[blk][a]; a < ndw -> dw, else db
+__global__ __launch_bounds__(256) void wgrad_h16_finish(const float* __restrict__ partial, int nv, int ndw,
+                                                        float* __restrict__ dw, float* __restrict__ db, int nblocks,
+                                                        int use_bias, int accumulate, float unscale) {
+    __shared__ double smem[16];
+    const int a = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += (double)partial[(size_t)i * nv + a];
+    s = block_reduce_sum(s, smem);
+    if (threadIdx.x != 0) return;
+    float* dst = a < ndw ? dw + a : db + (a - ndw);
+    if (a >= ndw && !use_bias) s = 0.0;
+    s *= (double)unscale;                                  // UOCR_F16_SCALED(k): 2^-k
+    *dst = accumulate ? (float)((double)*dst + s) : (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// (2) upsample2x + 5x5 4 -> 4 on the low-res grid
+// ------------------------------------------------------------------------------------------------------------
+namespace up {
+constexpr int BR = 16, BC = 64;                  // low-res positions per tile
+constexpr int XR = BR + 2, XRS = 68;             // xl pair-word planes: rows, row stride (words): 64 + 2 + lookahead
+constexpr int XPW = XR * XRS + 8;                // plane stride (words) = 16 (mod 64)
+constexpr int GRS = 64;                          // dy plane row stride (halves)
+constexpr int GP = BR * GRS + 8;                 // dy plane stride (halves): 516 dwords = 4 (mod 64)
+constexpr int NV = 36 * 16 + 4;
+static_assert(XPW % 64 == 16 && (GP / 2) % 64 == 4, "bank layout");
+}  // namespace up
+
+__global__ __launch_bounds__(256) void wgrad_h16_up_kernel(const _Float16* __restrict__ xl,
+                                                           const _Float16* __restrict__ dy,
+                                                           float* __restrict__ partial, int hl, int wl, int tiles_x,
+                                                           int tiles_y, int ntiles) {
+    using namespace up;
+    __shared__ __attribute__((aligned(16))) uint32_t xs[4 * XPW + 4];     // [ci][row][pair word] (+ the ones)
+    __shared__ __attribute__((aligned(16))) _Float16 gs[16 * GP];         // [(py, px, co)][row][col]
+    __shared__ float red[4][NV];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
+    if (tid < 4) xs[4 * XPW + tid] = ONES;
+    // A rows m = mx * 4 + ci (12 of 16; row 12 of the my = 0 tile is all ones -> db); B column n = (py, px, co)
+    const int mx = min(n >> 2, 2), ci = n & 3;
+    const int a0 = ci * XPW + 4 * kq + mx;
+    const bool ones_row = n == 12;
+    const int b0 = n * GP + 4 * kq;
+    f32x4 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int H = 2 * hl, W = 2 * wl;
+    // staging roles: xl unit = 4 pixels + the next one (40 bytes), 17 units per row; dy unit = 4 low-res columns of
+    // one high-res row = 8 pixels (64 bytes), 16 units per row
+    const int xu = tid % 17, xr0 = tid / 17;
+    const int gu = tid & 15, gr0 = tid >> 4;
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int strip = t % tiles_x, trow = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+        const int C0 = strip * BC, R0 = trow * BR;
+        const _Float16* xb = xl + (size_t)img * hl * wl * 4;
+        const _Float16* gb = dy + (size_t)img * H * W * 4;
+        __syncthreads();                                 // the previous tile's reads are over
+        {   // ---- xl: (R0 - 1 + r, C0 - 1 + 4 xu + p), p = 0..4 -> pair-word planes, zero outside
+            const int gx0 = C0 - 1 + 4 * xu;
+            const bool all_in = gx0 >= 0 && gx0 + 4 < wl, any_in = gx0 + 4 >= 0 && gx0 < wl;
+            uint32_t v[2][10];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int r = xr0 + 15 * k, gy = R0 - 1 + r;
+                const bool row_ok = r < XR && xr0 < 15 && (unsigned)gy < (unsigned)hl;
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(xb + (size_t)min(max(gy, 0), hl - 1) * wl * 4);
+#pragma unroll
+                for (int p = 0; p < 10; ++p) v[k][p] = 0u;
+                if (row_ok && all_in) {
+                    const uint4 q0 = *reinterpret_cast<const uint4*>(src + 2 * gx0);
+                    const uint4 q1 = *reinterpret_cast<const uint4*>(src + 2 * gx0 + 4);
+                    const uint2 q2 = *reinterpret_cast<const uint2*>(src + 2 * gx0 + 8);
+                    v[k][0] = q0.x, v[k][1] = q0.y, v[k][2] = q0.z, v[k][3] = q0.w;
+                    v[k][4] = q1.x, v[k][5] = q1.y, v[k][6] = q1.z, v[k][7] = q1.w;
+                    v[k][8] = q2.x, v[k][9] = q2.y;
+                } else if (row_ok && any_in) {
+#pragma unroll
+                    for (int p = 0; p < 5; ++p)
+                        if ((unsigned)(gx0 + p) < (unsigned)wl) {
+                            v[k][2 * p] = src[2 * (gx0 + p)];
+                            v[k][2 * p + 1] = src[2 * (gx0 + p) + 1];
+                        }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int r = xr0 + 15 * k;
+                if (r >= XR || xr0 >= 15) continue;
+                const uint32_t* d = v[k];                // pixel p = dwords (2p, 2p+1)
+                uint32_t* row = xs + r * XRS + 4 * xu;
+                *reinterpret_cast<uint4*>(row + 0 * XPW) = uint4{lo_pair(d[0], d[2]), lo_pair(d[2], d[4]), lo_pair(d[4], d[6]), lo_pair(d[6], d[8])};
+                *reinterpret_cast<uint4*>(row + 1 * XPW) = uint4{hi_pair(d[0], d[2]), hi_pair(d[2], d[4]), hi_pair(d[4], d[6]), hi_pair(d[6], d[8])};
+                *reinterpret_cast<uint4*>(row + 2 * XPW) = uint4{lo_pair(d[1], d[3]), lo_pair(d[3], d[5]), lo_pair(d[5], d[7]), lo_pair(d[7], d[9])};
+                *reinterpret_cast<uint4*>(row + 3 * XPW) = uint4{hi_pair(d[1], d[3]), hi_pair(d[3], d[5]), hi_pair(d[5], d[7]), hi_pair(d[7], d[9])};
+            }
+        }
+        {   // ---- dy: high-res row 2 (R0 + r) + py, low-res columns C0 + 4 gu + j -> planes (py, px, co)
+            const int gx0 = C0 + 4 * gu;
+            const bool all_in = gx0 + 3 < wl, any_in = gx0 < wl;
+            uint4 q[2][4];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int rr = gr0 + 16 * k, r = rr >> 1, py = rr & 1, gy = 2 * (R0 + r) + py;
+                const bool row_ok = gy < H;
+                const _Float16* src = gb + ((size_t)min(gy, H - 1) * W + 2 * gx0) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    q[k][j] = uint4{0u, 0u, 0u, 0u};
+                    if (row_ok && (all_in || (any_in && gx0 + j < wl))) q[k][j] = *reinterpret_cast<const uint4*>(src + 8 * j);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int rr = gr0 + 16 * k, r = rr >> 1, py = rr & 1;
+                // q[j] = low-res column j: (px0: c0|c1, c2|c3), (px1: c0|c1, c2|c3); plane (py, px, co) gets columns 0..3
+                _Float16* row = gs + (py * 8) * GP + r * GRS + 4 * gu;
+                const uint4* c = q[k];
+                *reinterpret_cast<u32x2*>(row + 0 * GP) = u32x2{lo_pair(c[0].x, c[1].x), lo_pair(c[2].x, c[3].x)};
+                *reinterpret_cast<u32x2*>(row + 1 * GP) = u32x2{hi_pair(c[0].x, c[1].x), hi_pair(c[2].x, c[3].x)};
+                *reinterpret_cast<u32x2*>(row + 2 * GP) = u32x2{lo_pair(c[0].y, c[1].y), lo_pair(c[2].y, c[3].y)};
+                *reinterpret_cast<u32x2*>(row + 3 * GP) = u32x2{hi_pair(c[0].y, c[1].y), hi_pair(c[2].y, c[3].y)};
+                *reinterpret_cast<u32x2*>(row + 4 * GP) = u32x2{lo_pair(c[0].z, c[1].z), lo_pair(c[2].z, c[3].z)};
+                *reinterpret_cast<u32x2*>(row + 5 * GP) = u32x2{hi_pair(c[0].z, c[1].z), hi_pair(c[2].z, c[3].z)};
+                *reinterpret_cast<u32x2*>(row + 6 * GP) = u32x2{lo_pair(c[0].w, c[1].w), lo_pair(c[2].w, c[3].w)};
+                *reinterpret_cast<u32x2*>(row + 7 * GP) = u32x2{hi_pair(c[0].w, c[1].w), hi_pair(c[2].w, c[3].w)};
+            }
+        }
+        __syncthreads();
+        // ---- wave wv: rows wv, wv + 4, ...; xl tile row of position row r and source offset my is r + my
+#pragma unroll 2
+        for (int r = wv; r < BR; r += 4) {
+#pragma unroll
+            for (int c0 = 0; c0 < BC; c0 += 16) {
+                const f16x4 b = read8(gs + b0 + r * GRS + c0);
+                const f16x4 x0 = read_words(xs + (ones_row ? 4 * XPW : a0 + r * XRS + c0));
+                const f16x4 x1 = read_words(xs + a0 + (r + 1) * XRS + c0);
+                const f16x4 x2 = read_words(xs + a0 + (r + 2) * XRS + c0);
+                acc[0] = mfma16(x0, b, acc[0]);
+                acc[1] = mfma16(x1, b, acc[1]);
+                acc[2] = mfma16(x2, b, acc[2]);
+            }
+        }
+    }
+    // ---- block reduction: lane (n = (phase, co), kq = mx) holds dWeff[(my * 3 + mx) * 4 + ci = i][n]; db from the
+    // ones row (my = 0, kq = 3, i = 0), summed over the phases
+    for (int i = tid; i < 4 * NV; i += 256) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int my = 0; my < 3; ++my) {
+        if (kq < 3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wv][(((my * 3 + kq) * 4 + i) * 16) + n] = acc[my][i];
+        }
+    }
+    float dbv = kq == 3 ? acc[0][0] : 0.f;               // lanes 48..63: n = (phase, co)
+    dbv += __shfl_xor(dbv, 4, 64);
+    dbv += __shfl_xor(dbv, 8, 64);
+    if (kq == 3 && n < 4) red[wv][36 * 16 + n] = dbv;
+    __syncthreads();
+    for (int i = tid; i < NV; i += 256)
+        partial[(size_t)blockIdx.x * NV + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
+template <typename K>
+int resident_blocks(uocr_ctx* ctx, K kernel, int* cache) {
+    if (*cache == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0) != hipSuccess || nb < 1) nb = 1;
+        *cache = nb;
+    }
+    return *cache;
+}
+
+}  // namespace
+
+bool uocr_conv_wgrad_h16_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d) {
+    return UOCR_DTYPE_BASE(dtype) == UOCR_F16 && ctx->opt_fast && ctx->opt_h16 && d.kh == 5 && d.kw == 5 && d.sh == 1 &&
+           d.sw == 1 && d.ph == 2 && d.pw == 2 && d.oh == d.h && d.ow == d.w && d.cin == 4 && d.cout == 2 &&
+           (long)d.h * d.w * 4 < (1l << 31);
+}
+
+int uocr_conv_wgrad_h16(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
+                        double pad_value, int use_bias, int accumulate) {
+    static int cache = 0;
+    const int tiles_x = (d.w + 4 + e42::BC - 1) / e42::BC, tiles_y = (d.h + e42::BR - 1) / e42::BR;
+    const long ntiles = (long)d.n * tiles_y * tiles_x;
+    UOCR_REQUIRE(ctx, ntiles < (1l << 31));
+    const long cap = (long)ctx->cu_count * resident_blocks(ctx, wgrad_h16_e42_kernel, &cache);
+    const int grid = (int)(ntiles < cap ? ntiles : cap);
+    int rc = uocr_need_workspace(ctx, (size_t)grid * e42::NV * sizeof(float));
+    if (rc != UOCR_OK) return rc;
+    float* partial = (float*)ctx->workspace;
+    hipLaunchKernelGGL(wgrad_h16_e42_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const _Float16*)x,
+                       (const _Float16*)dy, partial, d.h, d.w, tiles_x, tiles_y, (int)ntiles, (float)pad_value);
+    UOCR_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(wgrad_h16_finish, dim3(e42::NV), dim3(256), 0, ctx->stream, (const float*)partial, e42::NV, 200,
+                       (float*)dw, (float*)db, grid, use_bias, accumulate, (float)uocr_grad_unscale(dtype));
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
+}
+
+// partial rows in the layout of conv_up.hip's upconv_wgrad_finish: [(m * 4 + ci) * 16 + phase * 4 + co], then db[4]
+int uocr_upconv_wgrad_h16(uocr_ctx* ctx, const void* x_low, const void* dy, float* partial, size_t partial_floats,
+                          int n, int hl, int wl, int* nblocks) {
+    static int cache = 0;
+    const int tiles_x = (wl + up::BC - 1) / up::BC, tiles_y = (hl + up::BR - 1) / up::BR;
+    const long ntiles = (long)n * tiles_y * tiles_x;
+    UOCR_REQUIRE(ctx, ntiles < (1l << 31) && (long)hl * wl * 16 < (1l << 31));
+    const long cap = (long)ctx->cu_count * resident_blocks(ctx, wgrad_h16_up_kernel, &cache);
+    const int grid = (int)(ntiles < cap ? ntiles : cap);
+    UOCR_REQUIRE(ctx, (size_t)grid * up::NV <= partial_floats);
+    hipLaunchKernelGGL(wgrad_h16_up_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const _Float16*)x_low,
+                       (const _Float16*)dy, partial, hl, wl, tiles_x, tiles_y, (int)ntiles);
+    UOCR_LAUNCH_CHECK(ctx);
+    *nblocks = grid;
+    return UOCR_OK;
+}

@@ -586,13 +586,26 @@ extern "C" int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_
     UOCR_REQUIRE(ctx, x_low && dy && dw && db);
     int rc = check_up(ctx, dtype, n, hl, wl, cin, cout, kh, kw, ph, pw);
     if (rc != UOCR_OK) return rc;
+    const float unscale = (float)uocr_grad_unscale(dtype);
+    if (uocr_upconv_h16_eligible(ctx, dtype, cin, cout) && uocr_aligned_act(x_low, dtype) && uocr_aligned_act(dy, dtype)) {
+        // binary16 MFMAs over channel planes (conv_h16w.hip), same partial layout, same finish kernel
+        const size_t floats = (size_t)ctx->cu_count * 8 * (36 * 16 + 4);
+        rc = uocr_need_workspace(ctx, floats * sizeof(float));
+        if (rc != UOCR_OK) return rc;
+        int nblocks = 0;
+        rc = uocr_upconv_wgrad_h16(ctx, x_low, dy, (float*)ctx->workspace, floats, n, hl, wl, &nblocks);
+        if (rc != UOCR_OK) return rc;
+        hipLaunchKernelGGL(upconv_wgrad_finish, dim3(404), dim3(256), 0, ctx->stream, (const float*)ctx->workspace,
+                           (float*)dw, (float*)db, nblocks, use_bias, accumulate, unscale);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    }
     // fewer, longer blocks than the forward: every block ends with a reduction and a partial row for the finish kernel
     const int strips = (wl + RW - 1) / RW, rows = up_rows_per_block(strips, hl, n, 1024u);
     const int bands = (hl + rows - 1) / rows, nblocks = strips * bands * n;
     rc = uocr_need_workspace(ctx, (size_t)nblocks * (36 * 16 + 4) * sizeof(float));
     if (rc != UOCR_OK) return rc;
     float* partial = (float*)ctx->workspace;
-    const float unscale = (float)uocr_grad_unscale(dtype);
     UOCR_DISPATCH_TA(ctx, dtype, {
         if (cin == 1)
             hipLaunchKernelGGL((up1_wgrad_kernel<TA>), dim3(strips, bands, n), dim3(256), 0, ctx->stream,
