@@ -61,6 +61,12 @@ def main():
         ('up  5x5 4->4 dx+lrelu mask', lambda: ops.upconv2x_bwd_data(g4, w44, xl.shape, (2, 2), x_act=xl, act='leaky', alpha=0.01), 12 * px),
         ('up  5x5 4->4 dw', lambda: ops.upconv2x_bwd_weight(xl, g4, dw44, db4, (2, 2), True, accumulate=False), 10 * px),
     ]
+    xh4, gh4 = act((n, h // 2, w // 2, 4)), act((n, h // 4, w // 4, 4))
+    rows += [
+        ('down 5x5 s2 4->4 fwd+lrelu', lambda: ops.conv2d_fwd(xh4, w44, b4, (2, 2), (2, 2), 0.0, True, act='leaky', alpha=0.01), 2.5 * px),
+        ('down 5x5 s2 4->4 dx+mask', lambda: ops.conv2d_bwd_data(gh4, w44, xh4.shape, (2, 2), (2, 2), x_act=xh4, act='leaky', alpha=0.01), 4.5 * px),
+        ('down 5x5 s2 4->4 dw', lambda: ops.conv2d_bwd_weight(xh4, gh4, dw44, db4, (2, 2), (2, 2), 0.0, True, accumulate=False), 2.5 * px),
+    ]
     print(f'{"layer":30s} {"h16=0 us":>10s} {"h16=1 us":>10s} {"MB":>8s} {"GB/s":>8s}')
     for name, fn, nbytes in rows:
         t = []

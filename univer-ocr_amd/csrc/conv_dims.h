@@ -29,6 +29,8 @@ int uocr_conv_fwd_h16(uocr_ctx* ctx, const void* x, const void* w, const void* b
                       double pad_value, int use_bias, int act, double act_alpha);
 int uocr_conv_dgrad_h16(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d, const ActMask& mask);
 bool uocr_upconv_h16_eligible(uocr_ctx* ctx, int dtype, int cin, int cout);
+int uocr_upconv_fwd_h16(uocr_ctx* ctx, const void* x_low, const void* w, const void* b, void* y, int n, int hl, int wl,
+                        int use_bias, int act, double act_alpha);
 int uocr_upconv_dgrad_h16(uocr_ctx* ctx, const void* dy, const void* w, void* dx_low, int n, int hl, int wl,
                           const void* mask_y, int mask_act, double mask_alpha);
 // ... their weight gradients (conv_h16w.hip)

@@ -36,6 +36,10 @@ enum Mode {
     M_FWD = 0,       // forward conv, w[ky][kx][ci][co]
     M_DGRAD = 1,     // backward-data of a stride-1 conv: input dy (C = cout), flipped taps, w[ky][kx][co_out][ci_in]
     M_UPDGRAD = 2,   // backward-data of upsample2x + 5x5: stride-2 6x6 window over dy, taps summed per parity phase
+    M_UPFWD = 3,     // upsample2x + 5x5 forward: 3x3 window on the low-res input, 4 phases x COUT result rows, the
+                     // phases are the 2x2 output pixels of the source pixel (depth to space in the store)
+    M_S2DGRAD = 4,   // backward-data of a 5x5 / stride 2 / padding 2 conv: 3x3 window over dy, result rows =
+                     // (phase, ci) = the 2x2 input pixels around the source -- the same store
 };
 
 __device__ __forceinline__ f32x4 mfma16(f16x4 a, f16x4 b, f32x4 c) {
@@ -74,7 +78,9 @@ constexpr int pick_stride(int need, int mod, int target) {
 template <int C_, int COUT_, int KH_, int KW_, int S_, int MODE_>
 struct Geo {
     static constexpr int C = C_, COUT = COUT_, KH = KH_, KW = KW_, S = S_, MODE = MODE_;
-    static constexpr int DY = 16 / COUT;                       // output rows of one MFMA chain
+    static constexpr int U = (MODE == M_UPFWD || MODE == M_S2DGRAD) ? 2 : 1;   // output pixels per position and axis
+    static constexpr int NCO = U * U * COUT;                   // result rows per position: (phase, co)
+    static constexpr int DY = 16 / NCO;                        // position rows of one MFMA chain
     static constexpr int ROWS = (DY - 1) * S + KH;             // window rows of one chain
     static constexpr int IB = (ROWS + 3) / 4;                  // row quads
     static constexpr int Q = (KW * C + 3) / 4;                 // 4-half chunks per window row
@@ -92,8 +98,8 @@ struct Geo {
     static constexpr int RS = S == 2 ? pick_stride(UW * 8, 4, 2) : pick_stride(UW * 8, 64, C == 4 ? 32 : 16);
     static constexpr int RPP = 256 / UW;                       // tile rows staged per pass of the block
     static constexpr int NPASS = (IH + RPP - 1) / RPP;
-    static constexpr int NW = (MODE == M_UPDGRAD ? 25 : KH * KW) * C * COUT;   // float32 weights of the layer
-    static_assert(RPW >= 1 && 16 % COUT == 0 && (C == 2 || C == 4) && UW <= 256, "unsupported geometry");
+    static constexpr int NW = (MODE == M_UPDGRAD || MODE == M_UPFWD || MODE == M_S2DGRAD ? 25 : KH * KW) * C * COUT;
+    static_assert(RPW >= 1 && 16 % NCO == 0 && (C == 2 || C == 4) && UW <= 256, "unsupported geometry");
 };
 
 // weight of window position (ty, tx), input channel ci, output channel co, from the layer's float32 weights
@@ -105,7 +111,7 @@ __device__ __forceinline__ float weight_of(const float* w, int ty, int tx, int c
     } else if constexpr (G::MODE == M_DGRAD) {
         // dx[p][co] = sum dy[p + t - pad'][ci] w[K-1-t][co][ci]
         return w[(((G::KH - 1 - ty) * G::KW + (G::KW - 1 - tx)) * G::COUT + co) * G::C + ci];
-    } else {
+    } else if constexpr (G::MODE == M_UPDGRAD) {
         // dxl[Q][co] = sum_{a,b in 0..5} dy[2Q - 2 + (a,b)][ci] Weff[phase (a%2, b%2)][o = (4 - a + py) / 2, ..][co][ci],
         // Weff = the 5x5 taps of the phase that share a source pixel (at most 2 x 2 of them), summed
         const int py = ty & 1, px = tx & 1;
@@ -122,6 +128,29 @@ __device__ __forceinline__ float weight_of(const float* w, int ty, int tx, int c
                 s += (ylo + a < yhi && xlo + b < xhi) ? v : 0.f;
             }
         return s;
+    } else if constexpr (G::MODE == M_UPFWD) {
+        // y[2P + phase][o] = sum_{m in 3x3, ci} Weff[phase][m][ci][o] xl[P + m - 1][ci]; row co = phase * COUT + o
+        const int phase = co / G::COUT, o = co % G::COUT;
+        int ylo, yhi, xlo, xhi;
+        tap_group(phase >> 1, ty, ylo, yhi);
+        tap_group(phase & 1, tx, xlo, xhi);
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ky = min(ylo + a, 4), kx = min(xlo + b, 4);
+                const float v = w[((ky * 5 + kx) * G::C + ci) * G::COUT + o];
+                s += (ylo + a < yhi && xlo + b < xhi) ? v : 0.f;
+            }
+        return s;
+    } else {
+        // dx[2P + phase][c] = sum_{m in 3x3, o} dy[P + m - 1][o] w[4 - 2 m + phase][c][o] (taps beyond 4: none);
+        // row co = phase * COUT + c, input channel ci = o
+        const int phase = co / G::COUT, c = co % G::COUT;
+        const int ky = 4 - 2 * ty + (phase >> 1), kx = 4 - 2 * tx + (phase & 1);
+        const float v = w[((min(ky, 4) * 5 + min(kx, 4)) * G::COUT + c) * G::C + ci];
+        return (ky <= 4 && kx <= 4) ? v : 0.f;
     }
 }
 
@@ -170,7 +199,7 @@ __global__ __launch_bounds__(256) void conv_h16_kernel(const _Float16* __restric
     // weight operand: row m = lane % 16 = (dy, co), k-group kq = window row 4*ib + kq, j = half 4q + j of the row
     f16x4 wa[G::NM];
     {
-        const int m = n, dyi = m / COUT, co = m % COUT;
+        const int m = n, dyi = m / G::NCO, co = m % G::NCO;   // co = (phase, channel) in the depth-to-space modes
 #pragma unroll
         for (int ib = 0; ib < G::IB; ++ib)
 #pragma unroll
@@ -186,7 +215,7 @@ __global__ __launch_bounds__(256) void conv_h16_kernel(const _Float16* __restric
     }
     float bias4[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bias4[i] = use_bias ? bias[(4 * kq + i) % COUT] : 0.f;
+    for (int i = 0; i < 4; ++i) bias4[i] = use_bias ? bias[(4 * kq + i) % COUT] : 0.f;   // (row % NCO) % COUT
     const uint32_t padw = __builtin_bit_cast(uint32_t, f16x2{(_Float16)pad, (_Float16)pad});
     // staging role of this thread: 16-byte unit su of tile rows sr, sr + RPP, ...
     const int sr = tid / G::UW, su = tid - sr * G::UW;
@@ -257,8 +286,24 @@ __global__ __launch_bounds__(256) void conv_h16_kernel(const _Float16* __restric
                         acc = mfma16(wa[ib * G::Q + q], read_chunk<G>(base + ib * 4 * RS + 4 * q), acc);
                 // lane (column n, kq): rows m = 4kq + i of the result = (dy, co)
                 const int col = c_begin + cg * 16 + n;
-                if (col >= w_out) continue;
-                if constexpr (COUT == 4) {
+                if (G::U == 1 && col >= w_out) continue;
+                if constexpr (G::U == 2) {                // rows m = (phase = kq, channel i): output pixel 2 P + phase
+                    static_assert(G::U == 1 || COUT == 4, "depth-to-space store: 4 channels");
+                    const int row = 2 * (r0 + rb) + (kq >> 1), ocol = 2 * col + (kq & 1);
+                    if (row >= h_out || ocol >= w_out) continue;
+                    const size_t off = out_img + ((size_t)row * w_out + ocol) * 4;
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = fast_act(acc[i] + bias4[i], act, alpha);
+                    if (mask_act != UOCR_ACT_NONE) {
+                        const float4 my = ld4(mask_y + off);
+                        v[0] *= act_grad_from_output<float>(my.x, mask_act, mask_alpha);
+                        v[1] *= act_grad_from_output<float>(my.y, mask_act, mask_alpha);
+                        v[2] *= act_grad_from_output<float>(my.z, mask_act, mask_alpha);
+                        v[3] *= act_grad_from_output<float>(my.w, mask_act, mask_alpha);
+                    }
+                    st4(out + off, make_float4(v[0], v[1], v[2], v[3]));
+                } else if constexpr (COUT == 4) {
                     const int row = r0 + rb + kq;
                     if (row >= h_out) continue;
                     const size_t off = out_img + ((size_t)row * w_out + col) * 4;
@@ -304,7 +349,8 @@ int launch_h16(uocr_ctx* ctx, const void* in, const void* w, const void* bias, v
         UOCR_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_h16_kernel<G>, 256, 0));
         resident = nb > 0 ? nb : 1;
     }
-    const int tiles_x = (w_out + G::BC - 1) / G::BC, tiles_y = (h_out + G::BR - 1) / G::BR;
+    const int hp = (h_out + G::U - 1) / G::U, wp = (w_out + G::U - 1) / G::U;      // the position grid
+    const int tiles_x = (wp + G::BC - 1) / G::BC, tiles_y = (hp + G::BR - 1) / G::BR;
     const long ntiles = (long)n * tiles_y * tiles_x;
     UOCR_REQUIRE(ctx, ntiles < (1l << 31) && (long)h_in * w_in * G::C < (1l << 31));
     const int grid = (int)(ntiles < (long)ctx->cu_count * resident ? ntiles : (long)ctx->cu_count * resident);
@@ -318,42 +364,60 @@ int launch_h16(uocr_ctx* ctx, const void* in, const void* w, const void* bias, v
 inline bool same5x5(const ConvDims& d) {
     return d.kh == 5 && d.kw == 5 && d.sh == 1 && d.sw == 1 && d.ph == 2 && d.pw == 2 && d.oh == d.h && d.ow == d.w;
 }
+inline bool half5x5(const ConvDims& d) {                 // the encoder convs: 5x5 / stride 2 / padding 2
+    return d.kh == 5 && d.kw == 5 && d.sh == 2 && d.sw == 2 && d.ph == 2 && d.pw == 2 && d.oh == (d.h + 1) / 2 &&
+           d.ow == (d.w + 1) / 2;
+}
 
 }  // namespace
 
 // which: 0 forward, 1 backward-data
 bool uocr_conv_h16_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d, int which) {
     if (UOCR_DTYPE_BASE(dtype) != UOCR_F16 || !ctx->opt_fast || !ctx->opt_h16 || d.n > 65535) return false;
-    if (!same5x5(d)) return false;
-    return d.cin == 4 && (d.cout == 2 || d.cout == 4);
+    if (same5x5(d)) return d.cin == 4 && (d.cout == 2 || d.cout == 4);
+    if (half5x5(d)) return d.cin == 4 && d.cout == 4;
+    return false;
     (void)which;
 }
 
 int uocr_conv_fwd_h16(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
                       double pad_value, int use_bias, int act, double act_alpha) {
-    if (d.cout == 2)
-        return launch_h16<Geo<4, 2, 5, 5, 1, M_FWD>>(ctx, x, w, b, y, nullptr, d.n, d.h, d.w, d.oh, d.ow, d.ph, d.pw,
-                                                     (float)pad_value, use_bias, act, (float)act_alpha, UOCR_ACT_NONE,
-                                                     0.f);
-    return launch_h16<Geo<4, 4, 5, 5, 1, M_FWD>>(ctx, x, w, b, y, nullptr, d.n, d.h, d.w, d.oh, d.ow, d.ph, d.pw,
-                                                 (float)pad_value, use_bias, act, (float)act_alpha, UOCR_ACT_NONE, 0.f);
+    auto run = [&](auto geo) {
+        using G = decltype(geo);
+        return launch_h16<G>(ctx, x, w, b, y, nullptr, d.n, d.h, d.w, d.oh, d.ow, d.ph, d.pw, (float)pad_value, use_bias,
+                             act, (float)act_alpha, UOCR_ACT_NONE, 0.f);
+    };
+    if (d.sh == 2) return run(Geo<4, 4, 5, 5, 2, M_FWD>{});
+    if (d.cout == 2) return run(Geo<4, 2, 5, 5, 1, M_FWD>{});
+    return run(Geo<4, 4, 5, 5, 1, M_FWD>{});
 }
 
 int uocr_conv_dgrad_h16(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d,
                         const ActMask& mask) {
-    // a forward conv over dy with flipped taps: padding kh - 1 - ph
+    const int mact = mask.y ? mask.act : UOCR_ACT_NONE;
+    // stride 2: a 3x3 window over dy per 2x2 block of dx;  stride 1: a forward conv over dy with flipped taps
+    // (padding kh - 1 - ph)
+    if (d.sh == 2)
+        return launch_h16<Geo<4, 4, 3, 3, 1, M_S2DGRAD>>(ctx, dy, w, nullptr, dx, mask.y, d.n, d.oh, d.ow, d.h, d.w, 1, 1,
+                                                         0.f, 0, UOCR_ACT_NONE, 0.f, mact, (float)mask.alpha);
     if (d.cout == 2)
         return launch_h16<Geo<2, 4, 5, 5, 1, M_DGRAD>>(ctx, dy, w, nullptr, dx, mask.y, d.n, d.oh, d.ow, d.h, d.w,
                                                        d.kh - 1 - d.ph, d.kw - 1 - d.pw, 0.f, 0, UOCR_ACT_NONE, 0.f,
-                                                       mask.y ? mask.act : UOCR_ACT_NONE, (float)mask.alpha);
+                                                       mact, (float)mask.alpha);
     return launch_h16<Geo<4, 4, 5, 5, 1, M_DGRAD>>(ctx, dy, w, nullptr, dx, mask.y, d.n, d.oh, d.ow, d.h, d.w,
-                                                   d.kh - 1 - d.ph, d.kw - 1 - d.pw, 0.f, 0, UOCR_ACT_NONE, 0.f,
-                                                   mask.y ? mask.act : UOCR_ACT_NONE, (float)mask.alpha);
+                                                   d.kh - 1 - d.ph, d.kw - 1 - d.pw, 0.f, 0, UOCR_ACT_NONE, 0.f, mact,
+                                                   (float)mask.alpha);
 }
 
-// backward-data of Upsample2D(2) + conv 5x5 / padding 2, 4 -> 4 channels, on the low-res grid (conv_up.hip)
+// Upsample2D(2) + conv 5x5 / padding 2, 4 -> 4 channels, on the low-res grid (conv_up.hip)
 bool uocr_upconv_h16_eligible(uocr_ctx* ctx, int dtype, int cin, int cout) {
     return UOCR_DTYPE_BASE(dtype) == UOCR_F16 && ctx->opt_fast && ctx->opt_h16 && cin == 4 && cout == 4;
+}
+
+int uocr_upconv_fwd_h16(uocr_ctx* ctx, const void* x_low, const void* w, const void* b, void* y, int n, int hl, int wl,
+                        int use_bias, int act, double act_alpha) {
+    return launch_h16<Geo<4, 4, 3, 3, 1, M_UPFWD>>(ctx, x_low, w, b, y, nullptr, n, hl, wl, 2 * hl, 2 * wl, 1, 1, 0.f,
+                                                   use_bias, act, (float)act_alpha, UOCR_ACT_NONE, 0.f);
 }
 
 int uocr_upconv_dgrad_h16(uocr_ctx* ctx, const void* dy, const void* w, void* dx_low, int n, int hl, int wl,

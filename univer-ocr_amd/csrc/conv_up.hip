@@ -533,6 +533,8 @@ extern "C" int uocr_upconv2x_fwd(uocr_ctx* ctx, int dtype, const void* x_low, co
     UOCR_REQUIRE(ctx, x_low && w && b && y);
     int rc = check_up(ctx, dtype, n, hl, wl, cin, cout, kh, kw, ph, pw);
     if (rc != UOCR_OK) return rc;
+    if (uocr_upconv_h16_eligible(ctx, dtype, cin, cout) && uocr_aligned_act(x_low, dtype) && uocr_aligned_act(y, dtype))
+        return uocr_upconv_fwd_h16(ctx, x_low, w, b, y, n, hl, wl, use_bias, act, act_alpha);
     const int strips = (wl + RW - 1) / RW, rows = up_rows_per_block(strips, hl, n);
     UOCR_DISPATCH_TA(ctx, dtype, {
         if (cin == 1)
