@@ -322,6 +322,7 @@ def main():
     ap.add_argument('--h2d', action='store_true',
                     help='upload every batch as uint8 from pinned host memory on a copy stream and convert on the '
                          'device (PCIe-inclusive rate; flagged in metric and config, never the headline value)')
+    ap.add_argument('--lane-per-net', action='store_true', help='one lane per net instead of the balanced groups')
     ap.add_argument('--option', action='append', default=[],
                     help='kernel selection knob of the C ABI, key=value (uocr_ctx_set_option: split_blocks, split_min, '
                          'gemm_bm, mfma, tiled, xcd_remap); experiments only')
@@ -390,7 +391,8 @@ def main():
                            input_grads=not args.skip_input_grads, graphs=graphs,
                            eager_nets=('Monochrome',),    # the probed kernel's net stays eager (events in a graph are refused)
                            pipelined=not args.no_pipeline, data_parallel=use_dp,
-                           dp_coalesce=args.dp_single_collective, dp_backend=dp_backend)
+                           dp_coalesce=args.dp_single_collective, dp_backend=dp_backend,
+                           **({'lane_groups': None} if args.lane_per_net else {}))
     dp_fallback = None
     try:
         trainer = build_trainer('gloo' if rehearsal else None)

@@ -19,6 +19,7 @@ def f32():
     yield CP
     CP.runtime().set_option('mfma', 1)
     CP.runtime().set_option('fast_paths', 1)
+    CP.runtime().set_option('t32', 2)
 
 
 def check(a, b, tol, what):
@@ -164,6 +165,60 @@ def test_fast_conv_kernels_against_oracle(case, pad_value, bias, f32):
         check(db, ref_db + 0.25, 2e-5, f'{mode} db')
     # the two kernels must have actually been different code paths yet agree closely
     check(results['fast'][0], CP.asnumpy(results['generic'][0]).astype(np.float64), 1e-5, 'fast vs generic y')
+
+
+TOEPLITZ_SHAPES = [
+    # (x shape, cout): 5x5 / stride 1 / padding 2 layers of the page nets
+    ((2, 40, 72, 4), 2), ((2, 33, 47, 4), 2), ((1, 70, 130, 4), 2),      # Line end: one tile, ragged, several tiles
+    ((2, 37, 66, 4), 4),                                                 # 4 -> 4
+    ((2, 40, 72, 1), 1), ((1, 70, 133, 1), 1),                           # Paragraph end
+]
+
+
+@pytest.mark.parametrize('case', range(len(TOEPLITZ_SHAPES)))
+@pytest.mark.parametrize('pad_value,bias', [(0.0, True), (0.75, False)])
+def test_toeplitz_f32_conv_kernels(case, pad_value, bias, f32):
+    """conv_t32.hip (vertical-Toeplitz float32 MFMA forward / backward-data, every instantiation forced through the
+    't32' option) against the oracle, with the fused activation and the backward mask of a consumer."""
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    CP.runtime().set_option('t32', 63)
+    xs, cout = TOEPLITZ_SHAPES[case]
+    rng = np.random.default_rng(700 + case)
+    X = rng.standard_normal(xs)
+    w = rng.standard_normal((5, 5, xs[3], cout)) * 0.2
+    b = rng.standard_normal(cout)
+    ref_y = O.conv2d_fwd(X, w, b, 1, 2, pad_value, bias)
+    g = rng.standard_normal(ref_y.shape)
+    ref_dx, _, _ = O.conv2d_bwd(X, w, g, 1, 2, pad_value, bias)
+    Xd, wd, bd, gd = CP.copy(X), CP.copy(w), CP.copy(b), CP.copy(g)
+    check(ops.conv2d_fwd(Xd, wd, bd, (1, 1), (2, 2), pad_value, bias), ref_y, 1e-5, 'y')
+    check(ops.conv2d_fwd(Xd, wd, bd, (1, 1), (2, 2), pad_value, bias, act='sigmoid'), O.sigmoid_fwd(ref_y), 1e-5, 'sigmoid(y)')
+    check(ops.conv2d_bwd_data(gd, wd, Xd.shape, (1, 1), (2, 2)), ref_dx, 1e-5, 'dx')
+    slope = np.where(X >= 0, 1.0, 0.01)
+    check(ops.conv2d_bwd_data(gd, wd, Xd.shape, (1, 1), (2, 2), x_act=Xd, act='leaky', alpha=0.01), ref_dx * slope, 1e-5,
+          'masked dx')
+
+
+@pytest.mark.parametrize('ch,hl,wl', [(4, 24, 40), (4, 17, 33), (1, 24, 40), (1, 19, 21), (4, 40, 70)])
+def test_toeplitz_f32_upconv_dgrad(ch, hl, wl, f32):
+    """Upsample2D(2) + conv5x5 backward-data as a stride-2 6x6 window over dy (conv_t32.hip) against the two layers
+    of the oracle."""
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    CP.runtime().set_option('t32', 63)
+    rng = np.random.default_rng(ch * 10 + hl)
+    xl = rng.standard_normal((2, hl, wl, ch))
+    w = rng.standard_normal((5, 5, ch, ch)) * 0.2
+    g = rng.standard_normal((2, 2 * hl, 2 * wl, ch))
+    up = O.upsample2d_fwd(xl, (2, 2))
+    dx_hi, _, _ = O.conv2d_bwd(up, w, g, 1, 2, 0.0, True)
+    ref_dx = O.upsample2d_bwd(dx_hi, (2, 2))
+    xd, wd, gd = CP.copy(xl), CP.copy(w), CP.copy(g)
+    check(ops.upconv2x_bwd_data(gd, wd, xd.shape, (2, 2)), ref_dx, 1e-5, 'dx')
+    slope = np.where(xl >= 0, 1.0, 0.01)
+    check(ops.upconv2x_bwd_data(gd, wd, xd.shape, (2, 2), x_act=xd, act='leaky', alpha=0.01), ref_dx * slope, 1e-5,
+          'masked dx')
 
 
 PAIR_SHAPES = [(3, 37, 83), (2, 16, 32), (1, 1, 1), (2, 5, 200), (1, 70, 33), (4, 64, 96)]

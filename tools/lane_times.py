@@ -9,11 +9,21 @@ from univer_ocr_amd.my_model.synthetic import make_page_batch
 from univer_ocr_amd.my_model.trainer import PageTrainer
 from univer_ocr_amd.nn import CP
 
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument('--highres', action='store_true', help='the highres-fp16 configuration: 8 pages 1024x2048, float16, no Char')
+args = ap.parse_args()
 CP.use_gpu(0)
-CP.set_dtype('float32')
+CP.set_dtype('float16' if args.highres else 'float32')
 CP.lazy_losses = True
-trainer = PageTrainer(32)
-context = trainer.make_context(make_page_batch(32, seed=1))
+if args.highres:
+    make = lambda **kw: PageTrainer(8, 1024, 2048, 64, nets=('Monochrome', 'Paragraph', 'Line'), **kw)
+    batch = make_page_batch(8, 1024, 2048, 64, seed=1)
+else:
+    make = lambda **kw: PageTrainer(32, **kw)
+    batch = make_page_batch(32, seed=1)
+trainer = make()
+context = trainer.make_context(batch)
 for _ in range(5):
     trainer.step(context)
 rt = CP.runtime()
@@ -48,8 +58,8 @@ for name, (m, e) in acc.items():
     print(f'{name:12s} fwd+bwd done at {m / reps:6.3f} ms, step done at {e / reps:6.3f} ms')
 
 # the same with the per-net HIP graphs (host enqueue out of the picture)
-trainer = PageTrainer(32, graphs=True)
-context = trainer.make_context(make_page_batch(32, seed=1))
+trainer = make(graphs=True)
+context = trainer.make_context(batch)
 trainer.capture(context)
 for _ in range(3):
     trainer.step(context)

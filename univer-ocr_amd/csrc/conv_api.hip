@@ -31,6 +31,8 @@ int uocr_conv2d_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, cons
     UOCR_REQUIRE(ctx, act >= UOCR_ACT_NONE && act <= UOCR_ACT_SIGMOID);
     if (uocr_conv_h16_eligible(ctx, dtype, d, 0) && uocr_aligned_act(x, dtype) && uocr_aligned_act(y, dtype))
         return uocr_conv_fwd_h16(ctx, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
+    if (uocr_conv_t32_eligible(ctx, dtype, d, 0) && aligned16(x) && aligned16(y))
+        return uocr_conv_fwd_t32(ctx, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
     if (uocr_conv_tiled_eligible(ctx, dtype, d) && uocr_aligned_act(x, dtype) && uocr_aligned_act(y, dtype))
         return uocr_conv_fwd_tiled(ctx, dtype, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
     if (uocr_conv_fast_eligible(ctx, dtype, d, x, y, w))
@@ -53,6 +55,8 @@ int uocr_conv2d_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, const void* w
     if (uocr_conv_h16_eligible(ctx, dtype, d, 1) && uocr_aligned_act(dy, dtype) && uocr_aligned_act(dx, dtype) &&
         (!mask.y || uocr_aligned_act(mask.y, dtype)))
         return uocr_conv_dgrad_h16(ctx, dy, w, dx, d, mask);
+    if (uocr_conv_t32_eligible(ctx, dtype, d, 1) && aligned16(dy) && aligned16(dx) && (!mask.y || aligned16(mask.y)))
+        return uocr_conv_dgrad_t32(ctx, dy, w, dx, d, mask);
     if (uocr_conv_fast_eligible(ctx, dtype, d, dy, dx, w)) return uocr_conv_dgrad_fast(ctx, dtype, dy, w, dx, d, mask);
     if (uocr_conv_mfma_eligible(ctx, dtype, d, 1)) return uocr_conv_dgrad_mfma(ctx, dy, w, dx, d, mask);
     return uocr_conv_dgrad_generic(ctx, dtype, dy, w, dx, d, mask);

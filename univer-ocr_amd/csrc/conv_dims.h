@@ -39,6 +39,14 @@ int uocr_conv_wgrad_h16(uocr_ctx* ctx, int dtype, const void* x, const void* dy,
                         double pad_value, int use_bias, int accumulate);
 int uocr_upconv_wgrad_h16(uocr_ctx* ctx, const void* x_low, const void* dy, float* partial, size_t partial_floats,
                           int n, int hl, int wl, int* nblocks);
+// float32 vertical-Toeplitz MFMA kernels of the small-channel convs (conv_t32.hip); which: 0 fwd, 1 dgrad
+bool uocr_conv_t32_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d, int which);
+int uocr_conv_fwd_t32(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
+                      double pad_value, int use_bias, int act, double act_alpha);
+int uocr_conv_dgrad_t32(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d, const ActMask& mask);
+bool uocr_upconv_t32_eligible(uocr_ctx* ctx, int dtype, int cin, int cout);
+int uocr_upconv_dgrad_t32(uocr_ctx* ctx, const void* dy, const void* w, void* dx_low, int n, int hl, int wl, int ch,
+                          const void* mask_y, int mask_act, double mask_alpha);
 // LDS-tiled forward for the 5x5 stride-1 4-channel convs (conv_tiled.hip), f32 / f16 storage
 bool uocr_conv_tiled_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d);
 int uocr_conv_fwd_tiled(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* b, void* y, const ConvDims& d,

@@ -561,6 +561,9 @@ extern "C" int uocr_upconv2x_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, 
     if (uocr_upconv_h16_eligible(ctx, dtype, cin, cout) && uocr_aligned_act(dy, dtype) &&
         uocr_aligned_act(dx_low, dtype) && (act == UOCR_ACT_NONE || uocr_aligned_act(x_act, dtype)))
         return uocr_upconv_dgrad_h16(ctx, dy, w, dx_low, n, hl, wl, act == UOCR_ACT_NONE ? nullptr : x_act, act, act_alpha);
+    if (uocr_upconv_t32_eligible(ctx, dtype, cin, cout) && (reinterpret_cast<uintptr_t>(dy) & 15u) == 0 &&
+        (reinterpret_cast<uintptr_t>(dx_low) & 15u) == 0 && (act == UOCR_ACT_NONE || (reinterpret_cast<uintptr_t>(x_act) & 15u) == 0))
+        return uocr_upconv_dgrad_t32(ctx, dy, w, dx_low, n, hl, wl, cin, act == UOCR_ACT_NONE ? nullptr : x_act, act, act_alpha);
     float* weff = nullptr;
     if (cin != 1) {
         rc = uocr_need_workspace(ctx, NWEFF * sizeof(float));

@@ -26,6 +26,7 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->opt_split_min = 3;
     ctx->opt_bm = 0;
     ctx->opt_h16 = 1;
+    ctx->opt_t32 = 2;    // measured: only the 4-channel backward-data beats its vector kernel in the step (conv_t32.hip)
     ctx->opt_xcd = 1;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -78,6 +79,7 @@ int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "gemm_bm")) ctx->opt_bm = value;
     else if (!strcmp(key, "xcd_remap")) ctx->opt_xcd = value;
     else if (!strcmp(key, "h16")) ctx->opt_h16 = value;
+    else if (!strcmp(key, "t32")) ctx->opt_t32 = value;
     else UOCR_FAIL(ctx, UOCR_ERR_ARG, "unknown option '%s'", key);
     return UOCR_OK;
 }

@@ -22,6 +22,7 @@ struct uocr_ctx {
     int opt_xcd;         // 1 = MFMA GEMM blocks are renumbered so that neighbours share an XCD (L2)
     int opt_bm;          // 0 = choose the MFMA GEMM row tile automatically, 64 / 128 = force it (experiments)
     int opt_h16;         // 1 = binary16-MFMA kernels for the small-channel convs in UOCR_F16 mode (default)
+    int opt_t32;         // float32 vertical-Toeplitz MFMA kernels for the small-channel convs: bit 0 forward, bit 1 backward-data
     char err[512];
 };
 
