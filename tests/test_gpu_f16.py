@@ -103,6 +103,9 @@ CONVS = [
     ((2, 37, 66, 4), (5, 5), 4, (1, 1), (2, 2), 0.0),     # 4 -> 4 stride 1, ragged
     ((2, 33, 47, 4), (5, 5), 4, (2, 2), (2, 2), 0.5),     # Line down_2, odd sizes, padding value
     ((1, 70, 140, 4), (5, 5), 4, (2, 2), (2, 2), 0.0),    # ... more than one tile
+    ((2, 33, 47, 1), (5, 5), 1, (2, 2), (2, 2), 0.5),     # Paragraph down, odd sizes, padding value
+    ((1, 70, 141, 1), (5, 5), 1, (1, 1), (2, 2), 0.25),   # Paragraph end, several tiles, odd width
+    ((1, 37, 141, 1), (5, 5), 4, (2, 2), (2, 2), 0.0),    # Line down_1, odd width
     ((2, 21, 35, 1), (3, 3), 16, (1, 1), (1, 1), 0.5),    # Monochrome conv_1 unfused, padding value
     ((2, 21, 35, 16), (3, 3), 1, (1, 1), (1, 1), 0.0),    # Monochrome conv_2 unfused
     ((3, 11, 13, 6), (4, 4), 7, (2, 1), (1, 2), 0.25),    # generic kernels
@@ -120,13 +123,13 @@ def test_conv_kernels_f16(case, f16):
     b = rng.standard_normal(cout)
     X16 = r16(X)
     w32, b32 = w.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64)
-    if xs[3] == 4 and ks == (5, 5):
-        # binary16-MFMA kernels (conv_h16.hip): the float32 master weights enter the matrix cores rounded to binary16
-        w32 = r16(w32)
-    ref_y = O.conv2d_fwd(X16, w32, b32, st, pd, pv, True)
+    h16_fwd = ks == (5, 5) and (xs[3] == 4 or (st == (1, 1) and cout == 1))
+    h16_dx = ks == (5, 5) and (xs[3] == 4 or (st == (2, 2) and cout == 4))
+    # binary16-MFMA kernels (conv_h16.hip): the float32 master weights enter the matrix cores rounded to binary16
+    ref_y = O.conv2d_fwd(X16, r16(w32) if h16_fwd else w32, b32, st, pd, pv, True)
     g = rng.standard_normal(ref_y.shape)
     g16 = r16(g)
-    ref_dx, ref_dw, ref_db = O.conv2d_bwd(X16, w32, g16, st, pd, pv, True)
+    ref_dx, ref_dw, ref_db = O.conv2d_bwd(X16, r16(w32) if h16_dx else w32, g16, st, pd, pv, True)
     Xd, gd = CP.copy(X), CP.copy(g)
     wd, bd = params32(CP, w, b)
     y = ops.conv2d_fwd(Xd, wd, bd, st, pd, pv, True)

@@ -67,6 +67,22 @@ def main():
         ('down 5x5 s2 4->4 dx+mask', lambda: ops.conv2d_bwd_data(gh4, w44, xh4.shape, (2, 2), (2, 2), x_act=xh4, act='leaky', alpha=0.01), 4.5 * px),
         ('down 5x5 s2 4->4 dw', lambda: ops.conv2d_bwd_weight(xh4, gh4, dw44, db4, (2, 2), (2, 2), 0.0, True, accumulate=False), 2.5 * px),
     ]
+    x1, g1, xl1 = act((n, h, w, 1)), act((n, h, w, 1)), act((n, h // 2, w // 2, 1))
+    w11, b1 = par((5, 5, 1, 1)), par((1,))
+    w14 = par((5, 5, 1, 4))
+    dw11, db1 = CP.zeros((5, 5, 1, 1), np.float32), CP.zeros((1,), np.float32)
+    rows += [
+        ('par end 5x5 1->1 fwd+sigmoid', lambda: ops.conv2d_fwd(x1, w11, b1, (1, 1), (2, 2), 0.0, True, act='sigmoid'), 4 * px),
+        ('par end 5x5 1->1 dx+mask', lambda: ops.conv2d_bwd_data(g1, w11, x1.shape, (1, 1), (2, 2), x_act=x1, act='leaky', alpha=0.01), 6 * px),
+        ('par end 5x5 1->1 dw', lambda: ops.conv2d_bwd_weight(x1, g1, dw11, db1, (1, 1), (2, 2), 0.0, True, accumulate=False), 4 * px),
+        ('par up 1->1 fwd+lrelu', lambda: ops.upconv2x_fwd(xl1, w11, b1, (2, 2), True, act='leaky', alpha=0.01), 2.5 * px),
+        ('par up 1->1 dx+mask', lambda: ops.upconv2x_bwd_data(g1, w11, xl1.shape, (2, 2), x_act=xl1, act='leaky', alpha=0.01), 3 * px),
+        ('par up 1->1 dw', lambda: ops.upconv2x_bwd_weight(xl1, g1, dw11, db1, (2, 2), True, accumulate=False), 2.5 * px),
+        ('par down s2 1->1 fwd', lambda: ops.conv2d_fwd(x1, w11, b1, (2, 2), (2, 2), 0.0, True, act='leaky', alpha=0.01), 2.5 * px),
+        ('par down s2 1->1 dx', lambda: ops.conv2d_bwd_data(xl1, w11, x1.shape, (2, 2), (2, 2)), 2.5 * px),
+        ('line down s2 1->4 fwd', lambda: ops.conv2d_fwd(x1, w14, b4, (2, 2), (2, 2), 0.0, True, act='leaky', alpha=0.01), 4 * px),
+        ('line down s2 1->4 dx', lambda: ops.conv2d_bwd_data(xh4, w14, x1.shape, (2, 2), (2, 2)), 4 * px),
+    ]
     print(f'{"layer":30s} {"h16=0 us":>10s} {"h16=1 us":>10s} {"MB":>8s} {"GB/s":>8s}')
     for name, fn, nbytes in rows:
         t = []

@@ -52,31 +52,37 @@ constexpr int pick_stride(int need, int mod, int target) {
     return rs;
 }
 
-template <int C_, int COUT_, int KH_, int KW_, int S_, int MODE_>
+template <int C_, int COUT_, int KH_, int KW_, int S_, int MODE_, int DY_ = 0>
 struct Geo {
     static constexpr int C = C_, COUT = COUT_, KH = KH_, KW = KW_, S = S_, MODE = MODE_;
     static constexpr int U = (MODE == M_UPFWD || MODE == M_S2DGRAD) ? 2 : 1;   // output pixels per position and axis
     static constexpr int NCO = U * U * COUT;                   // result rows per position: (phase, co)
-    static constexpr int DY = 16 / NCO;                        // position rows of one MFMA chain
+    static constexpr int DY = DY_ ? DY_ : 16 / NCO;            // position rows of one MFMA chain (fewer: zero rows)
     static constexpr int ROWS = (DY - 1) * S + KH;             // window rows of one chain
     static constexpr int IB = (ROWS + 3) / 4;                  // row quads
     static constexpr int Q = (KW * C + 3) / 4;                 // 4-half chunks per window row
     static constexpr int NM = IB * Q;                          // MFMAs per chain
     static constexpr int BC = 64;                              // output columns of a block tile (4 chains)
-    static constexpr int RPW = S == 1 ? 32 / (4 * DY) : 16 / (4 * DY);   // chains (row bands) per wave
+    static constexpr int BRT = S == 1 ? 32 : 16;
+    static constexpr int RPW = BRT / (4 * DY) > 0 ? BRT / (4 * DY) : 1;  // chains (row bands) per wave
     static constexpr int BR = 4 * RPW * DY;                    // output rows of a block tile
     static constexpr int IH = (BR - 1) * S + KH;               // staged input rows
     static constexpr int IHA = (BR - DY) * S + 4 * IB;         // rows a chain may address (the rest stays zero)
-    static constexpr int PXU = 8 / C;                          // pixels per 16-byte staging unit
-    static constexpr int UW = ((BC - 1) * S * C + Q * 4 + 7) / 8;        // staging units per tile row
-    // row stride in halves.  A chain's ds_read_b64 takes 2 LDS passes at best (64 lanes x 8 bytes); the rows kq and
-    // kq + 1 of a half wave must then fall on complementary banks: lanes are 2 dwords apart (C = 4), 1 (C = 2),
-    // 4 (stride 2)
-    static constexpr int RS = S == 2 ? pick_stride(UW * 8, 4, 2) : pick_stride(UW * 8, 64, C == 4 ? 32 : 16);
+    // one channel, stride 1: a chunk starts at any pixel, i.e. at any 2-byte offset -- the tile holds PAIR WORDS
+    // (word[c] = (x[c], x[c+1])), a chunk is the words c and c + 2 (one ds_read2_b32)
+    static constexpr bool PAIRW = C == 1 && S == 1;
+    static constexpr int XS = PAIRW ? 2 : C;                   // halves per pixel in the tile
+    static constexpr int QS = PAIRW ? 8 : 4;                   // halves from one chunk to the next
+    static constexpr int PXU = 8 / XS;                         // pixels per 16-byte staging unit
+    static constexpr int UW = ((BC - 1) * S * XS + Q * QS + 7) / 8;      // staging units per tile row
+    // row stride in halves.  A chain's 8-byte read takes 2 LDS passes at best (64 lanes x 8 bytes); the rows kq and
+    // kq + 1 of a half wave must then fall on complementary banks: lanes are 2 dwords apart (C = 4), 1 (C = 2 and
+    // pair words), 4 (stride 2)
+    static constexpr int RS = (S == 2 && C > 1) ? pick_stride(UW * 8, 4, 2) : pick_stride(UW * 8, 64, C == 4 ? 32 : 16);
     static constexpr int RPP = 256 / UW;                       // tile rows staged per pass of the block
     static constexpr int NPASS = (IH + RPP - 1) / RPP;
     static constexpr int NW = (MODE == M_UPDGRAD || MODE == M_UPFWD || MODE == M_S2DGRAD ? 25 : KH * KW) * C * COUT;
-    static_assert(RPW >= 1 && 16 % NCO == 0 && (C == 2 || C == 4) && UW <= 256, "unsupported geometry");
+    static_assert(RPW >= 1 && 16 % NCO == 0 && DY * NCO <= 16 && (C == 1 || C == 2 || C == 4) && UW <= 256, "unsupported geometry");
 };
 
 template <class G>
@@ -84,8 +90,8 @@ __device__ __forceinline__ f16x4 read_chunk(const _Float16* p) {
     if constexpr (G::C == 4) {
         return *reinterpret_cast<const f16x4*>(p);                       // 8-byte aligned: one pixel
     } else {
-        const uint32_t* q = reinterpret_cast<const uint32_t*>(p);        // 4-byte aligned: two 2-channel pixels
-        const u32x2 v = {q[0], q[1]};
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(p);        // 4-byte aligned
+        const u32x2 v = {q[0], q[G::PAIRW ? 2 : 1]};                     // pair words c, c + 2 / two adjacent dwords
         return __builtin_bit_cast(f16x4, v);
     }
 }
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256) void conv_h16_kernel(const _Float16* __restric
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int ty = 4 * ib + kq - dyi * S, hh = 4 * q + j, tx = hh / C, ci = hh % C;
-                    const bool live = ty >= 0 && ty < G::KH && tx < G::KW;
+                    const bool live = dyi < G::DY && ty >= 0 && ty < G::KH && tx < G::KW;
                     wa[ib * G::Q + q][j] =
                         live ? (_Float16)weight_of<G>(wl, min(max(ty, 0), G::KH - 1), min(tx, G::KW - 1), ci, co)
                              : (_Float16)0.f;
@@ -156,10 +162,11 @@ __global__ __launch_bounds__(256) void conv_h16_kernel(const _Float16* __restric
         // The column part of a thread's address and its in-image bits are the same for all its rows.
         if (stager) {
             const int iy0 = r0 * S - ph, gx0 = c_begin * S - pw + su * G::PXU;
-            bool in_px[G::PXU];
+            constexpr int NPX = G::PXU + (G::PAIRW ? 1 : 0);          // pair words need the pixel after the unit
+            bool in_px[NPX];
             bool all_in = true, any_in = false;
 #pragma unroll
-            for (int k = 0; k < G::PXU; ++k) {
+            for (int k = 0; k < NPX; ++k) {
                 in_px[k] = (unsigned)(gx0 + k) < (unsigned)w_in;
                 all_in = all_in && in_px[k];
                 any_in = any_in || in_px[k];
@@ -172,17 +179,39 @@ __global__ __launch_bounds__(256) void conv_h16_kernel(const _Float16* __restric
                 const bool row_ok = (unsigned)gy < (unsigned)h_in;
                 const _Float16* src = inb + (size_t)min(max(gy, 0), h_in - 1) * w_in * C;
                 v[k] = uint4{padw, padw, padw, padw};
-                if (row_ok && all_in) {
-                    v[k] = *reinterpret_cast<const uint4*>(src + col_off);      // (4-byte aligned at least)
+                if constexpr (G::PAIRW) {
+                    // pixels gx0 .. gx0 + 4 -> the words (p0,p1) (p1,p2) (p2,p3) (p3,p4)
+                    uint32_t px[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) px[q] = padw & 0xFFFFu;
+                    if (row_ok && all_in) {
+                        const uint2 d = *reinterpret_cast<const uint2*>(src + col_off);   // (2-byte aligned at least)
+                        px[0] = d.x & 0xFFFFu, px[1] = d.x >> 16, px[2] = d.y & 0xFFFFu, px[3] = d.y >> 16;
+                        px[4] = __builtin_bit_cast(unsigned short, src[col_off + 4]);
+                    } else if (row_ok && any_in) {
+#pragma unroll
+                        for (int q = 0; q < 5; ++q)
+                            if (in_px[q]) px[q] = __builtin_bit_cast(unsigned short, src[gx0 + q]);
+                    }
+                    v[k] = uint4{px[0] | (px[1] << 16), px[1] | (px[2] << 16), px[2] | (px[3] << 16), px[3] | (px[4] << 16)};
+                } else if (row_ok && all_in) {
+                    v[k] = *reinterpret_cast<const uint4*>(src + col_off);      // (4-byte aligned at least; C = 1: 2)
                 } else if (row_ok && any_in) {                                   // the image edge cuts the unit
-                    uint32_t* vw = reinterpret_cast<uint32_t*>(&v[k]);
+                    if constexpr (C == 1) {
+                        unsigned short* vh = reinterpret_cast<unsigned short*>(&v[k]);
 #pragma unroll
-                    for (int px = 0; px < G::PXU; ++px)
-                        if (in_px[px]) {
-                            const uint32_t* sp = reinterpret_cast<const uint32_t*>(src + (size_t)(gx0 + px) * C);
+                        for (int q = 0; q < 8; ++q)
+                            if (in_px[q]) vh[q] = __builtin_bit_cast(unsigned short, src[gx0 + q]);
+                    } else {
+                        uint32_t* vw = reinterpret_cast<uint32_t*>(&v[k]);
 #pragma unroll
-                            for (int d = 0; d < C / 2; ++d) vw[px * (C / 2) + d] = sp[d];
-                        }
+                        for (int px = 0; px < G::PXU; ++px)
+                            if (in_px[px]) {
+                                const uint32_t* sp = reinterpret_cast<const uint32_t*>(src + (size_t)(gx0 + px) * C);
+#pragma unroll
+                                for (int d = 0; d < C / 2; ++d) vw[px * (C / 2) + d] = sp[d];
+                            }
+                    }
                 }
             }
 #pragma unroll
@@ -202,18 +231,29 @@ __global__ __launch_bounds__(256) void conv_h16_kernel(const _Float16* __restric
             const int rb = (wv * G::RPW + s) * G::DY;    // first output row of the band, relative to the tile
 #pragma unroll
             for (int cg = 0; cg < 4; ++cg) {
-                const _Float16* base = tile + (rb * S + kq) * RS + (cg * 16 + n) * S * C;
+                const _Float16* base = tile + (rb * S + kq) * RS + (cg * 16 + n) * S * G::XS;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ib = 0; ib < G::IB; ++ib)
 #pragma unroll
                     for (int q = 0; q < G::Q; ++q)
-                        acc = mfma16(wa[ib * G::Q + q], read_chunk<G>(base + ib * 4 * RS + 4 * q), acc);
+                        acc = mfma16(wa[ib * G::Q + q], read_chunk<G>(base + ib * 4 * RS + G::QS * q), acc);
                 // lane (column n, kq): rows m = 4kq + i of the result = (dy, co)
                 const int col = c_begin + cg * 16 + n;
                 if (G::U == 1 && col >= w_out) continue;
-                if constexpr (G::U == 2) {                // rows m = (phase = kq, channel i): output pixel 2 P + phase
-                    static_assert(G::U == 1 || COUT == 4, "depth-to-space store: 4 channels");
+                if constexpr (COUT == 1) {                // rows 4kq + i, or (depth to space) row kq, phase i
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int dyi = G::U == 2 ? kq : 4 * kq + i;
+                        const int row = G::U == 2 ? 2 * (r0 + rb + dyi) + (i >> 1) : r0 + rb + dyi;
+                        const int ocol = G::U == 2 ? 2 * col + (i & 1) : col;
+                        if (row >= h_out || ocol >= w_out || dyi >= G::DY) continue;
+                        const size_t off = out_img + (size_t)row * w_out + ocol;
+                        float vi = fast_act(acc[i] + bias4[i], act, alpha);
+                        if (mask_act != UOCR_ACT_NONE) vi *= act_grad_from_output<float>(ld1(mask_y + off), mask_act, mask_alpha);
+                        st1(out + off, vi);
+                    }
+                } else if constexpr (G::U == 2) {         // rows m = (phase = kq, channel i): output pixel 2 P + phase
                     const int row = 2 * (r0 + rb) + (kq >> 1), ocol = 2 * col + (kq & 1);
                     if (row >= h_out || ocol >= w_out) continue;
                     const size_t off = out_img + ((size_t)row * w_out + ocol) * 4;
@@ -296,13 +336,15 @@ inline bool half5x5(const ConvDims& d) {                 // the encoder convs: 5
 
 }  // namespace
 
-// which: 0 forward, 1 backward-data
+// which: 0 forward, 1 backward-data.  Measured against the vector kernels at 8 x 1024 x 2048 (tools/bench_h16.py):
+// every 4-channel layer wins (1.2 - 2.8x); of the 1-channel layers only the stride-1 forward (49 -> 38 us) and the
+// stride-2 1 -> 4 backward-data (30 -> 23 us) do -- 2-byte result stores and 25 FMAs per pixel leave the matrix
+// cores nothing to win -- so the others stay on conv_fast.hip / conv_up.hip.
 bool uocr_conv_h16_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d, int which) {
     if (UOCR_DTYPE_BASE(dtype) != UOCR_F16 || !ctx->opt_fast || !ctx->opt_h16 || d.n > 65535) return false;
-    if (same5x5(d)) return d.cin == 4 && (d.cout == 2 || d.cout == 4);
-    if (half5x5(d)) return d.cin == 4 && d.cout == 4;
+    if (same5x5(d)) return (d.cin == 4 && (d.cout == 2 || d.cout == 4)) || (d.cin == 1 && d.cout == 1 && which == 0);
+    if (half5x5(d)) return (d.cin == 4 && d.cout == 4) || (d.cin == 1 && d.cout == 4 && which == 1);
     return false;
-    (void)which;
 }
 
 int uocr_conv_fwd_h16(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
@@ -313,6 +355,7 @@ int uocr_conv_fwd_h16(uocr_ctx* ctx, const void* x, const void* w, const void* b
                              act, (float)act_alpha, UOCR_ACT_NONE, 0.f);
     };
     if (d.sh == 2) return run(Geo<4, 4, 5, 5, 2, M_FWD>{});
+    if (d.cin == 1) return run(Geo<1, 1, 5, 5, 1, M_FWD>{});
     if (d.cout == 2) return run(Geo<4, 2, 5, 5, 1, M_FWD>{});
     return run(Geo<4, 4, 5, 5, 1, M_FWD>{});
 }
@@ -322,16 +365,18 @@ int uocr_conv_dgrad_h16(uocr_ctx* ctx, const void* dy, const void* w, void* dx, 
     const int mact = mask.y ? mask.act : UOCR_ACT_NONE;
     // stride 2: a 3x3 window over dy per 2x2 block of dx;  stride 1: a forward conv over dy with flipped taps
     // (padding kh - 1 - ph)
-    if (d.sh == 2)
-        return launch_h16<Geo<4, 4, 3, 3, 1, M_S2DGRAD>>(ctx, dy, w, nullptr, dx, mask.y, d.n, d.oh, d.ow, d.h, d.w, 1, 1,
-                                                         0.f, 0, UOCR_ACT_NONE, 0.f, mact, (float)mask.alpha);
-    if (d.cout == 2)
-        return launch_h16<Geo<2, 4, 5, 5, 1, M_DGRAD>>(ctx, dy, w, nullptr, dx, mask.y, d.n, d.oh, d.ow, d.h, d.w,
-                                                       d.kh - 1 - d.ph, d.kw - 1 - d.pw, 0.f, 0, UOCR_ACT_NONE, 0.f,
-                                                       mact, (float)mask.alpha);
-    return launch_h16<Geo<4, 4, 5, 5, 1, M_DGRAD>>(ctx, dy, w, nullptr, dx, mask.y, d.n, d.oh, d.ow, d.h, d.w,
-                                                   d.kh - 1 - d.ph, d.kw - 1 - d.pw, 0.f, 0, UOCR_ACT_NONE, 0.f, mact,
-                                                   (float)mask.alpha);
+    auto run = [&](auto geo, int ph, int pw) {
+        using G = decltype(geo);
+        return launch_h16<G>(ctx, dy, w, nullptr, dx, mask.y, d.n, d.oh, d.ow, d.h, d.w, ph, pw, 0.f, 0, UOCR_ACT_NONE, 0.f,
+                             mact, (float)mask.alpha);
+    };
+    if (d.sh == 2) {
+        if (d.cin == 4) return run(Geo<4, 4, 3, 3, 1, M_S2DGRAD>{}, 1, 1);
+        return run(Geo<4, 1, 3, 3, 1, M_S2DGRAD>{}, 1, 1);
+    }
+    const int ph = d.kh - 1 - d.ph, pw = d.kw - 1 - d.pw;
+    if (d.cout == 2) return run(Geo<2, 4, 5, 5, 1, M_DGRAD>{}, ph, pw);
+    return run(Geo<4, 4, 5, 5, 1, M_DGRAD>{}, ph, pw);
 }
 
 // Upsample2D(2) + conv 5x5 / padding 2, 4 -> 4 channels, on the low-res grid (conv_up.hip)
