@@ -184,6 +184,111 @@ __global__ __launch_bounds__(256) void wgrad_h16_e42_kernel(const _Float16* __re
     if (tid < NV) partial[(size_t)blockIdx.x * NV + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// (1b) 5x5 1 -> 1 (the Paragraph output conv): the same shift trick with M = ty (5 rows + the ones row for db),
+// N = sx: one MFMA per 16 positions; one channel is its own plane, so x is staged as it lies in memory
+// ------------------------------------------------------------------------------------------------------------
+namespace e11 {
+constexpr int BR = 32, BC = 64;
+constexpr int XR = BR + 4, XRS = 72;             // x rows / row stride (halves)
+constexpr int DRS = 72;                          // dy row stride (pair words)
+constexpr int NV = 26;                           // 25 dw + db
+}  // namespace e11
+
+__global__ __launch_bounds__(256) void wgrad_h16_e11_kernel(const _Float16* __restrict__ x,
+                                                            const _Float16* __restrict__ dy,
+                                                            float* __restrict__ partial, int h, int wd, int tiles_x,
+                                                            int tiles_y, int ntiles, float pad) {
+    using namespace e11;
+    __shared__ __attribute__((aligned(16))) _Float16 xs[XR * XRS + 8];    // [row][col] (+ the ones)
+    __shared__ __attribute__((aligned(16))) uint32_t ds[BR * DRS];        // [row][pair word]
+    __shared__ float red[4][NV];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
+    if (tid < 4) reinterpret_cast<uint32_t*>(xs + XR * XRS)[tid] = ONES;
+    const int a0 = min(n, 4) * XRS + 4 * kq;             // A row m = ty (0..4); row 5 = ones; the rest is not read back
+    const bool ones_row = n == 5;
+    const int b0 = 4 * kq + min(n, 4);                   // B column n = sx
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const uint32_t padw = __builtin_bit_cast(uint32_t, f16x2{(_Float16)pad, (_Float16)pad});
+    const int xu = tid & 7, xr0 = tid >> 3;              // x unit = 8 pixels (16 bytes), 8 units per row
+    const int du = tid % 18, dr0 = tid / 18;             // dy unit = 4 pixels + the next one, 18 units per row
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int strip = t % tiles_x, trow = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+        const int C0 = strip * BC - 4, R0 = trow * BR;
+        const _Float16* xb = x + (size_t)img * h * wd;
+        const _Float16* gb = dy + (size_t)img * h * wd;
+        __syncthreads();                                 // the previous tile's reads are over
+        {   // ---- x: image (R0 - 2 + r, C0 + 2 + 8 xu + p)
+            const int gx0 = C0 + 2 + 8 * xu;
+            const bool all_in = gx0 >= 0 && gx0 + 7 < wd, any_in = gx0 + 7 >= 0 && gx0 < wd;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int r = xr0 + 32 * k, gy = R0 - 2 + r;
+                if (r >= XR) continue;
+                const bool row_ok = (unsigned)gy < (unsigned)h;
+                const _Float16* src = xb + (size_t)min(max(gy, 0), h - 1) * wd;
+                uint4 v = uint4{padw, padw, padw, padw};
+                if (row_ok && all_in) {
+                    v = *reinterpret_cast<const uint4*>(src + gx0);                   // (2-byte aligned at least)
+                } else if (row_ok && any_in) {
+                    unsigned short* vh = reinterpret_cast<unsigned short*>(&v);
+#pragma unroll
+                    for (int p = 0; p < 8; ++p)
+                        if ((unsigned)(gx0 + p) < (unsigned)wd) vh[p] = __builtin_bit_cast(unsigned short, src[gx0 + p]);
+                }
+                *reinterpret_cast<uint4*>(xs + r * XRS + 8 * xu) = v;
+            }
+        }
+        {   // ---- dy: image (R0 + r, C0 + 4 du + p), p = 0..4 -> pair words, zero outside the image
+            const int gx0 = C0 + 4 * du;
+            const bool all_in = gx0 >= 0 && gx0 + 4 < wd, any_in = gx0 + 4 >= 0 && gx0 < wd;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int r = dr0 + 14 * k, gy = R0 + r;
+                if (r >= BR || dr0 >= 14) continue;
+                const bool row_ok = gy < h;
+                const _Float16* src = gb + (size_t)min(gy, h - 1) * wd;
+                uint32_t g[5] = {0u, 0u, 0u, 0u, 0u};
+                if (row_ok && all_in) {
+                    const uint2 q = *reinterpret_cast<const uint2*>(src + gx0);
+                    g[0] = q.x & 0xFFFFu, g[1] = q.x >> 16, g[2] = q.y & 0xFFFFu, g[3] = q.y >> 16;
+                    g[4] = __builtin_bit_cast(unsigned short, src[gx0 + 4]);
+                } else if (row_ok && any_in) {
+#pragma unroll
+                    for (int p = 0; p < 5; ++p)
+                        if ((unsigned)(gx0 + p) < (unsigned)wd) g[p] = __builtin_bit_cast(unsigned short, src[gx0 + p]);
+                }
+                *reinterpret_cast<uint4*>(ds + r * DRS + 4 * du) =
+                    uint4{g[0] | (g[1] << 16), g[1] | (g[2] << 16), g[2] | (g[3] << 16), g[3] | (g[4] << 16)};
+            }
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int r = wv; r < BR; r += 4) {
+#pragma unroll
+            for (int c0 = 0; c0 < BC; c0 += 16) {
+                const f16x4 b = read_words(ds + b0 + r * DRS + c0);
+                const f16x4 a = read8(xs + (ones_row ? XR * XRS : a0 + r * XRS + c0));
+                acc = mfma16(a, b, acc);
+            }
+        }
+    }
+    // ---- lane (n = sx, kq) holds rows m = 4kq + i: dw[ty = m][tx = 4 - sx] for m < 5, db at m = 5 (sx = 0)
+    for (int i = tid; i < 4 * NV; i += 256) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+    if (n <= 4 && kq < 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = 4 * kq + i;
+            if (m < 5) red[wv][m * 5 + 4 - n] = acc[i];
+            if (m == 5 && n == 0) red[wv][25] = acc[i];
+        }
+    }
+    __syncthreads();
+    if (tid < NV) partial[(size_t)blockIdx.x * NV + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
 // block a: out[a] (+)= unscale * sum over blocks of partial[blk][a]; a < ndw -> dw, else db
 __global__ __launch_bounds__(256) void wgrad_h16_finish(const float* __restrict__ partial, int nv, int ndw,
                                                         float* __restrict__ dw, float* __restrict__ db, int nblocks,
@@ -363,26 +468,31 @@ int resident_blocks(uocr_ctx* ctx, K kernel, int* cache) {
 
 bool uocr_conv_wgrad_h16_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d) {
     return UOCR_DTYPE_BASE(dtype) == UOCR_F16 && ctx->opt_fast && ctx->opt_h16 && d.kh == 5 && d.kw == 5 && d.sh == 1 &&
-           d.sw == 1 && d.ph == 2 && d.pw == 2 && d.oh == d.h && d.ow == d.w && d.cin == 4 && d.cout == 2 &&
-           (long)d.h * d.w * 4 < (1l << 31);
+           d.sw == 1 && d.ph == 2 && d.pw == 2 && d.oh == d.h && d.ow == d.w &&
+           ((d.cin == 4 && d.cout == 2) || (d.cin == 1 && d.cout == 1)) && (long)d.h * d.w * 4 < (1l << 31);
 }
 
 int uocr_conv_wgrad_h16(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
                         double pad_value, int use_bias, int accumulate) {
-    static int cache = 0;
-    const int tiles_x = (d.w + 4 + e42::BC - 1) / e42::BC, tiles_y = (d.h + e42::BR - 1) / e42::BR;
+    static int cache42 = 0, cache11 = 0;
+    const bool one = d.cin == 1;
+    const int nv = one ? e11::NV : e42::NV;
+    const int tiles_x = (d.w + 4 + e42::BC - 1) / e42::BC, tiles_y = (d.h + e42::BR - 1) / e42::BR;   // (e11: same tile)
     const long ntiles = (long)d.n * tiles_y * tiles_x;
     UOCR_REQUIRE(ctx, ntiles < (1l << 31));
-    const long cap = (long)ctx->cu_count * resident_blocks(ctx, wgrad_h16_e42_kernel, &cache);
+    const long cap = (long)ctx->cu_count * (one ? resident_blocks(ctx, wgrad_h16_e11_kernel, &cache11)
+                                                : resident_blocks(ctx, wgrad_h16_e42_kernel, &cache42));
     const int grid = (int)(ntiles < cap ? ntiles : cap);
-    int rc = uocr_need_workspace(ctx, (size_t)grid * e42::NV * sizeof(float));
+    int rc = uocr_need_workspace(ctx, (size_t)grid * nv * sizeof(float));
     if (rc != UOCR_OK) return rc;
     float* partial = (float*)ctx->workspace;
-    hipLaunchKernelGGL(wgrad_h16_e42_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const _Float16*)x,
-                       (const _Float16*)dy, partial, d.h, d.w, tiles_x, tiles_y, (int)ntiles, (float)pad_value);
+    hipLaunchKernelGGL(one ? wgrad_h16_e11_kernel : wgrad_h16_e42_kernel, dim3(grid), dim3(256), 0, ctx->stream,
+                       (const _Float16*)x, (const _Float16*)dy, partial, d.h, d.w, tiles_x, tiles_y, (int)ntiles,
+                       (float)pad_value);
     UOCR_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(wgrad_h16_finish, dim3(e42::NV), dim3(256), 0, ctx->stream, (const float*)partial, e42::NV, 200,
-                       (float*)dw, (float*)db, grid, use_bias, accumulate, (float)uocr_grad_unscale(dtype));
+    hipLaunchKernelGGL(wgrad_h16_finish, dim3(nv), dim3(256), 0, ctx->stream, (const float*)partial, nv,
+                       one ? 25 : 200, (float*)dw, (float*)db, grid, use_bias, accumulate,
+                       (float)uocr_grad_unscale(dtype));
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
 }
