@@ -293,6 +293,54 @@ def secondary_rooflines(rt, timer, watchdog):
     return out
 
 
+def secondary_rooflines_f16(rt, timer, watchdog, batch, height, width):
+    """highres-fp16: the Line net's full-resolution layers (binary16 storage, binary16 MFMAs: csrc/conv_h16.hip,
+    conv_h16w.hip) alone, against the HBM peak.  Algorithmic bytes = every tensor the op reads or writes once, 2 bytes
+    per activation element."""
+    import numpy as np
+
+    from univer_ocr_amd.nn import CP, ops
+    CP.set_dtype('float16')
+    rng = np.random.default_rng(0)
+    n, h, w = batch, height, width
+
+    def act(shape):
+        t = CP.empty(shape, np.float16)
+        slab = CP.copy(rng.standard_normal((1,) + tuple(shape[1:])).astype(np.float32))
+        for i in range(shape[0]):
+            t.t[i].copy_(slab.t[0], non_blocking=True)
+        return t
+
+    def par(shape, s=0.2):
+        return CP.copy(rng.standard_normal(shape) * s, np.float32)
+    x4, g2, g4, xl = act((n, h, w, 4)), act((n, h, w, 2)), act((n, h, w, 4)), act((n, h // 2, w // 2, 4))
+    w42, b2, w44, b4 = par((5, 5, 4, 2)), par((2,)), par((5, 5, 4, 4)), par((4,))
+    dw42, db2 = CP.zeros((5, 5, 4, 2), np.float32), CP.zeros((2,), np.float32)
+    dw44, db4 = CP.zeros((5, 5, 4, 4), np.float32), CP.zeros((4,), np.float32)
+    px = n * h * w
+    rows = (
+        ('Line end conv 5x5 4->2 + Sigmoid fwd (f16 MFMA, Toeplitz rows)',
+         lambda: ops.conv2d_fwd(x4, w42, b2, (1, 1), (2, 2), 0.0, True, act='sigmoid'), 12 * px),
+        ('Line end conv dx + LeakyReLU mask', lambda: ops.conv2d_bwd_data(g2, w42, x4.shape, (1, 1), (2, 2), x_act=x4,
+                                                                         act='leaky', alpha=0.01), 20 * px),
+        ('Line end conv dw', lambda: ops.conv2d_bwd_weight(x4, g2, dw42, db2, (1, 1), (2, 2), 0.0, True, accumulate=False),
+         12 * px),
+        ('Line up_1 (upsample 2x + conv 5x5 4->4 + LeakyReLU) fwd',
+         lambda: ops.upconv2x_fwd(xl, w44, b4, (2, 2), True, act='leaky', alpha=0.01), 10 * px),
+        ('Line up_1 dx + LeakyReLU mask', lambda: ops.upconv2x_bwd_data(g4, w44, xl.shape, (2, 2), x_act=xl, act='leaky',
+                                                                       alpha=0.01), 12 * px),
+        ('Line up_1 dw', lambda: ops.upconv2x_bwd_weight(xl, g4, dw44, db4, (2, 2), True, accumulate=False), 10 * px),
+    )
+    out = []
+    for label, fn, nbytes in rows:
+        us = timer.time_us(fn, 10)
+        gbs = nbytes / us / 1e3
+        out.append({'kernel': f'{label}, {n} x {h} x {w}', 'bound': 'hbm', 'achieved': round(gbs, 0), 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 3), 'launch_us': round(us, 1)})
+        watchdog.beat('secondary rooflines')
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -577,7 +625,11 @@ def main():
             del context, layers
             trainer.join()
             torch.cuda.synchronize()
-            out['roofline']['secondary'] = secondary_rooflines(rt, timer, watchdog)
+            if cfg['dtype'] == 'float16':
+                out['roofline']['secondary'] = secondary_rooflines_f16(rt, timer, watchdog, cfg['batch'], cfg['height'],
+                                                                       cfg['width'])
+            else:
+                out['roofline']['secondary'] = secondary_rooflines(rt, timer, watchdog)
         if world == 1 and not args.no_cpu_baseline:
             watchdog.limit = max(watchdog.limit, 600.0)      # host-only phase: no collective can hang here
             out['cpu_baseline'] = cpu_baseline(cfg, args, initial)

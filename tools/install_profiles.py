@@ -44,7 +44,7 @@ def summarise(stats_dir, stem, marker, steps=25):
 
 def main():
     rows, out = summarise('stats', 'rocprofv3', 'conv_pair_bwd_kernel')
-    summarise('stats_hr', 'rocprofv3_highres_fp16', 'conv_pair_bwd_kernel')
+    summarise('stats_hr', 'rocprofv3_highres_fp16', 'conv_pair_bwd')
     for src, dst in (('bench_n1.json', 'bench_n1.json'), ('bench_under_rocprofv3.json', 'bench_n1_under_rocprofv3.json'),
                      ('bench_hr_n1.json', 'bench_highres_fp16_n1.json'),
                      ('bench_hr_under_rocprofv3.json', 'bench_highres_fp16_under_rocprofv3.json'),
@@ -54,6 +54,7 @@ def main():
     for src, dst in (('conv_microbench.txt', f'{TAG}_conv_microbench.txt'), ('membw.txt', f'{TAG}_membw.txt'),
                      ('ubench_coexec.txt', f'{TAG}_ubench_mfma_valu_coexec.txt'),
                      ('ubench_switch.txt', f'{TAG}_ubench_mfma_switch.txt'),
+                     ('bench_h16.txt', f'{TAG}_h16_microbench.txt'),
                      ('pmc_pair_summary.txt', f'{TAG}_pmc_pair_kernels.txt')):
         if os.path.exists(f'{R}/{src}'):
             open(f'{P}/{dst}', 'w').write(''.join(line for line in open(f'{R}/{src}') if 'amdgpu.ids' not in line))

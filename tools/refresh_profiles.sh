@@ -23,6 +23,7 @@ case "$1" in
     UOCR_BENCH_FORCE_DP=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-secondary > "$OUT/bench_dp1_rehearsal.json" 2> "$OUT/bench_dp1.err"
     timeout -k 10 400 python3 tools/bench_conv.py > "$OUT/conv_microbench.txt" 2>&1
     timeout -k 10 300 python3 tools/bench_membw.py > "$OUT/membw.txt" 2>&1
+    timeout -k 10 300 python3 tools/bench_h16.py > "$OUT/bench_h16.txt" 2>&1
     hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_valu_coexec.hip -o /tmp/coexec 2> /dev/null && timeout -k 5 60 /tmp/coexec > "$OUT/ubench_coexec.txt"
     hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_switch.hip -o /tmp/sw 2> /dev/null && timeout -k 5 60 /tmp/sw > "$OUT/ubench_switch.txt"
     ;;
