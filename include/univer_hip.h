@@ -73,8 +73,13 @@ void* uocr_ctx_get_stream(uocr_ctx* ctx);
  * "tiled" = 0 / 1 (default) LDS-tiled conv kernels where instantiated; MFMA GEMM tuning:
  * "split_blocks" (1024: split the depth until about this many blocks exist, 0 = never),
  * "split_min" (3: smallest number of slabs worth a reduce pass), "gemm_bm" (0 auto / 64 / 128 row
- * tile), "xcd_remap" (1: neighbouring tiles are numbered onto the same XCD / L2).  Results do not
- * depend on any of them beyond float32 summation order. */
+ * tile), "xcd_remap" (1: neighbouring tiles are numbered onto the same XCD / L2), "h16" (1: UOCR_F16
+ * convolutions with 1-4 channels run on binary16 MFMAs -- the float32 weights enter the matrix cores
+ * rounded to binary16, accumulation stays float32; 0: float32 vector arithmetic on the binary16 data),
+ * "t32" (bit mask, default 2: which float32 small-channel convolutions use the float32-MFMA Toeplitz
+ * kernels: 1 forward / 2 backward-data / 4 upsample+conv backward-data of the 4-channel layers,
+ * 8 / 16 / 32 the same for 1-channel layers).  Results do not depend on any of them beyond float32
+ * summation order ("h16": beyond the binary16 rounding of the weight operands). */
 int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value);
 int uocr_ctx_reserve_workspace(uocr_ctx* ctx, size_t bytes);   /* synchronises; not capturable */
 const char* uocr_last_error(uocr_ctx* ctx);
