@@ -335,8 +335,9 @@ def test_pipelined_lanes_match_joined_steps(graphs):
                 last = context
             trainer.join()
             pred = CP.asnumpy(last['line_pred'])
+            # every step's losses are read only now: with graphs they are per-step snapshots of the static slots
             history = [{n: [float(v) for v in l['output_losses']] + [float(l['regularization_loss'])]
-                        for n, l in losses.items()} for losses in kept[-2:]]
+                        for n, l in losses.items()} for losses in kept]
             weights = {}
             for model in trainer.models.values():
                 weights.update(model.get_weights())
@@ -344,6 +345,8 @@ def test_pipelined_lanes_match_joined_steps(graphs):
     finally:
         CP.lazy_losses = lazy
     assert results[0][0] == results[1][0]
+    # the snapshots are distinct values per step (fresh batches, moving weights), not seven aliases of the last one
+    assert len({tuple(step['Line']) for step in results[0][0]}) == 7
     assert np.array_equal(results[0][1], results[1][1])
     for name, w in results[0][2].items():
         assert np.array_equal(np.asarray(w), np.asarray(results[1][2][name])), name

@@ -31,6 +31,7 @@ class PageTrainer:
                  nets=('Monochrome', 'Paragraph', 'Line', 'Char'), data_parallel=None, overlap=True,
                  dp_coalesce=False, dp_backend=None,
                  init='kaiming_normal', fuse=True, lanes=True, input_grads=True, graphs=False, eager_nets=(), pipelined=False,
+                 snapshot_losses=True,
                  lane_groups=(('Monochrome', 'Paragraph'), ('Line',), ('Char',))):
         np.random.seed(seed)                        # kaiming_uniform draws from the NumPy global RNG
         self.batch = batch
@@ -73,6 +74,10 @@ class PageTrainer:
         # Works best with one hardware queue per stream: GPU_MAX_HW_QUEUES=8 in the environment before the
         # first GPU call (bench.py sets it; ROCm's default 4 makes two nets share a queue)
         self.pipelined = bool(pipelined) and self.lanes is not None
+        # graphs: the captured step writes its losses into static slots that the NEXT replay overwrites; with
+        # snapshot_losses every step() copies them (one 8-byte-per-loss copy per net, on the net's lane) so that the
+        # scalars it returns keep the value of THEIR step however late they are read
+        self.snapshot_losses = bool(snapshot_losses)
         self._lane_done = {}
         self.eager_nets = tuple(eager_nets)          # nets kept out of the graphs (e.g. to time one kernel)
         self._captured = None
@@ -247,10 +252,12 @@ class PageTrainer:
                 finish = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(finish, stream=stream, capture_error_mode='thread_local'):
                     losses = model.train_finish()
+                    # all loss slots of the net side by side: one copy per step snapshots them (step())
+                    packed = torch.stack([v.t.reshape(()) for v in pending] + [losses['regularization_loss'].t.reshape(())])
             for value in pending + [losses['regularization_loss']]:
                 if not isinstance(value, DeviceScalar):
                     raise RuntimeError('graph capture: a loss was materialised on the host')
-            entry.update(begin=begin, finish=finish, output_losses=[v.t for v in pending],
+            entry.update(begin=begin, finish=finish, packed_losses=packed, output_losses=[v.t for v in pending],
                          regularization_loss=losses['regularization_loss'].t,
                          prediction=context.get(comp.selector.pred_label))
             model.grad_sync = sync
@@ -317,6 +324,7 @@ class PageTrainer:
                 if comp.model.grad_sync is not None:
                     comp.model.grad_sync(comp.model)          # RCCL all-reduce of the flat gradient
         context['losses'] = {}
+        snaps = {}
         for comp in comps:
             entry, model = self._captured.get(comp.name), comp.model
             with rt.lane(self.lanes[comp.name]) as stream:
@@ -326,6 +334,8 @@ class PageTrainer:
                     if model.grad_sync is not None and model.defer_grad_sync:
                         model.grad_sync.__self__.wait(model)
                     entry['finish'].replay()
+                    if self.snapshot_losses:
+                        snaps[comp.name] = entry['packed_losses'].clone()
                 done = self._events[comp.name] if not self.pipelined else torch.cuda.Event()
                 done.record(stream)
             if entry is None:
@@ -333,9 +343,15 @@ class PageTrainer:
                 continue
             if entry['prediction'] is not None:
                 context[comp.selector.pred_label] = entry['prediction']
-            context['losses'][comp.name] = {
-                'output_losses': [DeviceScalar(t) for t in entry['output_losses']],
-                'regularization_loss': DeviceScalar(entry['regularization_loss'])}
+            if snaps.get(comp.name) is not None:
+                snap = snaps[comp.name]
+                context['losses'][comp.name] = {
+                    'output_losses': [DeviceScalar(snap[i]) for i in range(len(entry['output_losses']))],
+                    'regularization_loss': DeviceScalar(snap[len(entry['output_losses'])])}
+            else:                                             # aliases of the static slots: read before the next step()
+                context['losses'][comp.name] = {
+                    'output_losses': [DeviceScalar(t) for t in entry['output_losses']],
+                    'regularization_loss': DeviceScalar(entry['regularization_loss'])}
             self._finish_lane(comp.name, done, context['losses'][comp.name], main)
         return context['losses']
 
