@@ -43,7 +43,7 @@ constexpr uint32_t ONES = 0x3C003C00u;                                     // (1
 // (1) 5x5 4 -> 2
 // ------------------------------------------------------------------------------------------------------------
 namespace e42 {
-constexpr int BR = 32, BC = 64;                  // positions per tile
+constexpr int BR = 16, BC = 64;                  // positions per tile
 constexpr int XR = BR + 4;                       // x rows of a tile
 constexpr int XRS = 72;                          // x plane row stride (halves): 36 dwords, with XP = 16 (mod 64) dwords
 constexpr int XP = XR * XRS;                     //   the 16 (ty, ci) rows of an A read fall on disjoint banks
@@ -477,7 +477,8 @@ int uocr_conv_wgrad_h16(uocr_ctx* ctx, int dtype, const void* x, const void* dy,
     static int cache42 = 0, cache11 = 0;
     const bool one = d.cin == 1;
     const int nv = one ? e11::NV : e42::NV;
-    const int tiles_x = (d.w + 4 + e42::BC - 1) / e42::BC, tiles_y = (d.h + e42::BR - 1) / e42::BR;   // (e11: same tile)
+    const int br = one ? e11::BR : e42::BR;
+    const int tiles_x = (d.w + 4 + e42::BC - 1) / e42::BC, tiles_y = (d.h + br - 1) / br;   // (both: 64 columns)
     const long ntiles = (long)d.n * tiles_y * tiles_x;
     UOCR_REQUIRE(ctx, ntiles < (1l << 31));
     const long cap = (long)ctx->cu_count * (one ? resident_blocks(ctx, wgrad_h16_e11_kernel, &cache11)
