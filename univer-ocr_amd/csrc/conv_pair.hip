@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void conv_pair_fwd_h_kernel(const _Float16* __
             for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
                 for (int tx = 0; tx < 3; ++tx) v += ps[((pr + ty) * RW + pc + tx) * 9 + ty * 3 + tx];
-            if (gy < row_end && gx < wd) st1(yb + (size_t)gy * wd + gx, out_act(v, act2));
+            if (gy < row_end && gx < wd) st1(yb + (size_t)gy * wd + gx, act2 == UOCR_ACT_SIGMOID ? __builtin_amdgcn_rcpf(1.f + __expf(-v)) : v);   // (binary16 result: v_exp / v_rcp suffice)
         }
     }
 }
