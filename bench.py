@@ -393,6 +393,9 @@ def main():
     # communication streams, so two of them share a queue and run one after the other (1.25 -> 1.10 ms/step).
     # Read by the HIP runtime when it starts, hence set before torch touches the GPU.
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+    # RCCL shares device buffers between the ranks' processes through dmabuf IPC; the host driver of this pool
+    # supports no other mode (without it: hipIpcGetMemHandle: invalid argument)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
     import torch
     import torch.distributed as dist

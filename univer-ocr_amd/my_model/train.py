@@ -34,6 +34,11 @@ def load_weights(path=MODEL_WEIGHTS_FILE_PATH):
         return {}
 
 
+def _ipc_env():
+    """RCCL shares device buffers between the ranks' processes through dmabuf IPC (set before the GPU is touched)."""
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+
 def _init_data_parallel():
     """Launched by torch.distributed.run (one rank per GPU)?  Then torch.distributed -- gloo: host-side
     rendezvous only -- carries the RCCL id and the epoch losses; the gradients travel through the C ABI's RCCL
@@ -41,6 +46,7 @@ def _init_data_parallel():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world == 1:
         return 0, 1, None
+    _ipc_env()
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     rank = int(os.environ.get('RANK', '0'))
