@@ -81,6 +81,8 @@ def main():
         ('par down s2 1->1 fwd', lambda: ops.conv2d_fwd(x1, w11, b1, (2, 2), (2, 2), 0.0, True, act='leaky', alpha=0.01), 2.5 * px),
         ('par down s2 1->1 dx', lambda: ops.conv2d_bwd_data(xl1, w11, x1.shape, (2, 2), (2, 2)), 2.5 * px),
         ('line down s2 1->4 fwd', lambda: ops.conv2d_fwd(x1, w14, b4, (2, 2), (2, 2), 0.0, True, act='leaky', alpha=0.01), 4 * px),
+        ('par down s2 1->1 dw', lambda: ops.conv2d_bwd_weight(x1, xl1, dw11, db1, (2, 2), (2, 2), 0.0, True, accumulate=False), 2.5 * px),
+        ('line down s2 1->4 dw', lambda: ops.conv2d_bwd_weight(x1, xh4, CP.zeros((5, 5, 1, 4), np.float32), db4, (2, 2), (2, 2), 0.0, True, accumulate=False), 4 * px),
         ('line down s2 1->4 dx', lambda: ops.conv2d_bwd_data(xh4, w14, x1.shape, (2, 2), (2, 2)), 4 * px),
     ]
     print(f'{"layer":30s} {"h16=0 us":>10s} {"h16=1 us":>10s} {"MB":>8s} {"GB/s":>8s}')

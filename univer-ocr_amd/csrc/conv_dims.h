@@ -37,6 +37,9 @@ int uocr_upconv_dgrad_h16(uocr_ctx* ctx, const void* dy, const void* w, void* dx
 bool uocr_conv_wgrad_h16_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d);
 int uocr_conv_wgrad_h16(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
                         double pad_value, int use_bias, int accumulate);
+bool uocr_conv_wgrad_s2_h16_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d);
+int uocr_conv_wgrad_s2_h16(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
+                           double pad_value, int use_bias, int accumulate);
 int uocr_upconv_wgrad_h16(uocr_ctx* ctx, const void* x_low, const void* dy, float* partial, size_t partial_floats,
                           int n, int hl, int wl, int* nblocks);
 // float32 vertical-Toeplitz MFMA kernels of the small-channel convs (conv_t32.hip); which: 0 fwd, 1 dgrad

@@ -454,6 +454,201 @@ __global__ __launch_bounds__(256) void wgrad_h16_up_kernel(const _Float16* __res
         partial[(size_t)blockIdx.x * NV + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// (3) 5x5 / stride 2 / padding 2 (the encoder convs: 4 -> 4, 1 -> 4, 1 -> 1)
+//     dw[ty][tx][ci][co] = sum_{Y, X} xpad[2Y + ty - 2][2X + tx - 2][ci] * dy[Y][X][co]
+// The stride makes the x operand every second column: x is staged as EVEN / ODD column planes per channel
+// (E[j] = x[2j], O[j] = x[2j+1]); tap column tx = 2e reads E[X + e - 1], tx = 2o + 1 reads O[X + o - 1].  As in (1)
+// the shift s in {-1, 0, +1} moves to the dy operand: with Q = X + s, N = (co, sx = 1 - s) reads dy[Q + sx - 1]
+// (pair words) and M = (parity, ty, ci) reads its plane at Q (aligned): 10 * CI rows -> 3 MFMAs (CI = 4) or 1 (CI = 1)
+// per 16 positions; (odd plane, sx = 0) would be tx = 5 and is dropped; a row of ones yields db.
+// ------------------------------------------------------------------------------------------------------------
+template <int CI, int CO>
+struct S2 {
+    static constexpr int BR = 8, BC = 64;            // positions (Y, Q) per tile
+    static constexpr int XR = 2 * BR + 3;            // x rows of a tile
+    static constexpr int XRS = 72;                   // plane row stride (halves): 68 used
+    static constexpr int XP = XR * XRS + 8;          // plane stride (halves)
+    static constexpr int DRS = 72;                   // dy plane row stride (pair words)
+    static constexpr int DP = BR * DRS + 8;          // dy plane stride (words)
+    static constexpr int NT = (10 * CI + 1 + 15) / 16;   // M tiles (the ones row included)
+    static constexpr int NV = 25 * CI * CO + CO;
+    static constexpr int XU = 17;                    // x staging units (8 pixels) per row: 136 >= 132 pixels
+};
+
+template <int CI, int CO>
+__global__ __launch_bounds__(256) void wgrad_h16_s2_kernel(const _Float16* __restrict__ x,
+                                                           const _Float16* __restrict__ dy,
+                                                           float* __restrict__ partial, int h, int wd, int oh, int ow,
+                                                           int tiles_x, int tiles_y, int ntiles, float pad) {
+    using G = S2<CI, CO>;
+    constexpr int BR = G::BR, BC = G::BC, XR = G::XR, XRS = G::XRS, XP = G::XP, DRS = G::DRS, DP = G::DP, NT = G::NT;
+    __shared__ __attribute__((aligned(16))) _Float16 xs[2 * CI * XP + 8];   // [(ci, parity)][row][j] (+ the ones)
+    __shared__ __attribute__((aligned(16))) uint32_t ds[CO * DP];           // [co][row][pair word]
+    __shared__ float red[4][G::NV];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
+    if (tid < 4) reinterpret_cast<uint32_t*>(xs + 2 * CI * XP)[tid] = ONES;
+    // A rows m = (parity * 5 + ty) * CI + ci (10 * CI of them), then the ones row; per M tile the lane's plane offset
+    int a_off[NT];
+    bool a_ones[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int m = 16 * t + n, mm = min(m, 10 * CI - 1);
+        const int ci = mm % CI, pt = mm / CI, ty = pt % 5, par = pt / 5;
+        a_off[t] = (ci * 2 + par) * XP + ty * XRS + 4 * kq;      // + 2 r * XRS + c0
+        a_ones[t] = m == 10 * CI;
+    }
+    // B column n = co * 4 + sx (CO = 4) / sx (CO = 1); sx = 3 (and columns >= 3 for CO = 1) are not read back
+    const int b_sx = min(CO == 4 ? (n & 3) : n, 2), b_co = CO == 4 ? (n >> 2) : 0;
+    const int b0 = b_co * DP + 4 * kq + b_sx;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint32_t padw = __builtin_bit_cast(uint32_t, f16x2{(_Float16)pad, (_Float16)pad});
+    const int xu = tid % G::XU, xr0 = tid / G::XU;       // x unit = 8 pixels, 17 units per row, 15 rows per pass
+    const int du = tid % 18, dr0 = tid / 18;             // dy unit = 4 pixels + the next one, 18 units per row
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int strip = t % tiles_x, trow = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+        const int C0 = strip * BC - 1, R0 = trow * BR;   // plane index Q of tile column 0; first position row
+        const _Float16* xb = x + (size_t)img * h * wd * CI;
+        const _Float16* gb = dy + (size_t)img * oh * ow * CO;
+        __syncthreads();                                 // the previous tile's reads are over
+        {   // ---- x: image row 2 R0 - 2 + r, pixels 2 C0 + 8 xu + p (p = 0..7) -> even / odd planes at j = 4 xu + p / 2
+            const int gx0 = 2 * C0 + 8 * xu;
+            const bool all_in = gx0 >= 0 && gx0 + 7 < wd, any_in = gx0 + 7 >= 0 && gx0 < wd;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int r = xr0 + 15 * k, gy = 2 * R0 - 2 + r;
+                if (r >= XR || xr0 >= 15) continue;
+                const bool row_ok = (unsigned)gy < (unsigned)h;
+                const _Float16* src = xb + (size_t)min(max(gy, 0), h - 1) * wd * CI;
+                _Float16* row = xs + r * XRS + 4 * xu;
+                if constexpr (CI == 4) {
+                    uint32_t d[16];                      // pixel p = dwords (2p, 2p+1) = (c0 | c1 << 16, c2 | c3 << 16)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) d[q] = padw;
+                    if (row_ok && all_in) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)gx0 * 4 + 8 * q);
+                            d[4 * q] = v.x, d[4 * q + 1] = v.y, d[4 * q + 2] = v.z, d[4 * q + 3] = v.w;
+                        }
+                    } else if (row_ok && any_in) {
+#pragma unroll
+                        for (int p = 0; p < 8; ++p)
+                            if ((unsigned)(gx0 + p) < (unsigned)wd) {
+                                const uint32_t* sp = reinterpret_cast<const uint32_t*>(src + (size_t)(gx0 + p) * 4);
+                                d[2 * p] = sp[0], d[2 * p + 1] = sp[1];
+                            }
+                    }
+                    // plane (ci, parity) <- that channel of the pixels parity, parity + 2, parity + 4, parity + 6
+#pragma unroll
+                    for (int par = 0; par < 2; ++par) {
+                        const int o = 2 * par;
+                        *reinterpret_cast<u32x2*>(row + (0 * 2 + par) * XP) = u32x2{lo_pair(d[o], d[o + 4]), lo_pair(d[o + 8], d[o + 12])};
+                        *reinterpret_cast<u32x2*>(row + (1 * 2 + par) * XP) = u32x2{hi_pair(d[o], d[o + 4]), hi_pair(d[o + 8], d[o + 12])};
+                        *reinterpret_cast<u32x2*>(row + (2 * 2 + par) * XP) = u32x2{lo_pair(d[o + 1], d[o + 5]), lo_pair(d[o + 9], d[o + 13])};
+                        *reinterpret_cast<u32x2*>(row + (3 * 2 + par) * XP) = u32x2{hi_pair(d[o + 1], d[o + 5]), hi_pair(d[o + 9], d[o + 13])};
+                    }
+                } else {
+                    uint32_t d[4] = {padw, padw, padw, padw};         // 8 one-channel pixels
+                    if (row_ok && all_in) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(src + gx0);
+                        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+                    } else if (row_ok && any_in) {
+                        unsigned short* dh = reinterpret_cast<unsigned short*>(d);
+#pragma unroll
+                        for (int p = 0; p < 8; ++p)
+                            if ((unsigned)(gx0 + p) < (unsigned)wd) dh[p] = __builtin_bit_cast(unsigned short, src[gx0 + p]);
+                    }
+                    *reinterpret_cast<u32x2*>(row + 0 * XP) = u32x2{lo_pair(d[0], d[1]), lo_pair(d[2], d[3])};
+                    *reinterpret_cast<u32x2*>(row + 1 * XP) = u32x2{hi_pair(d[0], d[1]), hi_pair(d[2], d[3])};
+                }
+            }
+        }
+        if (dr0 < BR) {   // ---- dy: (R0 + dr0, C0 - 1 + 4 du + p), p = 0..4 -> pair-word planes, zero outside
+            const int gx0 = C0 - 1 + 4 * du, gy = R0 + dr0;
+            const bool all_in = gx0 >= 0 && gx0 + 4 < ow, any_in = gx0 + 4 >= 0 && gx0 < ow;
+            const bool row_ok = gy < oh;
+            const _Float16* src = gb + (size_t)min(gy, oh - 1) * ow * CO;
+            uint32_t* row = ds + dr0 * DRS + 4 * du;
+            if constexpr (CO == 4) {
+                uint32_t v[10];
+#pragma unroll
+                for (int q = 0; q < 10; ++q) v[q] = 0u;
+                const uint32_t* sw = reinterpret_cast<const uint32_t*>(src);
+                if (row_ok && all_in) {
+                    const uint4 q0 = *reinterpret_cast<const uint4*>(sw + 2 * gx0);
+                    const uint4 q1 = *reinterpret_cast<const uint4*>(sw + 2 * gx0 + 4);
+                    const uint2 q2 = *reinterpret_cast<const uint2*>(sw + 2 * gx0 + 8);
+                    v[0] = q0.x, v[1] = q0.y, v[2] = q0.z, v[3] = q0.w, v[4] = q1.x, v[5] = q1.y, v[6] = q1.z, v[7] = q1.w;
+                    v[8] = q2.x, v[9] = q2.y;
+                } else if (row_ok && any_in) {
+#pragma unroll
+                    for (int p = 0; p < 5; ++p)
+                        if ((unsigned)(gx0 + p) < (unsigned)ow) v[2 * p] = sw[2 * (gx0 + p)], v[2 * p + 1] = sw[2 * (gx0 + p) + 1];
+                }
+                *reinterpret_cast<uint4*>(row + 0 * DP) = uint4{lo_pair(v[0], v[2]), lo_pair(v[2], v[4]), lo_pair(v[4], v[6]), lo_pair(v[6], v[8])};
+                *reinterpret_cast<uint4*>(row + 1 * DP) = uint4{hi_pair(v[0], v[2]), hi_pair(v[2], v[4]), hi_pair(v[4], v[6]), hi_pair(v[6], v[8])};
+                *reinterpret_cast<uint4*>(row + 2 * DP) = uint4{lo_pair(v[1], v[3]), lo_pair(v[3], v[5]), lo_pair(v[5], v[7]), lo_pair(v[7], v[9])};
+                *reinterpret_cast<uint4*>(row + 3 * DP) = uint4{hi_pair(v[1], v[3]), hi_pair(v[3], v[5]), hi_pair(v[5], v[7]), hi_pair(v[7], v[9])};
+            } else {
+                uint32_t g[5] = {0u, 0u, 0u, 0u, 0u};
+                if (row_ok && all_in) {
+                    const uint2 q = *reinterpret_cast<const uint2*>(src + gx0);
+                    g[0] = q.x & 0xFFFFu, g[1] = q.x >> 16, g[2] = q.y & 0xFFFFu, g[3] = q.y >> 16;
+                    g[4] = __builtin_bit_cast(unsigned short, src[gx0 + 4]);
+                } else if (row_ok && any_in) {
+#pragma unroll
+                    for (int p = 0; p < 5; ++p)
+                        if ((unsigned)(gx0 + p) < (unsigned)ow) g[p] = __builtin_bit_cast(unsigned short, src[gx0 + p]);
+                }
+                *reinterpret_cast<uint4*>(row) = uint4{g[0] | (g[1] << 16), g[1] | (g[2] << 16), g[2] | (g[3] << 16), g[3] | (g[4] << 16)};
+            }
+        }
+        __syncthreads();
+        // ---- wave wv: position rows wv, wv + 4; x rows of position row r and tap row ty: 2 r + ty
+#pragma unroll
+        for (int r = wv; r < BR; r += 4) {
+#pragma unroll
+            for (int c0 = 0; c0 < BC; c0 += 16) {
+                const f16x4 b = read_words(ds + b0 + r * DRS + c0);
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    const f16x4 a = read8(xs + (a_ones[tt] ? 2 * CI * XP : a_off[tt] + 2 * r * XRS + c0));
+                    acc[tt] = mfma16(a, b, acc[tt]);
+                }
+            }
+        }
+    }
+    // ---- block reduction: lane (n = (co, sx), kq) holds rows m = 16 t + 4 kq + i = (parity, ty, ci) | ones
+    for (int i = tid; i < 4 * G::NV; i += 256) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+    {
+        const int sx = CO == 4 ? (n & 3) : n, co = CO == 4 ? (n >> 2) : 0;
+        const bool col_ok = CO == 4 ? sx < 3 : n < 3;
+        if (col_ok) {
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = 16 * tt + 4 * kq + i;
+                    if (m < 10 * CI) {
+                        const int ci = m % CI, pt = m / CI, ty = pt % 5, par = pt / 5;
+                        const int tx = 2 * (2 - sx) + par;           // s = 1 - sx; even plane: 2 (s + 1), odd: 2 (s + 1) + 1
+                        if (tx < 5) red[wv][((ty * 5 + tx) * CI + ci) * CO + co] = acc[tt][i];
+                    } else if (m == 10 * CI && sx == 0) {
+                        red[wv][25 * CI * CO + co] = acc[tt][i];
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < G::NV; i += 256)
+        partial[(size_t)blockIdx.x * G::NV + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
 template <typename K>
 int resident_blocks(uocr_ctx* ctx, K kernel, int* cache) {
     if (*cache == 0) {
@@ -513,4 +708,43 @@ int uocr_upconv_wgrad_h16(uocr_ctx* ctx, const void* x_low, const void* dy, floa
     UOCR_LAUNCH_CHECK(ctx);
     *nblocks = grid;
     return UOCR_OK;
+}
+
+// dw / db of the 5x5 / stride 2 / padding 2 encoder convs (4 -> 4, 1 -> 4, 1 -> 1)
+bool uocr_conv_wgrad_s2_h16_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d) {
+    return UOCR_DTYPE_BASE(dtype) == UOCR_F16 && ctx->opt_fast && ctx->opt_h16 && d.kh == 5 && d.kw == 5 && d.sh == 2 &&
+           d.sw == 2 && d.ph == 2 && d.pw == 2 && d.oh == (d.h + 1) / 2 && d.ow == (d.w + 1) / 2 &&
+           ((d.cin == 4 && d.cout == 4) || (d.cin == 1 && (d.cout == 4 || d.cout == 1))) &&
+           (long)d.h * d.w * d.cin < (1l << 31);
+}
+
+namespace {
+template <int CI, int CO>
+int launch_s2(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
+              double pad_value, int use_bias, int accumulate) {
+    using G = S2<CI, CO>;
+    static int cache = 0;
+    const int tiles_x = (d.ow + 2 + G::BC - 1) / G::BC, tiles_y = (d.oh + G::BR - 1) / G::BR;   // Q runs over [-1, ow]
+    const long ntiles = (long)d.n * tiles_y * tiles_x;
+    UOCR_REQUIRE(ctx, ntiles < (1l << 31));
+    const long cap = (long)ctx->cu_count * resident_blocks(ctx, wgrad_h16_s2_kernel<CI, CO>, &cache);
+    const int grid = (int)(ntiles < cap ? ntiles : cap);
+    int rc = uocr_need_workspace(ctx, (size_t)grid * G::NV * sizeof(float));
+    if (rc != UOCR_OK) return rc;
+    float* partial = (float*)ctx->workspace;
+    hipLaunchKernelGGL((wgrad_h16_s2_kernel<CI, CO>), dim3(grid), dim3(256), 0, ctx->stream, (const _Float16*)x,
+                       (const _Float16*)dy, partial, d.h, d.w, d.oh, d.ow, tiles_x, tiles_y, (int)ntiles, (float)pad_value);
+    UOCR_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(wgrad_h16_finish, dim3(G::NV), dim3(256), 0, ctx->stream, (const float*)partial, G::NV,
+                       25 * CI * CO, (float*)dw, (float*)db, grid, use_bias, accumulate, (float)uocr_grad_unscale(dtype));
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
+}
+}  // namespace
+
+int uocr_conv_wgrad_s2_h16(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
+                           double pad_value, int use_bias, int accumulate) {
+    if (d.cin == 4) return launch_s2<4, 4>(ctx, dtype, x, dy, dw, db, d, pad_value, use_bias, accumulate);
+    if (d.cout == 4) return launch_s2<1, 4>(ctx, dtype, x, dy, dw, db, d, pad_value, use_bias, accumulate);
+    return launch_s2<1, 1>(ctx, dtype, x, dy, dw, db, d, pad_value, use_bias, accumulate);
 }
