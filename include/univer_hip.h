@@ -78,7 +78,8 @@ void* uocr_ctx_get_stream(uocr_ctx* ctx);
  * rounded to binary16, accumulation stays float32; 0: float32 vector arithmetic on the binary16 data),
  * "t32" (bit mask, default 2: which float32 small-channel convolutions use the float32-MFMA Toeplitz
  * kernels: 1 forward / 2 backward-data / 4 upsample+conv backward-data of the 4-channel layers,
- * 8 / 16 / 32 the same for 1-channel layers).  Results do not depend on any of them beyond float32
+ * 8 / 16 / 32 the same for 1-channel layers, 64 / 128 the float32-MFMA weight gradients of the stride-1 /
+ * stride-2 5x5 convolutions).  Results do not depend on any of them beyond float32
  * summation order ("h16": beyond the binary16 rounding of the weight operands). */
 int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value);
 int uocr_ctx_reserve_workspace(uocr_ctx* ctx, size_t bytes);   /* synchronises; not capturable */

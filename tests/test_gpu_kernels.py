@@ -221,6 +221,36 @@ def test_toeplitz_f32_upconv_dgrad(ch, hl, wl, f32):
           'masked dx')
 
 
+T32W_SHAPES = [
+    # (x shape, cout, stride): the 5x5 / padding 2 convs whose dw has a float32-MFMA form (conv_t32w.hip)
+    ((2, 40, 72, 4), 2, 1), ((1, 70, 133, 4), 2, 1), ((2, 33, 47, 1), 1, 1), ((1, 70, 141, 1), 1, 1),
+    ((2, 40, 72, 4), 4, 2), ((2, 33, 47, 4), 4, 2), ((1, 70, 140, 4), 4, 2),
+    ((2, 40, 72, 1), 4, 2), ((1, 37, 141, 1), 4, 2), ((2, 33, 47, 1), 1, 2), ((1, 70, 140, 1), 1, 2),
+]
+
+
+@pytest.mark.parametrize('case', range(len(T32W_SHAPES)))
+@pytest.mark.parametrize('pad_value,bias', [(0.0, True), (0.75, False)])
+def test_toeplitz_f32_weight_gradients(case, pad_value, bias, f32):
+    """conv_t32w.hip (channel planes + shifted dy operand on float32 MFMAs; off by default, forced through the 't32'
+    option) against the oracle, accumulating into non-zero dw / db."""
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    CP.runtime().set_option('t32', 255)
+    xs, cout, s = T32W_SHAPES[case]
+    rng = np.random.default_rng(900 + case)
+    X = rng.standard_normal(xs)
+    w = rng.standard_normal((5, 5, xs[3], cout)) * 0.2
+    ref_y = O.conv2d_fwd(X, w, np.zeros(cout), s, 2, pad_value, bias)
+    g = rng.standard_normal(ref_y.shape)
+    _, ref_dw, ref_db = O.conv2d_bwd(X, w, g, s, 2, pad_value, bias)
+    Xd, gd = CP.copy(X), CP.copy(g)
+    dw, db = CP.full(w.shape, 0.5), CP.full((cout,), 0.25)
+    ops.conv2d_bwd_weight(Xd, gd, dw, db, (s, s), (2, 2), pad_value, bias, accumulate=True)
+    check(dw, ref_dw + 0.5, 2e-5, 'dw')
+    check(db, ref_db + 0.25, 2e-5, 'db')
+
+
 PAIR_SHAPES = [(3, 37, 83), (2, 16, 32), (1, 1, 1), (2, 5, 200), (1, 70, 33), (4, 64, 96)]
 
 

@@ -72,6 +72,8 @@ int uocr_conv2d_bwd_weight(uocr_ctx* ctx, int dtype, const void* x, const void* 
     UOCR_REQUIRE(ctx, x && dy && dw && db);
     if (uocr_conv_wgrad_h16_eligible(ctx, dtype, d) && uocr_aligned_act(x, dtype) && uocr_aligned_act(dy, dtype))
         return uocr_conv_wgrad_h16(ctx, dtype, x, dy, dw, db, d, pad_value, use_bias, accumulate);
+    if (uocr_conv_wgrad_t32_eligible(ctx, dtype, d) && aligned16(x) && aligned16(dy))
+        return uocr_conv_wgrad_t32(ctx, x, dy, dw, db, d, pad_value, use_bias, accumulate);
     if (uocr_conv_wgrad_s2_h16_eligible(ctx, dtype, d) && uocr_aligned_act(x, dtype) && uocr_aligned_act(dy, dtype))
         return uocr_conv_wgrad_s2_h16(ctx, dtype, x, dy, dw, db, d, pad_value, use_bias, accumulate);
     if (uocr_conv_fast_eligible(ctx, dtype, d, x, dy, dw))

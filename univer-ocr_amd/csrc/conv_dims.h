@@ -47,6 +47,10 @@ bool uocr_conv_t32_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d, int whi
 int uocr_conv_fwd_t32(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
                       double pad_value, int use_bias, int act, double act_alpha);
 int uocr_conv_dgrad_t32(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d, const ActMask& mask);
+// ... their weight gradients (conv_t32w.hip)
+bool uocr_conv_wgrad_t32_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d);
+int uocr_conv_wgrad_t32(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
+                        double pad_value, int use_bias, int accumulate);
 bool uocr_upconv_t32_eligible(uocr_ctx* ctx, int dtype, int cin, int cout);
 int uocr_upconv_dgrad_t32(uocr_ctx* ctx, const void* dy, const void* w, void* dx_low, int n, int hl, int wl, int ch,
                           const void* mask_y, int mask_act, double mask_alpha);

@@ -26,7 +26,8 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->opt_split_min = 3;
     ctx->opt_bm = 0;
     ctx->opt_h16 = 1;
-    ctx->opt_t32 = 2;    // measured: only the 4-channel backward-data beats its vector kernel in the step (conv_t32.hip)
+    ctx->opt_t32 = 2;    // measured: only the 4-channel backward-data beats its vector kernel in the step (conv_t32.hip,
+                         // conv_t32w.hip: bits 64 / 128 = the float32-MFMA weight gradients, 37.0 -> 36.1 k images/s with both)
     ctx->opt_xcd = 1;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
