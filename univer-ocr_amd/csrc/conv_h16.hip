@@ -318,7 +318,11 @@ int launch_h16(uocr_ctx* ctx, const void* in, const void* w, const void* bias, v
     const int tiles_x = (wp + G::BC - 1) / G::BC, tiles_y = (hp + G::BR - 1) / G::BR;
     const long ntiles = (long)n * tiles_y * tiles_x;
     UOCR_REQUIRE(ctx, ntiles < (1l << 31) && (long)h_in * w_in * G::C < (1l << 31));
-    const int grid = (int)(ntiles < (long)ctx->cu_count * resident ? ntiles : (long)ctx->cu_count * resident);
+    // 4 x the resident blocks: when other lanes hold part of the CUs only some blocks of a launch are resident and
+    // the rest start late -- with exactly one block per slot the late ones still own 1/grid of the tiles each (measured
+    // in the three-lane step: 6.66 -> 6.75 k pages/s; alone the kernels do not care)
+    const long cap = (long)ctx->cu_count * resident * 4;
+    const int grid = (int)(ntiles < cap ? ntiles : cap);
     hipLaunchKernelGGL(conv_h16_kernel<G>, dim3(grid), dim3(256), 0, ctx->stream, (const _Float16*)in, (const float*)w,
                        (const float*)bias, (_Float16*)out, (const _Float16*)mask_y, h_in, w_in, h_out, w_out, ph, pw,
                        tiles_x, tiles_y, (int)ntiles, pad, use_bias, act, alpha, mask_act, mask_alpha);
