@@ -273,7 +273,8 @@ int launch_t32(uocr_ctx* ctx, const void* in, const void* w, const void* bias, v
     const int tiles_x = (wp + G::BC - 1) / G::BC, tiles_y = (hp + G::BR - 1) / G::BR;
     const long ntiles = (long)n * tiles_y * tiles_x;
     UOCR_REQUIRE(ctx, ntiles < (1l << 31) && (long)h_in * w_in * G::C < (1l << 31));
-    const int grid = (int)(ntiles < (long)ctx->cu_count * resident ? ntiles : (long)ctx->cu_count * resident);
+    const long cap = (long)ctx->cu_count * resident * 4;      // (4 x: conv_h16.hip, the tail when lanes share the CUs)
+    const int grid = (int)(ntiles < cap ? ntiles : cap);
     hipLaunchKernelGGL(conv_t32_kernel<G>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)in, (const float*)w,
                        (const float*)bias, (float*)out, (const float*)mask_y, h_in, w_in, h_out, w_out, ph, pw, tiles_x,
                        tiles_y, (int)ntiles, pad, use_bias, act, alpha, mask_act, mask_alpha);
