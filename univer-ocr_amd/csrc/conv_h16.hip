@@ -122,27 +122,47 @@ __global__ __launch_bounds__(256) void conv_h16_kernel(const _Float16* __restric
     __shared__ float wl[G::NW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
 
-    // the rows / halves no load ever writes must read as zero (their weights are zero, 0 * garbage is not)
-    for (int i = tid; i < G::IHA * RS / 4; i += 256) reinterpret_cast<uint64_t*>(tile)[i] = 0;
     for (int i = tid; i < G::NW; i += 256) wl[i] = w[i];
     __syncthreads();
 
-    // weight operand: row m = lane % 16 = (dy, co), k-group kq = window row 4*ib + kq, j = half 4q + j of the row
-    f16x4 wa[G::NM];
+    // weight operand: row m = lane % 16 = (dy, co), k-group kq = window row 4*ib + kq, j = half 4q + j of the row.
+    // The table [NM][64 lanes] is the same for the four waves: each wave builds a quarter of it (in the tile
+    // buffer, not yet in use), then every lane picks up its NM entries -- the prologue is what a block pays once,
+    // and the grid is 4 x the resident blocks
+    static_assert(G::NM * 64 * 4 <= G::IHA * RS, "the weight table is built in the tile buffer");
+    f16x4* wtab = reinterpret_cast<f16x4*>(tile);
     {
         const int m = n, dyi = m / G::NCO, co = m % G::NCO;   // co = (phase, channel) in the depth-to-space modes
 #pragma unroll
-        for (int ib = 0; ib < G::IB; ++ib)
-#pragma unroll
-            for (int q = 0; q < G::Q; ++q)
+        for (int i0 = 0; i0 < G::NM; i0 += 4) {
+            const int i = i0 + wv;
+            if (i < G::NM) {
+                const int ib = i / G::Q, q = i - ib * G::Q;
+                f16x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int ty = 4 * ib + kq - dyi * S, hh = 4 * q + j, tx = hh / C, ci = hh % C;
                     const bool live = dyi < G::DY && ty >= 0 && ty < G::KH && tx < G::KW;
-                    wa[ib * G::Q + q][j] =
-                        live ? (_Float16)weight_of<G>(wl, min(max(ty, 0), G::KH - 1), min(tx, G::KW - 1), ci, co)
-                             : (_Float16)0.f;
+                    v[j] = live ? (_Float16)weight_of<G>(wl, min(max(ty, 0), G::KH - 1), min(tx, G::KW - 1), ci, co)
+                                : (_Float16)0.f;
                 }
+                wtab[i * 64 + lane] = v;
+            }
+        }
+    }
+    __syncthreads();
+    f16x4 wa[G::NM];
+#pragma unroll
+    for (int i = 0; i < G::NM; ++i) wa[i] = wtab[i * 64 + lane];
+    __syncthreads();
+    // the rows / halves no load ever writes must read as zero (their weights are zero, 0 * garbage is not): the
+    // columns behind the staged units of every row, and the rows behind the staged ones
+    {
+        constexpr int PADC = (RS - G::UW * 8) / 4;                      // 8-byte words per row behind the units
+        for (int i = tid; i < G::IHA * PADC; i += 256)
+            reinterpret_cast<uint64_t*>(tile + (i / (PADC > 0 ? PADC : 1)) * RS + G::UW * 8)[i % (PADC > 0 ? PADC : 1)] = 0;
+        for (int i = tid; i < (G::IHA - G::IH) * (G::UW * 2); i += 256)
+            reinterpret_cast<uint64_t*>(tile + (G::IH + i / (G::UW * 2)) * RS)[i % (G::UW * 2)] = 0;
     }
     float bias4[4];
 #pragma unroll
