@@ -106,6 +106,11 @@ CONVS = [
     ((2, 33, 47, 1), (5, 5), 1, (2, 2), (2, 2), 0.5),     # Paragraph down, odd sizes, padding value
     ((1, 70, 141, 1), (5, 5), 1, (1, 1), (2, 2), 0.25),   # Paragraph end, several tiles, odd width
     ((1, 37, 141, 1), (5, 5), 4, (2, 2), (2, 2), 0.0),    # Line down_1, odd width
+    ((1, 3, 5, 4), (5, 5), 2, (1, 1), (2, 2), 0.5),       # images smaller than a tile / than a staging unit
+    ((2, 2, 3, 4), (5, 5), 4, (2, 2), (2, 2), 0.0),
+    ((2, 1, 1, 1), (5, 5), 1, (1, 1), (2, 2), 0.25),
+    ((1, 2, 7, 1), (5, 5), 4, (2, 2), (2, 2), 0.0),
+    ((1, 4, 3, 1), (5, 5), 1, (2, 2), (2, 2), 0.0),
     ((2, 21, 35, 1), (3, 3), 16, (1, 1), (1, 1), 0.5),    # Monochrome conv_1 unfused, padding value
     ((2, 21, 35, 16), (3, 3), 1, (1, 1), (1, 1), 0.0),    # Monochrome conv_2 unfused
     ((3, 11, 13, 6), (4, 4), 7, (2, 1), (1, 2), 0.25),    # generic kernels
@@ -152,7 +157,7 @@ def test_conv_kernels_f16(case, f16):
     assert rel_linf(CP.asnumpy(db), ref_db / 16 + 0.25) <= TOL_EXACT
 
 
-@pytest.mark.parametrize('ch,hl,wl', [(4, 24, 40), (1, 24, 40), (4, 17, 33), (1, 19, 21), (4, 40, 70)])
+@pytest.mark.parametrize('ch,hl,wl', [(4, 24, 40), (1, 24, 40), (4, 17, 33), (1, 19, 21), (4, 40, 70), (4, 2, 3), (4, 1, 1)])
 def test_upconv2x_f16(ch, hl, wl, f16):
     """Upsample2D(2) + conv5x5 on the low-res tensor (uocr_upconv2x_*) against the two layers of the oracle."""
     from univer_ocr_amd.nn import ops

@@ -172,6 +172,7 @@ TOEPLITZ_SHAPES = [
     ((2, 40, 72, 4), 2), ((2, 33, 47, 4), 2), ((1, 70, 130, 4), 2),      # Line end: one tile, ragged, several tiles
     ((2, 37, 66, 4), 4),                                                 # 4 -> 4
     ((2, 40, 72, 1), 1), ((1, 70, 133, 1), 1),                           # Paragraph end
+    ((1, 3, 5, 4), 2), ((2, 1, 1, 1), 1),                                # smaller than a tile / a staging unit
 ]
 
 
@@ -200,7 +201,7 @@ def test_toeplitz_f32_conv_kernels(case, pad_value, bias, f32):
           'masked dx')
 
 
-@pytest.mark.parametrize('ch,hl,wl', [(4, 24, 40), (4, 17, 33), (1, 24, 40), (1, 19, 21), (4, 40, 70)])
+@pytest.mark.parametrize('ch,hl,wl', [(4, 24, 40), (4, 17, 33), (1, 24, 40), (1, 19, 21), (4, 40, 70), (4, 2, 3), (1, 1, 1)])
 def test_toeplitz_f32_upconv_dgrad(ch, hl, wl, f32):
     """Upsample2D(2) + conv5x5 backward-data as a stride-2 6x6 window over dy (conv_t32.hip) against the two layers
     of the oracle."""
@@ -226,6 +227,7 @@ T32W_SHAPES = [
     ((2, 40, 72, 4), 2, 1), ((1, 70, 133, 4), 2, 1), ((2, 33, 47, 1), 1, 1), ((1, 70, 141, 1), 1, 1),
     ((2, 40, 72, 4), 4, 2), ((2, 33, 47, 4), 4, 2), ((1, 70, 140, 4), 4, 2),
     ((2, 40, 72, 1), 4, 2), ((1, 37, 141, 1), 4, 2), ((2, 33, 47, 1), 1, 2), ((1, 70, 140, 1), 1, 2),
+    ((1, 3, 5, 4), 2, 1), ((2, 1, 1, 1), 1, 1), ((2, 2, 3, 4), 4, 2), ((1, 2, 7, 1), 4, 2), ((1, 4, 3, 1), 1, 2),   # tiny
 ]
 
 
