@@ -70,7 +70,7 @@ for _ in range(reps):
     start = torch.cuda.Event(enable_timing=True)
     start.record(main)
     mids, ends = {}, {}
-    for comp in trainer.model_system.components:
+    for comp in trainer._lane_order():               # the enqueue order of PageTrainer.step
         with rt.lane(trainer.lanes[comp.name]) as stream:
             stream.wait_event(start)
             trainer._captured[comp.name]['begin'].replay()
