@@ -249,6 +249,20 @@ __global__ __launch_bounds__(256) void conv_h16_kernel(const _Float16* __restric
 #pragma unroll
         for (int s = 0; s < G::RPW; ++s) {
             const int rb = (wv * G::RPW + s) * G::DY;    // first output row of the band, relative to the tile
+            // backward-data (4 channels, plain store): the mask of the band's four chains is requested before their
+            // MFMAs (the epilogue otherwise waits out one global load per chain)
+            constexpr bool PREMASK = COUT == 4 && G::U == 1;
+            uocr_h4 mraw[PREMASK ? 4 : 1];
+            if constexpr (PREMASK) {
+                if (mask_act != UOCR_ACT_NONE) {
+                    const int row = min(r0 + rb + kq, h_out - 1);
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg) {
+                        const int col = min(c_begin + cg * 16 + n, w_out - 1);
+                        mraw[cg] = *reinterpret_cast<const uocr_h4*>(mask_y + out_img + ((size_t)row * w_out + col) * 4);
+                    }
+                }
+            }
 #pragma unroll
             for (int cg = 0; cg < 4; ++cg) {
                 const _Float16* base = tile + (rb * S + kq) * RS + (cg * 16 + n) * S * G::XS;
@@ -296,11 +310,11 @@ __global__ __launch_bounds__(256) void conv_h16_kernel(const _Float16* __restric
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = fast_act(acc[i] + bias4[i], act, alpha);
                     if (mask_act != UOCR_ACT_NONE) {
-                        const float4 my = ld4(mask_y + off);
-                        v[0] *= act_grad_from_output<float>(my.x, mask_act, mask_alpha);
-                        v[1] *= act_grad_from_output<float>(my.y, mask_act, mask_alpha);
-                        v[2] *= act_grad_from_output<float>(my.z, mask_act, mask_alpha);
-                        v[3] *= act_grad_from_output<float>(my.w, mask_act, mask_alpha);
+                        const uocr_h4 my = mraw[cg];
+                        v[0] *= act_grad_from_output<float>((float)my.x, mask_act, mask_alpha);
+                        v[1] *= act_grad_from_output<float>((float)my.y, mask_act, mask_alpha);
+                        v[2] *= act_grad_from_output<float>((float)my.z, mask_act, mask_alpha);
+                        v[3] *= act_grad_from_output<float>((float)my.w, mask_act, mask_alpha);
                     }
                     st4(out + off, make_float4(v[0], v[1], v[2], v[3]));
                 } else {                                 // COUT == 2: rows 2kq, 2kq + 1, both channels each
