@@ -82,6 +82,15 @@ class _Rccl:
         self.lane = rt.add_lane(workspace_mb=1)
         with rt.lane(self.lane):
             rt.call('uocr_dp_init', self.rank, self.world, C.c_char_p(raw))
+            # known-answer check of the fresh communicator: a SUM of ones over the ranks must read `world` everywhere
+            # (a mis-bound library or a half-initialised ring otherwise shows up as silently wrong gradients)
+            probe = CP.full((8,), 1.0, np.float32)
+            rt.call('uocr_dp_allreduce_sum', probe.ptr, probe.size, probe.code & 0xff)
+            rt.call('uocr_stream_sync')
+            got = CP.asnumpy(probe)
+            if not np.all(got == float(self.world)):
+                raise hiplib.HipError(f'RCCL all-reduce self-test failed on rank {self.rank}: sum of ones over '
+                                      f'{self.world} ranks read {got.tolist()}')
         self._events = []
 
     def event(self):
