@@ -50,14 +50,25 @@ __device__ __forceinline__ float out_act(float v, int act) {
 struct Stage {
     size_t off[NPF];
     bool in[NPF];
-    __device__ __forceinline__ void locate(int tid, int ys, int xs0, int h, int wd) {
+    // what does not change while a block walks down its column strip: tile row, clamped image column, column in image
+    int row[NPF], col[NPF];
+    bool cin[NPF];
+    __device__ __forceinline__ void prepare(int tid, int xs0, int wd) {
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             const int i = tid + k * 256;
-            const int r = i / XW, c = i - r * XW;
-            const int gy = ys + r, gx = xs0 + c;
-            in[k] = i < XH * XW && gy >= 0 && gy < h && gx >= 0 && gx < wd;
-            off[k] = (size_t)min(max(gy, 0), h - 1) * wd + min(max(gx, 0), wd - 1);
+            const int r = i / XW, c = i - r * XW, gx = xs0 + c;
+            row[k] = r;
+            col[k] = min(max(gx, 0), wd - 1);
+            cin[k] = i < XH * XW && gx >= 0 && gx < wd;
+        }
+    }
+    __device__ __forceinline__ void locate(int ys, int h, int wd) {       // tile origin row ys
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int gy = ys + row[k];
+            in[k] = cin[k] && (unsigned)gy < (unsigned)h;
+            off[k] = (size_t)min(max(gy, 0), h - 1) * wd + col[k];
         }
     }
 };
@@ -99,7 +110,8 @@ __global__ __launch_bounds__(256) void conv_pair_fwd_kernel(const TA* __restrict
 
     Stage st;
     float px[NPF];
-    st.locate(tid, row_begin - 2, x0 - 2, h, wd);
+    st.prepare(tid, x0 - 2, wd);
+    st.locate(row_begin - 2, h, wd);
 #pragma unroll
     for (int k = 0; k < NPF; ++k) px[k] = ld1(xb + st.off[k]);
     for (int y0 = row_begin; y0 < row_end; y0 += TH) {
@@ -109,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_pair_fwd_kernel(const TA* __restrict
             if (tid + k * 256 < XH * XW) xs[tid + k * 256] = st.in[k] ? px[k] : pad1;
         __syncthreads();
         if (y0 + TH < row_end) {                         // next tile: loads overlap this tile's math
-            st.locate(tid, y0 + TH - 2, x0 - 2, h, wd);
+            st.locate(y0 + TH - 2, h, wd);
 #pragma unroll
             for (int k = 0; k < NPF; ++k) px[k] = ld1(xb + st.off[k]);
         }
@@ -295,11 +307,12 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_kernel(const TA* __restrict
     float db1acc = 0.f, db2acc = 0.f;
 
     Stage st;
+    st.prepare(tid, x0 - OFF - 1, wd);
     // the loads of the next tile are only issued here; their values are first touched at the LDS write after
     // the MFMAs (the sigmoid derivative included), so nothing in between waits for global memory
     float px[NPF], pg[NPF], py[SIG ? NPF : 1];
     auto prefetch = [&](int y0) {
-        st.locate(tid, y0 - OFF - 1, x0 - OFF - 1, h, wd);
+        st.locate(y0 - OFF - 1, h, wd);
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             px[k] = ld1(xb + st.off[k]);
@@ -431,17 +444,29 @@ __device__ __forceinline__ f16x4 window(const uint32_t* p) {      // halves c ..
 struct StageH {
     int off[NPF], off2[NPF];
     uint32_t mask[NPF];
-    __device__ __forceinline__ void locate(int tid, int ys, int xs0, int h, int wd) {
+    // what does not change while a block walks down its column strip: the tile row / column of the thread's
+    // elements, their clamped image columns and the in-image bits of the two columns of a pair word
+    int row[NPF], col0[NPF], col1[NPF];
+    uint32_t cmask[NPF];
+    __device__ __forceinline__ void prepare(int tid, int xs0, int wd) {
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             const int i = tid + k * 256;
-            const int r = i / XW, c = i - r * XW;
-            const int gy = ys + r, gx = xs0 + c;
-            const bool row_ok = i < XH * XW && gy >= 0 && gy < h;
+            const int r = i / XW, c = i - r * XW, gx = xs0 + c;
+            row[k] = r;
+            col0[k] = min(max(gx, 0), wd - 1);
+            col1[k] = min(max(gx + 1, 0), wd - 1);
+            cmask[k] = i < XH * XW ? ((gx >= 0 && gx < wd ? 0xFFFFu : 0u) | (gx + 1 >= 0 && gx + 1 < wd ? 0xFFFF0000u : 0u)) : 0u;
+        }
+    }
+    __device__ __forceinline__ void locate(int ys, int h, int wd) {       // tile origin row ys
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int gy = ys + row[k];
             const int base = min(max(gy, 0), h - 1) * wd;
-            off[k] = base + min(max(gx, 0), wd - 1);
-            off2[k] = base + min(max(gx + 1, 0), wd - 1);
-            mask[k] = (row_ok && gx >= 0 && gx < wd ? 0xFFFFu : 0u) | (row_ok && gx + 1 >= 0 && gx + 1 < wd ? 0xFFFF0000u : 0u);
+            off[k] = base + col0[k];
+            off2[k] = base + col1[k];
+            mask[k] = (unsigned)gy < (unsigned)h ? cmask[k] : 0u;
         }
     }
 };
@@ -481,7 +506,8 @@ __global__ __launch_bounds__(256) void conv_pair_fwd_h_kernel(const _Float16* __
 
     StageH st;
     uint32_t px[NPF];
-    st.locate(tid, row_begin - 2, x0 - 2, h, wd);
+    st.prepare(tid, x0 - 2, wd);
+    st.locate(row_begin - 2, h, wd);
 #pragma unroll
     for (int k = 0; k < NPF; ++k) px[k] = load_pair(xb, st.off[k], st.off2[k]);
     for (int y0 = row_begin; y0 < row_end; y0 += TH) {
@@ -491,7 +517,7 @@ __global__ __launch_bounds__(256) void conv_pair_fwd_h_kernel(const _Float16* __
             if (tid + k * 256 < XH * XW) xs2[tid + k * 256] = select_bits(st.mask[k], px[k], padword);
         __syncthreads();
         if (y0 + TH < row_end) {                         // next tile: loads overlap this tile's math
-            st.locate(tid, y0 + TH - 2, x0 - 2, h, wd);
+            st.locate(y0 + TH - 2, h, wd);
 #pragma unroll
             for (int k = 0; k < NPF; ++k) px[k] = load_pair(xb, st.off[k], st.off2[k]);
         }
@@ -580,9 +606,10 @@ __global__ __launch_bounds__(256) void conv_pair_bwd_h_kernel(const _Float16* __
     float db1acc = 0.f, db2acc = 0.f;
 
     StageH st;
+    st.prepare(tid, x0 - 1, wd);
     uint32_t px[NPF], pg[NPF], py[SIG ? NPF : 1];
     auto prefetch = [&](int y0) {
-        st.locate(tid, y0 - 1, x0 - 1, h, wd);
+        st.locate(y0 - 1, h, wd);
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             px[k] = load_pair(xb, st.off[k], st.off2[k]);
