@@ -154,7 +154,6 @@ __global__ __launch_bounds__(256) void wgrad_h16_e42_kernel(const _Float16* __re
         }
         __syncthreads();
         // ---- wave wv: rows wv, wv + 4, ...; 4 groups of 16 positions per row
-#pragma unroll 2
         for (int r = wv; r < BR; r += 4) {
 #pragma unroll
             for (int c0 = 0; c0 < BC; c0 += 16) {
@@ -264,7 +263,6 @@ __global__ __launch_bounds__(256) void wgrad_h16_e11_kernel(const _Float16* __re
             }
         }
         __syncthreads();
-#pragma unroll 2
         for (int r = wv; r < BR; r += 4) {
 #pragma unroll
             for (int c0 = 0; c0 < BC; c0 += 16) {
@@ -420,7 +418,6 @@ __global__ __launch_bounds__(256) void wgrad_h16_up_kernel(const _Float16* __res
         }
         __syncthreads();
         // ---- wave wv: rows wv, wv + 4, ...; xl tile row of position row r and source offset my is r + my
-#pragma unroll 2
         for (int r = wv; r < BR; r += 4) {
 #pragma unroll
             for (int c0 = 0; c0 < BC; c0 += 16) {

@@ -265,7 +265,6 @@ __global__ __launch_bounds__(256) void wgrad_t32_e_kernel(const float* __restric
                 *reinterpret_cast<float4*>(row + co * DP) = make_float4(v[co], v[CO + co], v[2 * CO + co], v[3 * CO + co]);
         }
         __syncthreads();
-#pragma unroll 2
         for (int r = wv; r < BR; r += 4) {
 #pragma unroll
             for (int c0 = 0; c0 < BC; c0 += 16) {

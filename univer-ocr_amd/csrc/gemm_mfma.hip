@@ -589,8 +589,6 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BLoader B, Ep
         const int tn = next_tile(t + 1);
         const bool more = tn < t_end;
         if (more) load_tile(tn);
-        const float* as = As[buf];
-        const float* bs = Bs[buf];
         if (band_live) {
             // fragments of depth step k+2 are read from LDS while the MFMAs of step k run
             // one base address per operand and tile (buffer + lane part), made opaque so that the compiler keeps it in
