@@ -271,11 +271,42 @@ __global__ __launch_bounds__(256) void conv_h16_kernel(const _Float16* __restric
                 for (int ib = 0; ib < G::IB; ++ib)
 #pragma unroll
                     for (int q = 0; q < G::Q; ++q)
-                        acc = mfma16(wa[ib * G::Q + q], read_chunk<G>(base + ib * 4 * RS + G::QS * q), acc);
+                    {
+                        // one output channel, plain store: operands swapped, D[column, row shift] -- a lane then holds 4
+                        // consecutive columns of one row (an 8-byte store) instead of 4 rows of one column (2-byte stores)
+                        const f16x4 chunk = read_chunk<G>(base + ib * 4 * RS + G::QS * q);
+                        acc = (COUT == 1 && G::U == 1) ? mfma16(chunk, wa[ib * G::Q + q], acc) : mfma16(wa[ib * G::Q + q], chunk, acc);
+                    }
                 // lane (column n, kq): rows m = 4kq + i of the result = (dy, co)
                 const int col = c_begin + cg * 16 + n;
-                if (G::U == 1 && col >= w_out) continue;
-                if constexpr (COUT == 1) {                // rows 4kq + i, or (depth to space) row kq, phase i
+                if (G::U == 1 && COUT != 1 && col >= w_out) continue;
+                if constexpr (COUT == 1 && G::U == 1) {   // D[column 4kq + i, row shift n]: 4 columns of row rb + n
+                    const int row = r0 + rb + n, col4 = c_begin + cg * 16 + 4 * kq;
+                    if (row >= h_out || n >= G::DY || col4 >= w_out) continue;
+                    const size_t off = out_img + (size_t)row * w_out + col4;
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = fast_act(acc[i] + bias4[0], act, alpha);
+                    if (col4 + 4 <= w_out && (off & 3) == 0) {
+                        if (mask_act != UOCR_ACT_NONE) {
+                            const float4 my = ld4(mask_y + off);
+                            v[0] *= act_grad_from_output<float>(my.x, mask_act, mask_alpha);
+                            v[1] *= act_grad_from_output<float>(my.y, mask_act, mask_alpha);
+                            v[2] *= act_grad_from_output<float>(my.z, mask_act, mask_alpha);
+                            v[3] *= act_grad_from_output<float>(my.w, mask_act, mask_alpha);
+                        }
+                        st4(out + off, make_float4(v[0], v[1], v[2], v[3]));
+                    } else {                             // image edge, or a row that does not start on 8 bytes (odd width)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (col4 + i < w_out) {
+                                float vi = v[i];
+                                if (mask_act != UOCR_ACT_NONE)
+                                    vi *= act_grad_from_output<float>(ld1(mask_y + off + i), mask_act, mask_alpha);
+                                st1(out + off + i, vi);
+                            }
+                    }
+                } else if constexpr (COUT == 1) {         // (depth to space) row kq, phase i
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int dyi = G::U == 2 ? kq : 4 * kq + i;
