@@ -41,7 +41,7 @@ bool uocr_conv_wgrad_s2_h16_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d
 int uocr_conv_wgrad_s2_h16(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
                            double pad_value, int use_bias, int accumulate);
 int uocr_upconv_wgrad_h16(uocr_ctx* ctx, const void* x_low, const void* dy, float* partial, size_t partial_floats,
-                          int n, int hl, int wl, int* nblocks);
+                          int n, int hl, int wl, int ch, int* nblocks);
 // float32 vertical-Toeplitz MFMA kernels of the small-channel convs (conv_t32.hip); which: 0 fwd, 1 dgrad
 bool uocr_conv_t32_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d, int which);
 int uocr_conv_fwd_t32(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,

@@ -452,6 +452,124 @@ __global__ __launch_bounds__(256) void wgrad_h16_up_kernel(const _Float16* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// (2b) upsample2x + 5x5 1 -> 1 (the Paragraph decoder blocks): dWeff[(my, mx)][phase] = sum_pos xl[pos + m - 1] *
+// dy[2 pos + phase].  One xl pair-word plane; dy as four PHASE planes (row parity from the row, column parity
+// de-interleaved while staging); per source row my one MFMA with M = mx (3 rows + the ones row), N = phase.
+// Partial rows in the layout of conv_up.hip's up1_wgrad_finish: [m * 4 + phase] (36), then db.
+// ------------------------------------------------------------------------------------------------------------
+namespace up1 {
+constexpr int BR = 16, BC = 64;                  // low-res positions per tile
+constexpr int XR = BR + 2, XRS = 68;             // xl pair words: rows, row stride
+constexpr int GRS = 72;                          // dy phase plane row stride (halves)
+constexpr int GP = BR * GRS + 8;                 // phase plane stride (halves)
+constexpr int NV = 37;
+}  // namespace up1
+
+__global__ __launch_bounds__(256) void wgrad_h16_up1_kernel(const _Float16* __restrict__ xl,
+                                                            const _Float16* __restrict__ dy,
+                                                            float* __restrict__ partial, int hl, int wl, int tiles_x,
+                                                            int tiles_y, int ntiles) {
+    using namespace up1;
+    __shared__ __attribute__((aligned(16))) uint32_t xs[XR * XRS + 4];    // [row][pair word] (+ the ones)
+    __shared__ __attribute__((aligned(16))) _Float16 gs[4 * GP];          // [(py, px)][row][col]
+    __shared__ float red[4][NV];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
+    if (tid < 4) xs[XR * XRS + tid] = ONES;
+    // A rows m = mx (0..2); row 3 of the my = 0 tile is all ones -> db.  B column n = phase (0..3)
+    const int a0 = 4 * kq + min(n, 2);
+    const bool ones_row = n == 3;
+    const int b0 = min(n, 3) * GP + 4 * kq;
+    f32x4 acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int H = 2 * hl, W = 2 * wl;
+    const int xu = tid % 17, xr0 = tid / 17;             // xl unit = 4 pixels + the next one, 17 units per row
+    const int gu = tid & 15, gr0 = tid >> 4;             // dy unit = 8 high-res pixels (16 bytes) of one row
+
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int strip = t % tiles_x, trow = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+        const int C0 = strip * BC, R0 = trow * BR;
+        const _Float16* xb = xl + (size_t)img * hl * wl;
+        const _Float16* gb = dy + (size_t)img * H * W;
+        __syncthreads();
+        {   // ---- xl: (R0 - 1 + r, C0 - 1 + 4 xu + p), p = 0..4 -> pair words, zero outside
+            const int gx0 = C0 - 1 + 4 * xu;
+            const bool all_in = gx0 >= 0 && gx0 + 4 < wl, any_in = gx0 + 4 >= 0 && gx0 < wl;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int r = xr0 + 15 * k, gy = R0 - 1 + r;
+                if (r >= XR || xr0 >= 15) continue;
+                const bool row_ok = (unsigned)gy < (unsigned)hl;
+                const _Float16* src = xb + (size_t)min(max(gy, 0), hl - 1) * wl;
+                uint32_t g[5] = {0u, 0u, 0u, 0u, 0u};
+                if (row_ok && all_in) {
+                    const uint2 q = *reinterpret_cast<const uint2*>(src + gx0);
+                    g[0] = q.x & 0xFFFFu, g[1] = q.x >> 16, g[2] = q.y & 0xFFFFu, g[3] = q.y >> 16;
+                    g[4] = __builtin_bit_cast(unsigned short, src[gx0 + 4]);
+                } else if (row_ok && any_in) {
+#pragma unroll
+                    for (int p = 0; p < 5; ++p)
+                        if ((unsigned)(gx0 + p) < (unsigned)wl) g[p] = __builtin_bit_cast(unsigned short, src[gx0 + p]);
+                }
+                *reinterpret_cast<uint4*>(xs + r * XRS + 4 * xu) =
+                    uint4{g[0] | (g[1] << 16), g[1] | (g[2] << 16), g[2] | (g[3] << 16), g[3] | (g[4] << 16)};
+            }
+        }
+        {   // ---- dy: high-res row 2 (R0 + r) + py, pixels 2 C0 + 8 gu + p (p = 0..7) -> planes (py, px) at column 4 gu + p / 2
+            const int gx0 = 2 * C0 + 8 * gu;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int rr = gr0 + 16 * k, r = rr >> 1, py = rr & 1, gy = 2 * (R0 + r) + py;
+                const _Float16* src = gb + (size_t)min(gy, H - 1) * W;
+                uint32_t d[4] = {0u, 0u, 0u, 0u};
+                if (gy < H) {
+                    if (gx0 + 8 <= W) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(src + gx0);
+                        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+                    } else if (gx0 < W) {
+                        unsigned short* dh = reinterpret_cast<unsigned short*>(d);
+#pragma unroll
+                        for (int p = 0; p < 8; ++p)
+                            if (gx0 + p < W) dh[p] = __builtin_bit_cast(unsigned short, src[gx0 + p]);
+                    }
+                }
+                _Float16* row = gs + (py * 2) * GP + r * GRS + 4 * gu;
+                *reinterpret_cast<u32x2*>(row) = u32x2{lo_pair(d[0], d[1]), lo_pair(d[2], d[3])};           // px = 0
+                *reinterpret_cast<u32x2*>(row + GP) = u32x2{hi_pair(d[0], d[1]), hi_pair(d[2], d[3])};      // px = 1
+            }
+        }
+        __syncthreads();
+        for (int r = wv; r < BR; r += 4) {
+#pragma unroll
+            for (int c0 = 0; c0 < BC; c0 += 16) {
+                const f16x4 b = read8(gs + b0 + r * GRS + c0);
+                const f16x4 x0 = read_words(xs + (ones_row ? XR * XRS : a0 + r * XRS + c0));
+                const f16x4 x1 = read_words(xs + a0 + (r + 1) * XRS + c0);
+                const f16x4 x2 = read_words(xs + a0 + (r + 2) * XRS + c0);
+                acc[0] = mfma16(x0, b, acc[0]);
+                acc[1] = mfma16(x1, b, acc[1]);
+                acc[2] = mfma16(x2, b, acc[2]);
+            }
+        }
+    }
+    // ---- lane (n = phase, kq = 0) holds rows m = i: dWeff[(my * 3 + mx = i) * 4 + phase]; row 3 of my = 0: db per phase
+    for (int i = tid; i < 4 * NV; i += 256) (&red[0][0])[i] = 0.f;
+    __syncthreads();
+    float dbv = (kq == 0 && n < 4) ? acc[0][3] : 0.f;
+    dbv += __shfl_xor(dbv, 1, 64);
+    dbv += __shfl_xor(dbv, 2, 64);
+    if (kq == 0 && n < 4) {
+#pragma unroll
+        for (int my = 0; my < 3; ++my)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) red[wv][(my * 3 + i) * 4 + n] = acc[my][i];
+        if (n == 0) red[wv][36] = dbv;
+    }
+    __syncthreads();
+    if (tid < NV) partial[(size_t)blockIdx.x * NV + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // (3) 5x5 / stride 2 / padding 2 (the encoder convs: 4 -> 4, 1 -> 4, 1 -> 1)
 //     dw[ty][tx][ci][co] = sum_{Y, X} xpad[2Y + ty - 2][2X + tx - 2][ci] * dy[Y][X][co]
 // The stride makes the x operand every second column: x is staged as EVEN / ODD column planes per channel
@@ -690,9 +808,24 @@ int uocr_conv_wgrad_h16(uocr_ctx* ctx, int dtype, const void* x, const void* dy,
     return UOCR_OK;
 }
 
-// partial rows in the layout of conv_up.hip's upconv_wgrad_finish: [(m * 4 + ci) * 16 + phase * 4 + co], then db[4]
+// partial rows in the layout of conv_up.hip's finish kernels: 4 channels [(m * 4 + ci) * 16 + phase * 4 + co], then
+// db[4] (upconv_wgrad_finish); 1 channel [m * 4 + phase], then db (up1_wgrad_finish)
 int uocr_upconv_wgrad_h16(uocr_ctx* ctx, const void* x_low, const void* dy, float* partial, size_t partial_floats,
-                          int n, int hl, int wl, int* nblocks) {
+                          int n, int hl, int wl, int ch, int* nblocks) {
+    if (ch == 1) {
+        static int cache1 = 0;
+        const int tiles_x = (wl + up1::BC - 1) / up1::BC, tiles_y = (hl + up1::BR - 1) / up1::BR;
+        const long ntiles = (long)n * tiles_y * tiles_x;
+        UOCR_REQUIRE(ctx, ntiles < (1l << 31) && (long)hl * wl * 4 < (1l << 31));
+        const long cap = (long)ctx->cu_count * resident_blocks(ctx, wgrad_h16_up1_kernel, &cache1);
+        const int grid = (int)(ntiles < cap ? ntiles : cap);
+        UOCR_REQUIRE(ctx, (size_t)grid * up1::NV <= partial_floats);
+        hipLaunchKernelGGL(wgrad_h16_up1_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const _Float16*)x_low,
+                           (const _Float16*)dy, partial, hl, wl, tiles_x, tiles_y, (int)ntiles);
+        UOCR_LAUNCH_CHECK(ctx);
+        *nblocks = grid;
+        return UOCR_OK;
+    }
     static int cache = 0;
     const int tiles_x = (wl + up::BC - 1) / up::BC, tiles_y = (hl + up::BR - 1) / up::BR;
     const long ntiles = (long)n * tiles_y * tiles_x;

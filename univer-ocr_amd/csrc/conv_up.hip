@@ -592,16 +592,21 @@ extern "C" int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_
     int rc = check_up(ctx, dtype, n, hl, wl, cin, cout, kh, kw, ph, pw);
     if (rc != UOCR_OK) return rc;
     const float unscale = (float)uocr_grad_unscale(dtype);
-    if (uocr_upconv_h16_eligible(ctx, dtype, cin, cout) && uocr_aligned_act(x_low, dtype) && uocr_aligned_act(dy, dtype)) {
-        // binary16 MFMAs over channel planes (conv_h16w.hip), same partial layout, same finish kernel
+    if (UOCR_DTYPE_BASE(dtype) == UOCR_F16 && ctx->opt_fast && ctx->opt_h16 && uocr_aligned_act(x_low, dtype) &&
+        uocr_aligned_act(dy, dtype)) {
+        // binary16 MFMAs over channel / phase planes (conv_h16w.hip), same partial layouts, same finish kernels
         const size_t floats = (size_t)ctx->cu_count * 8 * (36 * 16 + 4);
         rc = uocr_need_workspace(ctx, floats * sizeof(float));
         if (rc != UOCR_OK) return rc;
         int nblocks = 0;
-        rc = uocr_upconv_wgrad_h16(ctx, x_low, dy, (float*)ctx->workspace, floats, n, hl, wl, &nblocks);
+        rc = uocr_upconv_wgrad_h16(ctx, x_low, dy, (float*)ctx->workspace, floats, n, hl, wl, cin, &nblocks);
         if (rc != UOCR_OK) return rc;
-        hipLaunchKernelGGL(upconv_wgrad_finish, dim3(404), dim3(256), 0, ctx->stream, (const float*)ctx->workspace,
-                           (float*)dw, (float*)db, nblocks, use_bias, accumulate, unscale);
+        if (cin == 1)
+            hipLaunchKernelGGL(up1_wgrad_finish, dim3(26), dim3(256), 0, ctx->stream, (const float*)ctx->workspace,
+                               (float*)dw, (float*)db, nblocks, use_bias, accumulate, unscale);
+        else
+            hipLaunchKernelGGL(upconv_wgrad_finish, dim3(404), dim3(256), 0, ctx->stream, (const float*)ctx->workspace,
+                               (float*)dw, (float*)db, nblocks, use_bias, accumulate, unscale);
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
