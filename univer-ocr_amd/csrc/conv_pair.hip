@@ -25,6 +25,7 @@
 // (MFMA accumulators in VGPRs: no v_accvgpr copies between the MFMAs and the VALU code that consumes them)
 #include <type_traits>
 
+#include "conv_pair.h"
 #include "uocr_common.h"
 
 namespace {
@@ -823,6 +824,11 @@ extern "C" int uocr_conv_pair_bwd(uocr_ctx* ctx, int dtype, const void* x, const
     UOCR_REQUIRE(ctx, x && y && dy && w1 && b1 && w2 && dw1 && db1 && dw2 && db2);
     int rc = check_pair(ctx, dtype, n, h, w, cmid, act2);
     if (rc != UOCR_OK) return rc;
+    if (UOCR_DTYPE_BASE(dtype) == UOCR_F32 && ctx->opt_pair)
+        return uocr_pair_strip_bwd_f32(ctx, (const float*)x, (const float*)y, (const float*)dy, (const float*)w1,
+                                       (const float*)b1, (const float*)w2, (float*)dw1, (float*)db1, (float*)dw2,
+                                       (float*)db2, (float*)dx, n, h, w, (float)pad_value1, use_bias1, use_bias2,
+                                       (float)alpha1, act2 == UOCR_ACT_SIGMOID, accumulate, 1.f);
     const int strips = (w + RW - 1) / RW, tiles_y = (h + RH - 1) / RH;
     const int rows_per_block = pair_rows_per_block(strips, h, n, RH, dx ? 1024u : 2048u);
     const int bands = (h + rows_per_block - 1) / rows_per_block;

@@ -29,6 +29,8 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->opt_t32 = 2;    // measured: only the 4-channel backward-data beats its vector kernel in the step (conv_t32.hip,
                          // conv_t32w.hip: bits 64 / 128 = the float32-MFMA weight gradients, 37.0 -> 36.1 k images/s with both)
     ctx->opt_xcd = 1;
+    ctx->opt_pair = 1;
+    ctx->opt_pair_band = 0;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return UOCR_ERR_HIP;
@@ -81,6 +83,8 @@ int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "xcd_remap")) ctx->opt_xcd = value;
     else if (!strcmp(key, "h16")) ctx->opt_h16 = value;
     else if (!strcmp(key, "t32")) ctx->opt_t32 = value;
+    else if (!strcmp(key, "pair")) ctx->opt_pair = value;
+    else if (!strcmp(key, "pair_band")) ctx->opt_pair_band = value;
     else UOCR_FAIL(ctx, UOCR_ERR_ARG, "unknown option '%s'", key);
     return UOCR_OK;
 }
