@@ -22,7 +22,7 @@
 // by one row of d_a1 on each side (recomputed, 10 of 18 MFMAs), column blocks by one column on each side.
 // Per group of 16 positions: 18 MFMAs (Z^T 3, S^T 3, dW1^T 4, dW2^T 4, U^T 4), ~27 vector and ~11 LDS
 // instructions (tile kernels: 58 / 19 + the 9-tap gather).  Deterministic: no atomics, fixed summation order.
-// hipcc-flags: -mllvm -amdgpu-mfma-vgpr-form=1
+// hipcc-flags: -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize
 #include <algorithm>
 #include <type_traits>
 
@@ -36,15 +36,24 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int CH = 16;
 constexpr int XROW = 80;      // floats per (ring slot, group) of the x ring: copies tx = 0, 1, 2, ones, dump
 constexpr int GROW = 64;      // ... of the g ring: copies tx = 0, 1, 2, dump
-constexpr int TST = 20;       // row stride of the d_a1 transpose scratch (16 x 16 floats, b128 reads 16-B aligned)
-constexpr int TRSZ = 16 * TST;
+// d_a1 transpose scratch of a group: [channel quad q][slot f(pos)][4 channels], plane stride TPL = 64 + 8 floats.
+// f sends the positions {0-3, 12-15} to the even and {4-11} to the odd slots: a ds_read_b128 lane group holds exactly
+// those two position sets of two neighbouring quads (MI355X LDS lane groups), so its 16 lanes hit 16 different 16-B
+// slots, and the 32 lanes of a ds_write_b32 group hit 32 different banks (row stride 20 floats: 2- to 3-way conflicts)
+constexpr int TPL = 72;
+constexpr int TRSZ = 4 * TPL;
+__device__ __forceinline__ int tslot(int pos) { return pos < 4 ? 2 * pos : pos >= 12 ? 2 * (pos - 12) + 8 : 2 * (pos - 4) + 1; }
 constexpr int NSLOT = 6;      // rows of the output ring: two batches of three
-constexpr int NPLANE = 4;     // tx = 0, 1, 2 and a dump plane for lane quarter 3
+constexpr int NPLANE = 3;     // tx = 0, 1, 2 (lane quarter 3 does not store)
 
 template <int G>
 struct Strip {
-    static constexpr int XS = 3 * G * XROW;          // x ring [slot][group][XROW]
-    static constexpr int GS = 3 * G * GROW;
+    // ring slot strides = 48 mod 64 floats: the three window rows a ds_read_b128 lane group reads (tap rows ty) then
+    // fall on different 16-float bank units ((3 ty + tx) mod 4) instead of on the same one
+    static constexpr int XSLOT = (G * XROW + 63) / 64 * 64 + 48;
+    static constexpr int GSLOT = (G * GROW + 63) / 64 * 64 + 48;
+    static constexpr int XS = 3 * XSLOT;             // x ring [slot][group][XROW]
+    static constexpr int GS = 3 * GSLOT;
     static constexpr int TR = G * TRSZ;              // one transpose scratch per group
     static constexpr int WAVE = XS + GS + TR;        // floats of wave-private LDS
     static constexpr int COLS = 16 * G;              // computed columns per wave
@@ -57,6 +66,11 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 template <int P>
 using phase_t = std::integral_constant<int, P>;
 
+// Keeps the MFMAs on either side in program order (everything else may still move across): hipcc otherwise
+// clusters the MFMAs of one accumulator back to back, and a dependent v_mfma_f32_16x16x4_f32 issues every 40
+// cycles instead of every 32 (measured here: 39.6 cycles per MFMA before, rounds of independent accumulators after)
+__device__ __forceinline__ void mfma_round() { __builtin_amdgcn_sched_barrier(0x7F6); }
+
 // partial[block][PAIR_NPART]: dW1^T (16 rows: taps 0..8, row 9 = db1) x 16 channels, dW2^T likewise, db2
 constexpr int PAIR_NPART = 2 * 256 + 1;
 
@@ -64,7 +78,7 @@ constexpr int PAIR_NPART = 2 * 256 + 1;
 // value: no position is ever masked.  MODE 1: anything else (halo columns between column blocks, computed columns
 // beyond the image, padding value) with per-position selects.
 template <int G, bool DX, bool SIG, int MODE>
-__global__ __launch_bounds__(512) void pair_strip_bwd_kernel(const float* __restrict__ x, const float* __restrict__ yout,
+__global__ __launch_bounds__(G <= 2 ? 1024 : 512) void pair_strip_bwd_kernel(const float* __restrict__ x, const float* __restrict__ yout,
                                                              const float* __restrict__ dy,
                                                              const float* __restrict__ w1,
                                                              const float* __restrict__ b1,
@@ -120,14 +134,16 @@ __global__ __launch_bounds__(512) void pair_strip_bwd_kernel(const float* __rest
     // dW operand rows: lane n = tap row of A (n = 9: the ones copy -> db1; n > 9: unused result rows, tap 8)
     int xr_addr[3], gr_addr[3];
     {
-        const int tapc = min(n, 8), ty = tapc / 3, tx = tapc - 3 * ty;
+        // (unused rows 10..15 read what a used lane of their ds_read_b128 lane group reads: a broadcast, no conflict)
+        const int tapc = n <= 8 ? n : n >= 12 ? 0 : n == 9 ? 8 : 4, ty = tapc / 3, tx = tapc - 3 * ty;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            xr_addr[p] = ((p + ty) % 3) * G * XROW + (n == 9 ? 3 : tx) * 16 + 4 * kq;       // row t-1+ty
-            gr_addr[p] = ((p + 2 - ty) % 3) * G * GROW + tx * 16 + 4 * kq;                  // row t+1-ty
+            xr_addr[p] = ((p + ty) % 3) * L::XSLOT + (n == 9 ? 3 : tx) * 16 + 4 * kq;       // row t-1+ty
+            gr_addr[p] = ((p + 2 - ty) % 3) * L::GSLOT + tx * 16 + 4 * kq;                  // row t+1-ty
         }
     }
-    const int tw_addr = 4 * kq * TST + n, tr_addr = n * TST + 4 * kq;
+    // transpose scratch: lane (kq, ch n) writes position 4kq + i (slot f(4kq) + 2i), lane (kq, pos n) reads quad kq
+    const int tw_addr = (n >> 2) * TPL + 4 * tslot(4 * kq) + (n & 3), tr_addr = kq * TPL + 4 * tslot(n);
     const int ow_addr = kq * outw + 1 + wv * L::COLS + n;
 
     // ---- global loads: one buffer descriptor per page row (base = the row, size = the row or nothing), so that the
@@ -189,21 +205,23 @@ __global__ __launch_bounds__(512) void pair_strip_bwd_kernel(const float* __rest
             }
             xw[g][slot] = xv;
             gw[g][slot] = gv;
-            xring[slot * G * XROW + g * XROW + xw_addr] = xv;
-            gring[slot * G * GROW + g * GROW + gw_addr] = gv;
+            xring[slot * L::XSLOT + g * XROW + xw_addr] = xv;
+            gring[slot * L::GSLOT + g * GROW + gw_addr] = gv;
         }
     };
 
     // ---- prologue: ones copy, output ring, rows r0-2 .. r0 --------------------------------------------------
-    for (int i = lane; i < 3 * G * 16; i += 64) xring[(i >> 4) * XROW + 3 * 16 + (i & 15)] = 1.f;
+    for (int i = lane; i < 3 * G * 16; i += 64) xring[(i / (16 * G)) * L::XSLOT + ((i >> 4) % G) * XROW + 3 * 16 + (i & 15)] = 1.f;
     if constexpr (DX)
         for (int i = tid; i < NSLOT * NPLANE * outw; i += blockDim.x) outr[i] = 0.f;
+    float xn[G], dyn[G], yn[G];                        // the row in flight: issued one whole step before it is used
     if (active) {
-        float xn[3][G], dyn[3][G], yn[3][G];
+        float xp[3][G], dyp[3][G], yp[3][G];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) load_row(r0 - 2 + j, xn[j], dyn[j], yn[j]);
+        for (int j = 0; j < 3; ++j) load_row(r0 - 2 + j, xp[j], dyp[j], yp[j]);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) finish_row(r0 - 2 + j, j, xn[j], dyn[j], yn[j]);
+        for (int j = 0; j < 3; ++j) finish_row(r0 - 2 + j, j, xp[j], dyp[j], yp[j]);
+        load_row(r0 + 1, xn, dyn, yn);
     }
     __syncthreads();
 
@@ -229,10 +247,13 @@ __global__ __launch_bounds__(512) void pair_strip_bwd_kernel(const float* __rest
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) { z[g] = mfma4(xw[g][S0], w1b[0], z[g]); s[g] = mfma4(gw[g][S2], w2b[0], s[g]); }
+        mfma_round();
 #pragma unroll
         for (int g = 0; g < G; ++g) { z[g] = mfma4(xw[g][S1], w1b[1], z[g]); s[g] = mfma4(gw[g][S1], w2b[1], s[g]); }
+        mfma_round();
 #pragma unroll
         for (int g = 0; g < G; ++g) { z[g] = mfma4(xw[g][S2], w1b[2], z[g]); s[g] = mfma4(gw[g][S0], w2b[2], s[g]); }
+        mfma_round();
         // results: channel n at positions (t, wc0 + 16g + 4kq + i)
         float a[G][4], d[G][4], dn[G][4];
 #pragma unroll
@@ -256,7 +277,7 @@ __global__ __launch_bounds__(512) void pair_strip_bwd_kernel(const float* __rest
             if constexpr (DX) {
                 float* tsc = trs + g * TRSZ;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) tsc[tw_addr + i * TST] = d[g][i];
+                for (int i = 0; i < 4; ++i) tsc[tw_addr + 8 * i] = d[g][i];
             }
         }
         if constexpr (OWN) {
@@ -266,6 +287,7 @@ __global__ __launch_bounds__(512) void pair_strip_bwd_kernel(const float* __rest
                 for (int g = 0; g < G; ++g) {
                     acc2[g & 1] = mfma4(ga[g][i], a[g][i], acc2[g & 1]);
                     acc1[g & 1] = mfma4(xa[g][i], dn[g][i], acc1[g & 1]);
+                    if (g & 1) mfma_round();
                 }
 #pragma unroll
             for (int g = 0; g < G; ++g) db2acc[g] += gw[g][S1];
@@ -280,9 +302,11 @@ __global__ __launch_bounds__(512) void pair_strip_bwd_kernel(const float* __rest
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int kc = 0; kc < 4; ++kc)
+            for (int kc = 0; kc < 4; ++kc) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) u[g] = mfma4(w1u[kc], dt[g][kc], u[g]);
+                mfma_round();
+            }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 cdone[g] = rr[g][S0] + u[g][0];          // row t-1 is complete
@@ -294,8 +318,6 @@ __global__ __launch_bounds__(512) void pair_strip_bwd_kernel(const float* __rest
     auto step = [&](auto ptag, int t, int oslot) {
         constexpr int P = decltype(ptag)::value;
         constexpr int S0 = P, S2 = (P + 2) % 3;
-        float xn[G], dyn[G], yn[G];
-        if (active) load_row(t + 2, xn, dyn, yn);
         float cdone[G];
         if (active && t >= 0 && t < h && t <= r1) {
             if (t >= r0 && t < r1) compute(ptag, std::true_type{}, t, cdone);
@@ -308,12 +330,22 @@ __global__ __launch_bounds__(512) void pair_strip_bwd_kernel(const float* __rest
             }
         }
         if constexpr (DX) {
-            if (active) {
+            if (active && kq < 3) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) outr[oslot * NPLANE * outw + ow_addr + 16 * g] = cdone[g];
             }
         }
-        if (active) finish_row(t + 2, S0, xn, dyn, yn);
+        if (active) {
+            // row t+2 was requested a whole step ago; keep its first use down here (the scheduler would hoist the
+            // arithmetic on it into the MFMA block above and wait for memory there), then request row t+3
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                asm volatile("" : "+v"(xn[g]), "+v"(dyn[g]));
+                if constexpr (SIG) asm volatile("" : "+v"(yn[g]));
+            }
+            finish_row(t + 2, S0, xn, dyn, yn);
+            load_row(t + 3, xn, dyn, yn);
+        }
     };
 
     const int nsteps = r1 - r0 + 2;                    // t = r0-1 .. r1
@@ -368,23 +400,40 @@ __global__ __launch_bounds__(512) void pair_strip_bwd_kernel(const float* __rest
     }
 }
 
-// block j: float64 sum over the block partials of output element j (dw1: 144, db1: 16, dw2: 144, db2: 1)
-__global__ __launch_bounds__(64) void pair_strip_finish(const float* __restrict__ partial, float* __restrict__ dw1,
+// Sum of the block partials in float64, fixed order.  Block = 32 consecutive partial columns x 8 segments of the
+// blocks (coalesced 128-byte reads, 8 loads in flight per thread), segments added in order; then the columns that
+// are outputs (dw1: 9 x 16, db1 = row 9 of dW1^T, dw2, db2) are stored.
+__global__ __launch_bounds__(256) void pair_strip_finish(const float* __restrict__ partial, float* __restrict__ dw1,
                                                         float* __restrict__ db1, float* __restrict__ dw2,
                                                         float* __restrict__ db2, int nblocks, int use_b1, int use_b2,
                                                         int accumulate, float unscale) {
-    const int j = blockIdx.x;
-    int src;
-    float* dst;
-    bool live = true;
-    if (j < 144) { src = j; dst = dw1 + j; }                              // dW1^T[tap][ch] = dw1[tap * 16 + ch]
-    else if (j < 160) { src = 9 * 16 + (j - 144); dst = db1 + (j - 144); live = use_b1; }
-    else if (j < 304) { src = 256 + (j - 160); dst = dw2 + (j - 160); }
-    else { src = 512; dst = db2; live = use_b2; }
+    __shared__ double seg[8][32];
+    const int o = threadIdx.x & 31, sg = threadIdx.x >> 5, j = blockIdx.x * 32 + o;
     double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 64) s += (double)partial[(size_t)b * PAIR_NPART + src];
-    s = wave_reduce_sum(s);
-    if (threadIdx.x != 0) return;
+    if (j < PAIR_NPART) {
+        const int per = (nblocks + 7) / 8, b0 = sg * per, b1 = min(nblocks, b0 + per);
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = partial[(size_t)(b + k) * PAIR_NPART + j];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += (double)v[k];
+        }
+        for (; b < b1; ++b) s += (double)partial[(size_t)b * PAIR_NPART + j];
+    }
+    seg[sg][o] = s;
+    __syncthreads();
+    if (sg != 0 || j >= PAIR_NPART) return;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += seg[k][o];
+    float* dst = nullptr;
+    bool live = true;
+    if (j < 144) dst = dw1 + j;                                           // dW1^T[tap][ch] = dw1[tap * 16 + ch]
+    else if (j < 160) { dst = db1 + (j - 144); live = use_b1; }           // row 9: the ones copy
+    else if (j >= 256 && j < 256 + 144) dst = dw2 + (j - 256);
+    else if (j == 512) { dst = db2; live = use_b2; }
+    if (!dst) return;
     s = live ? s * (double)unscale : 0.0;
     *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
@@ -397,15 +446,13 @@ size_t strip_lds_bytes(int nw, bool dx) {
     return sizeof(float) * (wave + ring > red ? wave + ring : red);
 }
 
-}  // namespace
-
-// float32 backward of the pair block on the strip kernels.  Returns UOCR_OK or an error code (ctx->err set).
-int uocr_pair_strip_bwd_f32(uocr_ctx* ctx, const float* x, const float* y, const float* dy, const float* w1,
-                            const float* b1, const float* w2, float* dw1, float* db1, float* dw2, float* db2,
-                            float* dx, int n, int h, int w, float pad1, int use_b1, int use_b2, float alpha,
-                            bool sig, int accumulate, float unscale) {
-    constexpr int G = 4;
-    const int nw = std::min(8, (w + Strip<G>::COLS - 1) / Strip<G>::COLS);
+// G groups of 16 columns per wave, up to MAXW waves per block
+template <int G, int MAXW>
+int strip_bwd_launch(uocr_ctx* ctx, const float* x, const float* y, const float* dy, const float* w1,
+                     const float* b1, const float* w2, float* dw1, float* db1, float* dw2, float* db2,
+                     float* dx, int n, int h, int w, float pad1, int use_b1, int use_b2, float alpha,
+                     bool sig, int accumulate, float unscale) {
+    const int nw = std::min(MAXW, (w + Strip<G>::COLS - 1) / Strip<G>::COLS);
     const int bwc = nw * Strip<G>::COLS;
     const int nbx = w <= bwc ? 1 : 1 + (w - bwc + (bwc - 2) - 1) / (bwc - 2);
     // bands: about one block per CU (a block of 8 waves holds 126 KB of LDS), rows per band a multiple of 3 + 1
@@ -441,8 +488,21 @@ int uocr_pair_strip_bwd_f32(uocr_ctx* ctx, const float* x, const float* y, const
     if (dx) rc = sig ? pick(std::true_type{}, std::true_type{}) : pick(std::true_type{}, std::false_type{});
     else rc = sig ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{});
     if (rc != UOCR_OK) return rc;
-    hipLaunchKernelGGL(pair_strip_finish, dim3(305), dim3(64), 0, ctx->stream, (const float*)partial, dw1, db1, dw2,
+    hipLaunchKernelGGL(pair_strip_finish, dim3((PAIR_NPART + 31) / 32), dim3(256), 0, ctx->stream, (const float*)partial, dw1, db1, dw2,
                        db2, (int)nblocks, use_b1, use_b2, accumulate, unscale);
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
+}
+}  // namespace
+
+// float32 backward of the pair block on the strip kernels.  Returns UOCR_OK or an error code (ctx->err set).
+int uocr_pair_strip_bwd_f32(uocr_ctx* ctx, const float* x, const float* y, const float* dy, const float* w1,
+                            const float* b1, const float* w2, float* dw1, float* db1, float* dw2, float* db2,
+                            float* dx, int n, int h, int w, float pad1, int use_b1, int use_b2, float alpha,
+                            bool sig, int accumulate, float unscale) {
+    if (ctx->opt_pair_g == 2)
+        return strip_bwd_launch<2, 16>(ctx, x, y, dy, w1, b1, w2, dw1, db1, dw2, db2, dx, n, h, w, pad1, use_b1, use_b2,
+                                       alpha, sig, accumulate, unscale);
+    return strip_bwd_launch<4, 8>(ctx, x, y, dy, w1, b1, w2, dw1, db1, dw2, db2, dx, n, h, w, pad1, use_b1, use_b2, alpha,
+                                  sig, accumulate, unscale);
 }

@@ -31,6 +31,7 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->opt_xcd = 1;
     ctx->opt_pair = 1;
     ctx->opt_pair_band = 0;
+    ctx->opt_pair_g = 4;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return UOCR_ERR_HIP;
@@ -85,6 +86,7 @@ int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "t32")) ctx->opt_t32 = value;
     else if (!strcmp(key, "pair")) ctx->opt_pair = value;
     else if (!strcmp(key, "pair_band")) ctx->opt_pair_band = value;
+    else if (!strcmp(key, "pair_g")) ctx->opt_pair_g = value;
     else UOCR_FAIL(ctx, UOCR_ERR_ARG, "unknown option '%s'", key);
     return UOCR_OK;
 }
