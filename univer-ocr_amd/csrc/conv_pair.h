@@ -7,3 +7,7 @@ int uocr_pair_strip_bwd_f32(uocr_ctx* ctx, const float* x, const float* y, const
                             const float* b1, const float* w2, float* dw1, float* db1, float* dw2, float* db2,
                             float* dx, int n, int h, int w, float pad1, int use_b1, int use_b2, float alpha,
                             bool sig, int accumulate, float unscale);
+
+int uocr_pair_strip_fwd_f32(uocr_ctx* ctx, const float* x, const float* w1, const float* b1, const float* w2,
+                            const float* b2, float* y, int n, int h, int w, float pad1, int use_b1, int use_b2,
+                            float alpha, int act2);

@@ -400,6 +400,184 @@ __global__ __launch_bounds__(G <= 2 ? 1024 : 512) void pair_strip_bwd_kernel(con
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Forward on the same strips.  Here the first product is taken the OTHER way round, Z[ch, pos] = W1^T . Xcol (the
+// window registers are its B operand), so that its result -- channels 4kq..4kq+3 of column n in lane (kq, n) -- is,
+// after LeakyReLU, directly the B operand of P^T[tap, pos] = W2 . A1^T: no transpose, no LDS but the output ring.
+// y[p] = b2 + sum_tap P[p + tap - 1, tap]: row q feeds rows q+1, q, q-1 (ty = 0, 1, 2: three rolling registers),
+// column c of lane quarter tx feeds column c - tx + 1 (one LDS row per tx).  7 MFMAs per group of 16 positions
+// (tile kernel: 7 + a 9-tap LDS gather per output), 3 window registers per group instead of an LDS tile with halo.
+// Band rows overlap by one row of a1 on each side.  MODE as in the backward kernel.
+template <int G, int MODE>
+__global__ __launch_bounds__(512) void pair_strip_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                             const float* __restrict__ b1,
+                                                             const float* __restrict__ w2,
+                                                             const float* __restrict__ b2, float* __restrict__ y,
+                                                             int h, int wd, int band_h, float pad1, int use_b1,
+                                                             int use_b2, float alpha, int act2) {
+    using L = Strip<G>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kq = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = blockDim.x >> 6;
+    const int bwc = nw * L::COLS;
+    const int outw = bwc + 16;
+    float* const outr = lds;                           // [NSLOT][NPLANE][outw]
+    const int cstart = blockIdx.x * (bwc - 2);
+    const int own_lo = cstart + (blockIdx.x > 0 ? 1 : 0);
+    const bool last_block = cstart + bwc >= wd;
+    const int own_hi = last_block ? wd : cstart + bwc - 1;
+    const int wc0 = cstart + wv * L::COLS;
+    const bool active = wc0 < wd;
+    const int r0 = blockIdx.y * band_h, r1 = min(h, r0 + band_h);
+    const size_t img = (size_t)blockIdx.z * h * wd;
+    const float* xb = x + img;
+
+    // Z[ch, pos]: A = W1^T[ch n][tap (kc, kq)], B = x of row t-1+kc shifted by tx = kq
+    // P^T[m, pos]: m = 4 tx + ty; A[m = n][k = ch 4kq + i] = W2[tap(m)][4kq + i], B = a1 (this lane's four Z results)
+    float w1a[3], w2a[4], bias4[4];
+#pragma unroll
+    for (int kc = 0; kc < 3; ++kc) w1a[kc] = kq < 3 ? w1[(kc * 3 + min(kq, 2)) * CH + n] : 0.f;
+    {
+        const int txm = n >> 2, tym = n & 3;
+        const bool live = txm < 3 && tym < 3;
+        const int tap = live ? tym * 3 + txm : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            w2a[i] = live ? w2[tap * CH + 4 * kq + i] : 0.f;
+            bias4[i] = use_b1 ? b1[4 * kq + i] : 0.f;
+        }
+    }
+    const float bias2 = use_b2 ? b2[0] : 0.f;
+    const int ow_addr = kq * outw + 1 + wv * L::COLS + n;
+
+    const int sh = min(kq, 2) - 1;
+    int xoff[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) xoff[g] = max(wc0 + 16 * g + n + sh, 0) * 4;
+    const float xkeep = wc0 + n + sh >= 0 ? 1.f : 0.f;
+    const unsigned row_bytes = (unsigned)wd * 4u;
+    auto load_row = [&](int row, float (&xn)[G]) {
+        const bool in = row >= 0 && row < h;
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)min(max(row, 0), h - 1) * wd), 0,
+                                                          in ? row_bytes : 0u, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            xn[g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff[g], 0, 0));
+    };
+    float xw[G][3], rr[G][3];
+    auto finish_row = [&](int row, int slot, float (&xn)[G]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float xv = xn[g];
+            if (g == 0) xv *= xkeep;
+            if constexpr (MODE == 1) {
+                const int cx = wc0 + 16 * g + n + sh;
+                xv = (row >= 0 && row < h && cx >= 0 && cx < wd) ? xv : pad1;
+            }
+            xw[g][slot] = xv;
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rr[g][j] = 0.f;
+    for (int i = tid; i < NSLOT * NPLANE * outw; i += blockDim.x) outr[i] = 0.f;
+    float xn[G];
+    if (active) {
+        float xp[3][G];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) load_row(r0 - 2 + j, xp[j]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) finish_row(r0 - 2 + j, j, xp[j]);
+        load_row(r0 + 1, xn);
+    }
+    __syncthreads();
+
+    auto step = [&](auto ptag, int t, int oslot) {
+        constexpr int P = decltype(ptag)::value;
+        constexpr int S0 = P, S1 = (P + 1) % 3, S2 = (P + 2) % 3;
+        float cdone[G];
+        if (active && t >= 0 && t < h && t <= r1) {
+            f32x4 z[G], u[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                z[g] = f32x4{bias4[0], bias4[1], bias4[2], bias4[3]};
+                u[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) z[g] = mfma4(w1a[0], xw[g][S0], z[g]);
+            mfma_round();
+#pragma unroll
+            for (int g = 0; g < G; ++g) z[g] = mfma4(w1a[1], xw[g][S1], z[g]);
+            mfma_round();
+#pragma unroll
+            for (int g = 0; g < G; ++g) z[g] = mfma4(w1a[2], xw[g][S2], z[g]);
+            mfma_round();
+            // results: channels 4kq + i of position (t, wc0 + 16g + n)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float a = z[g][i] >= 0.f ? z[g][i] : alpha * z[g][i];
+                    if constexpr (MODE == 1) a = wc0 + 16 * g + n < wd ? a : 0.f;     // conv_2 pads a1 with zeros
+                    z[g][i] = a;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) u[g] = mfma4(w2a[i], z[g][i], u[g]);
+                mfma_round();
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                cdone[g] = rr[g][S0] + u[g][2];          // y row t-1 is complete (tap row 2 of a1 row t)
+                rr[g][S1] += u[g][1];
+                rr[g][S2] = u[g][0];
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                cdone[g] = rr[g][S0];
+                rr[g][S2] = 0.f;
+            }
+        }
+        if (active && kq < 3) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) outr[oslot * NPLANE * outw + ow_addr + 16 * g] = cdone[g];
+        }
+        if (active) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) asm volatile("" : "+v"(xn[g]));
+            finish_row(t + 2, S0, xn);
+            load_row(t + 3, xn);
+        }
+    };
+
+    const int nsteps = r1 - r0 + 2;
+    for (int ss = 0, t0 = r0 - 1; ss * 3 < nsteps; ++ss, t0 += 3) {
+        const int ob = (ss & 1) * 3;
+        step(phase_t<0>{}, t0, ob);
+        step(phase_t<1>{}, t0 + 1, ob + 1);
+        step(phase_t<2>{}, t0 + 2, ob + 2);
+        __syncthreads();
+        // y[row][c] = act2(b2 + plane1[c] + plane0[c-1] + plane2[c+1])
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int row = t0 - 1 + j;
+            if (row < r0 || row >= r1) continue;
+            const float* o = outr + (ob + j) * NPLANE * outw + 1 + wv * L::COLS;
+            for (int cc = lane; cc < L::COLS; cc += 64) {
+                const int c = wc0 + cc;
+                float v = bias2 + (o[outw + cc] + o[cc - 1] + o[2 * outw + cc + 1]);
+                if (act2 == UOCR_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+                if (c >= own_lo && c < own_hi) y[img + (size_t)row * wd + c] = v;
+            }
+        }
+    }
+}
+
 // Sum of the block partials in float64, fixed order.  Block = 32 consecutive partial columns x 8 segments of the
 // blocks (coalesced 128-byte reads, 8 loads in flight per thread), segments added in order; then the columns that
 // are outputs (dw1: 9 x 16, db1 = row 9 of dW1^T, dw2, db2) are stored.
@@ -505,4 +683,30 @@ int uocr_pair_strip_bwd_f32(uocr_ctx* ctx, const float* x, const float* y, const
                                        alpha, sig, accumulate, unscale);
     return strip_bwd_launch<4, 8>(ctx, x, y, dy, w1, b1, w2, dw1, db1, dw2, db2, dx, n, h, w, pad1, use_b1, use_b2, alpha,
                                   sig, accumulate, unscale);
+}
+
+// float32 forward of the pair block on the strip kernels
+int uocr_pair_strip_fwd_f32(uocr_ctx* ctx, const float* x, const float* w1, const float* b1, const float* w2,
+                            const float* b2, float* y, int n, int h, int w, float pad1, int use_b1, int use_b2,
+                            float alpha, int act2) {
+    constexpr int G = 4;
+    const int nw = std::min(8, (w + Strip<G>::COLS - 1) / Strip<G>::COLS);
+    const int bwc = nw * Strip<G>::COLS;
+    const int nbx = w <= bwc ? 1 : 1 + (w - bwc + (bwc - 2) - 1) / (bwc - 2);
+    // the forward block holds 38 KB of LDS and ~100 registers: two blocks per CU
+    int bands = std::max(1, (2 * ctx->cu_count + n * nbx - 1) / (n * nbx));
+    if (ctx->opt_pair_band > 0) bands = (h + ctx->opt_pair_band - 1) / ctx->opt_pair_band;
+    int band_h = std::min(h, std::max(4, (h + bands - 1) / bands));
+    bands = (h + band_h - 1) / band_h;
+    UOCR_REQUIRE(ctx, bands <= 65535 && n <= 65535);
+    const size_t lds = sizeof(float) * NSLOT * NPLANE * (bwc + 16);
+    const bool plain = nbx == 1 && w == bwc && pad1 == 0.f;
+    if (plain)
+        hipLaunchKernelGGL((pair_strip_fwd_kernel<G, 0>), dim3(nbx, bands, n), dim3(nw * 64), lds, ctx->stream, x, w1, b1,
+                           w2, b2, y, h, w, band_h, pad1, use_b1, use_b2, alpha, act2);
+    else
+        hipLaunchKernelGGL((pair_strip_fwd_kernel<G, 1>), dim3(nbx, bands, n), dim3(nw * 64), lds, ctx->stream, x, w1, b1,
+                           w2, b2, y, h, w, band_h, pad1, use_b1, use_b2, alpha, act2);
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
 }
