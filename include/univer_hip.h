@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define UOCR_ABI_VERSION 2
+#define UOCR_ABI_VERSION 3
 
 typedef struct uocr_ctx uocr_ctx;
 
@@ -97,6 +97,19 @@ int uocr_event_record(uocr_ctx* ctx, void* event);
 /* the ctx's stream waits (on the device) for `event`, recorded on any other ctx's stream: orders lanes */
 int uocr_stream_wait_event(uocr_ctx* ctx, void* event);
 int uocr_event_elapsed_ms_sync(void* start, void* stop, float* out_ms);
+int uocr_event_synchronize(void* event);                                        /* host waits for the event */
+/* HIP-graph capture and replay of a call sequence on the ctx's stream.  The reference pays a Python dispatch and
+ * a cuda.synchronize() per layer (layers/layers.py:179-197, convolutional.py:192,278); a train step recorded once
+ * between begin_capture and end_capture (every entry point of this header that is not marked "not capturable" or
+ * "_sync" may be called in between; no allocation happens inside the library) is replayed with one uocr_graph_launch.
+ * Buffers named in the captured calls must stay allocated for the life of the graph; by-value arguments are frozen
+ * (optimizer hyper-parameters that change go through the `hyper` device arrays).  Capture mode: relaxed (the caller's
+ * allocator may call hipMalloc while capturing).  Other streams join a capture the HIP way: an event recorded on the
+ * capturing stream and waited for with uocr_stream_wait_event. */
+int uocr_graph_begin_capture(uocr_ctx* ctx);
+int uocr_graph_end_capture(uocr_ctx* ctx, void** out_graph_exec);
+int uocr_graph_launch(uocr_ctx* ctx, void* graph_exec);
+int uocr_graph_destroy(void* graph_exec);
 /* name, CU count, HBM bytes of the ctx's device (train.py:70-90 prints the numba equivalents) */
 int uocr_device_info(uocr_ctx* ctx, char* name_out, size_t name_cap, int* cu_count, size_t* hbm_bytes);
 

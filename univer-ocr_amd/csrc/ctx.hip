@@ -195,6 +195,43 @@ int uocr_event_elapsed_ms_sync(void* start, void* stop, float* out_ms) {
                                                                                            : UOCR_ERR_HIP;
 }
 
+int uocr_event_synchronize(void* event) {
+    if (!event) return UOCR_ERR_ARG;
+    return hipEventSynchronize((hipEvent_t)event) == hipSuccess ? UOCR_OK : UOCR_ERR_HIP;
+}
+
+int uocr_graph_begin_capture(uocr_ctx* ctx) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+    return UOCR_OK;
+}
+
+int uocr_graph_end_capture(uocr_ctx* ctx, void** out_graph_exec) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, out_graph_exec != nullptr);
+    *out_graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    UOCR_HIP(ctx, hipStreamEndCapture(ctx->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) UOCR_FAIL(ctx, UOCR_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    *out_graph_exec = (void*)exec;
+    return UOCR_OK;
+}
+
+int uocr_graph_launch(uocr_ctx* ctx, void* graph_exec) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, graph_exec != nullptr);
+    UOCR_HIP(ctx, hipGraphLaunch((hipGraphExec_t)graph_exec, ctx->stream));
+    return UOCR_OK;
+}
+
+int uocr_graph_destroy(void* graph_exec) {
+    if (!graph_exec) return UOCR_ERR_ARG;
+    return hipGraphExecDestroy((hipGraphExec_t)graph_exec) == hipSuccess ? UOCR_OK : UOCR_ERR_HIP;
+}
+
 int uocr_device_info(uocr_ctx* ctx, char* name_out, size_t name_cap, int* cu_count, size_t* hbm_bytes) {
     UOCR_CHECK_CTX(ctx);
     hipDeviceProp_t prop;

@@ -823,7 +823,19 @@ int uocr_conv_dgrad_mfma(uocr_ctx* ctx, const void* dy, const void* w, void* dx,
     ep.mask_y = (const float*)mask.y;
     ep.mask_act = mask.act;
     ep.mask_alpha = (float)mask.alpha;
-    return launch_mfma(ctx, A, B, ep, M, d.cin, D, (size_t)M * d.cin * 4 * 8 <= ws_half(ctx));
+    // A strided transposed conv only meets the tap rows ky with (iy + ph - ky) % sh == 0 and an output row inside the
+    // image; the kernel skips the depth tiles of the others.  When few tiles per block are live, a depth split only
+    // adds slabs of zeros and a reduce launch (Char conv_3, 5 x 3 stride (2, 1) on 5 rows: 1 of 5 tap rows live,
+    // 27.5 us split 6 ways, 18.5 us unsplit), so the split decision counts the live tiles
+    long live = 0;
+    for (int iy = 0; iy < d.h; ++iy)
+        for (int ky = 0; ky < d.kh; ++ky) {
+            const int t = iy + d.ph - ky;
+            live += t >= 0 && t % d.sh == 0 && t / d.sh < d.oh;
+        }
+    const long live_tiles = ((long)D + BD - 1) / BD * live / ((long)d.h * d.kh);
+    const bool split_ok = (size_t)M * d.cin * 4 * 8 <= ws_half(ctx) && live_tiles >= 12;
+    return launch_mfma(ctx, A, B, ep, M, d.cin, D, split_ok);
 }
 
 int uocr_conv_wgrad_mfma(uocr_ctx* ctx, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,

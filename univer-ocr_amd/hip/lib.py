@@ -62,6 +62,11 @@ _PROTOS = {
     'uocr_event_record': [_ctx, _vp],
     'uocr_stream_wait_event': [_ctx, _vp],
     'uocr_event_elapsed_ms_sync': [_vp, _vp, C.POINTER(C.c_float)],
+    'uocr_event_synchronize': [_vp],
+    'uocr_graph_begin_capture': [_ctx],
+    'uocr_graph_end_capture': [_ctx, C.POINTER(_vp)],
+    'uocr_graph_launch': [_ctx, _vp],
+    'uocr_graph_destroy': [_vp],
     'uocr_device_info': [_ctx, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_sz)],
     'uocr_conv2d_fwd': [_ctx, _i, _vp, _vp, _vp, _vp] + [_i] * 13 + [_d, _i, _i, _d],
     'uocr_conv2d_bwd_data': [_ctx, _i, _vp, _vp, _vp] + [_i] * 13 + [_vp, _i, _d],

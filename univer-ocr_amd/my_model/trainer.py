@@ -79,6 +79,7 @@ class PageTrainer:
         # scalars it returns keep the value of THEIR step however late they are read
         self.snapshot_losses = bool(snapshot_losses)
         self._lane_done = {}
+        self._event_rings = {}
         self.eager_nets = tuple(eager_nets)          # nets kept out of the graphs (e.g. to time one kernel)
         self._captured = None
         self._eager_steps = 0
@@ -171,7 +172,6 @@ class PageTrainer:
         """Every net on its own stream.  The lanes start after everything already queued on the main
         stream (the inputs) and the main stream ends the step by waiting for all of them.  With data
         parallelism each net's all-reduce is issued from its lane right after its backward."""
-        import torch
         if self.graphs:
             if self._captured is None and self._eager_steps >= 2:     # lazy initialisation is over
                 self._capture(context)
@@ -179,14 +179,12 @@ class PageTrainer:
                 return self._step_graphs(context)
             self._eager_steps += 1
         rt = CP.runtime()
-        main = torch.cuda.current_stream()
-        start = torch.cuda.Event()
-        start.record(main)
+        start = self._event('start').record()              # (on the main stream: after the inputs queued there)
         context['losses'] = {}
         comps = self._lane_order()
         for comp in comps:
             with rt.lane(self.lanes[comp.name]) as stream:
-                stream.wait_event(start)
+                start.wait()
                 comp.selector(context)
                 X, y = next(comp.selector.get())
                 if self.pipelined:                     # the caller may drop these arrays before the lane is done
@@ -195,16 +193,24 @@ class PageTrainer:
                 comp.model.train_begin(X, y)
                 comp._publish()
         for comp in comps:
-            with rt.lane(self.lanes[comp.name]) as stream:
+            with rt.lane(self.lanes[comp.name]):
                 context['losses'][comp.name] = comp.model.train_finish()
-                done = torch.cuda.Event()
-                done.record(stream)
-            self._finish_lane(comp.name, done, context['losses'][comp.name], main)
+                done = self._event(comp.name).record()
+            self._finish_lane(comp.name, done, context['losses'][comp.name])
         return context['losses']
 
-    def _finish_lane(self, name, done, losses, main):
+    def _event(self, key):
+        """Events of the C ABI, a ring of four per key: an event that is recorded again still stands for "at least
+        as late as" to whoever kept it from an earlier step (DeviceScalar.ready)."""
+        ring = self._event_rings.setdefault(key, [[], 0])
+        if len(ring[0]) < 4:
+            ring[0].append(CP.runtime().event())
+        ring[1] = (ring[1] + 1) % 4
+        return ring[0][min(ring[1], len(ring[0]) - 1)]
+
+    def _finish_lane(self, name, done, losses):
         if not self.pipelined:
-            main.wait_event(done)
+            done.wait()                                    # the main stream waits for the lane
             return
         self._lane_done[name] = done
         from ..nn.gpu import DeviceScalar
@@ -215,20 +221,21 @@ class PageTrainer:
     def join(self):
         """Pipelined mode: make the current stream wait for every lane (before reading outputs or
         overwriting inputs on it)."""
-        import torch
-        main = torch.cuda.current_stream()
         for done in self._lane_done.values():
-            main.wait_event(done)
+            done.wait()
         self._lane_done = {}
 
     # -- HIP-graph replay of the step ----------------------------------------------------------------
     def _capture(self, context):
         """Record, per net, graph A = forward + loss + backward and graph B = L2 + optimizer + gradient
-        reset on the net's lane stream.  The gradient all-reduce of data parallelism stays outside the
-        graphs (issued eagerly between A and B).  The device arrays of `context` become the static
-        inputs of the graphs; the loss slots and the published outputs are static outputs."""
+        reset on the net's lane through the C ABI (uocr_graph_begin_capture / end_capture; replay =
+        uocr_graph_launch).  The gradient all-reduce of data parallelism stays outside the graphs (issued
+        eagerly between A and B).  The device arrays of `context` become the static inputs of the graphs; the loss
+        slots (consecutive in one LossArena per net) and the published outputs are static outputs.  PyTorch only
+        provides the memory: one MemPool per net keeps what a graph's kernels read and write apart from every later
+        allocation."""
         import torch
-        from ..nn.gpu import DeviceScalar
+        from ..nn.gpu import DeviceScalar, LossArena
         if not CP.lazy_losses:
             raise RuntimeError('PageTrainer(graphs=True) needs CP.lazy_losses = True: a loss read with float() '
                                'inside the step is a host sync, which a HIP graph cannot contain')
@@ -243,30 +250,31 @@ class PageTrainer:
             comp.selector(context)
             labels = (comp.selector.X_label, comp.selector.y_label)
             X, y = (self._static_input(label, context[label]) for label in labels)
-            entry = {}
-            with rt.lane(self.lanes[comp.name]) as stream:
-                begin = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(begin, stream=stream, capture_error_mode='thread_local'):
-                    model.train_begin(X, y)
-                    comp._publish()
-                pending = model._pending_losses
-                finish = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(finish, stream=stream, capture_error_mode='thread_local'):
-                    losses = model.train_finish()
-                    # all loss slots of the net side by side: one copy per step snapshots them (step())
-                    packed = torch.stack([v.t.reshape(()) for v in pending] + [losses['regularization_loss'].t.reshape(())])
-            for value in pending + [losses['regularization_loss']]:
+            pool = torch.cuda.MemPool()
+            try:
+                with rt.lane(self.lanes[comp.name]):
+                    with torch.cuda.use_mem_pool(pool):
+                        arena = CP.loss_arena = LossArena(16)
+                    with rt.capture(pool) as begin:
+                        model.train_begin(X, y)
+                        comp._publish()
+                    pending = model._pending_losses
+                    with rt.capture(pool) as finish:
+                        losses = model.train_finish()
+            finally:
+                CP.loss_arena = None
+            slots = pending + [losses['regularization_loss']]
+            for value in slots:
                 if not isinstance(value, DeviceScalar):
                     raise RuntimeError('graph capture: a loss was materialised on the host')
-            entry.update(begin=begin, finish=finish, packed_losses=packed, output_losses=[v.t for v in pending],
-                         regularization_loss=losses['regularization_loss'].t,
-                         prediction=context.get(comp.selector.pred_label))
+            captured[comp.name] = dict(begin=begin, finish=finish, arena=arena,
+                                       slot_index=[arena.index_of(v.t) for v in slots],
+                                       output_losses=[v.t for v in pending],
+                                       regularization_loss=losses['regularization_loss'].t,
+                                       prediction=context.get(comp.selector.pred_label))
             model.grad_sync = sync
-            captured[comp.name] = entry
             del hook                                              # stays off: the backward now lives in the graph
         self._captured = captured
-        self._events = {comp.name: torch.cuda.Event() for comp in self.model_system.components}
-        self._start = torch.cuda.Event()
 
     def capture(self, context):
         """Run the eager steps still needed for lazy initialisation, then record the graphs now (step()
@@ -296,10 +304,8 @@ class PageTrainer:
         return static
 
     def _step_graphs(self, context):
-        import torch
-        from ..nn.gpu import DeviceScalar
+        from ..nn.gpu import DeviceArray, DeviceScalar
         rt = CP.runtime()
-        main = torch.cuda.current_stream()
         comps = self._lane_order()
         self.optimizer.refresh_hyper()                   # lr / betas changed since the last step? (device array)
         if self.pipelined and any(context[label] is not static for label, static in self._statics.items()):
@@ -308,13 +314,13 @@ class PageTrainer:
         for label, static in self._statics.items():          # new batch -> the graphs' static inputs
             fresh = context[label]
             if fresh is not static and (id(fresh), id(static)) not in copied:
-                static.t.copy_(fresh.t, non_blocking=True)
+                rt.call('uocr_d2d', static.ptr, fresh.ptr, static.nbytes)
                 copied.add((id(fresh), id(static)))
-        self._start.record(main)
+        start = self._event('start').record()
         for comp in comps:
             entry = self._captured.get(comp.name)
-            with rt.lane(self.lanes[comp.name]) as stream:
-                stream.wait_event(self._start)
+            with rt.lane(self.lanes[comp.name]):
+                start.wait()
                 if entry is None:                             # eager net
                     comp.selector(context)
                     X, y = next(comp.selector.get())
@@ -325,35 +331,30 @@ class PageTrainer:
                 if comp.model.grad_sync is not None:
                     comp.model.grad_sync(comp.model)          # RCCL all-reduce of the flat gradient
         context['losses'] = {}
-        snaps = {}
         for comp in comps:
             entry, model = self._captured.get(comp.name), comp.model
-            with rt.lane(self.lanes[comp.name]) as stream:
+            snap = None
+            with rt.lane(self.lanes[comp.name]):
                 if entry is None:
                     context['losses'][comp.name] = model.train_finish()
                 else:
                     if model.grad_sync is not None and model.defer_grad_sync:
                         model.grad_sync.__self__.wait(model)
                     entry['finish'].replay()
-                    if self.snapshot_losses:
-                        snaps[comp.name] = entry['packed_losses'].clone()
-                done = self._events[comp.name] if not self.pipelined else torch.cuda.Event()
-                done.record(stream)
+                    if self.snapshot_losses:                  # one 8-byte-per-loss copy on the lane, no kernel
+                        snap = entry['arena'].snapshot()
+                done = self._event(comp.name).record()
             if entry is None:
-                self._finish_lane(comp.name, done, context['losses'][comp.name], main)
+                self._finish_lane(comp.name, done, context['losses'][comp.name])
                 continue
             if entry['prediction'] is not None:
                 context[comp.selector.pred_label] = entry['prediction']
-            if snaps.get(comp.name) is not None:
-                snap = snaps[comp.name]
-                context['losses'][comp.name] = {
-                    'output_losses': [DeviceScalar(snap[i]) for i in range(len(entry['output_losses']))],
-                    'regularization_loss': DeviceScalar(snap[len(entry['output_losses'])])}
+            if snap is not None:
+                values = [DeviceScalar(snap.t[i]) for i in entry['slot_index']]
             else:                                             # aliases of the static slots: read before the next step()
-                context['losses'][comp.name] = {
-                    'output_losses': [DeviceScalar(t) for t in entry['output_losses']],
-                    'regularization_loss': DeviceScalar(entry['regularization_loss'])}
-            self._finish_lane(comp.name, done, context['losses'][comp.name], main)
+                values = [DeviceScalar(t) for t in entry['output_losses']] + [DeviceScalar(entry['regularization_loss'])]
+            context['losses'][comp.name] = {'output_losses': values[:-1], 'regularization_loss': values[-1]}
+            self._finish_lane(comp.name, done, context['losses'][comp.name])
         return context['losses']
 
     def forward(self, context):
@@ -366,10 +367,6 @@ class PageTrainer:
             self.model_system.predict({**context})
             return context
         rt = CP.runtime()
-        main = torch.cuda.current_stream()
-        if not hasattr(self, '_fwd_start'):
-            self._fwd_start = torch.cuda.Event()
-            self._fwd_done = {c.name: torch.cuda.Event() for c in self.model_system.components}
         # (one graph per net, replayed on the net's lane.  ONE multi-stream graph for the whole step -- the lanes
         # joining the capture through events -- was measured and lost: 0.30 ms per step against 0.17, the
         # branches of a replayed graph do not overlap the way free-running streams do)
@@ -379,28 +376,28 @@ class PageTrainer:
                 comp.model.predict(context[comp.selector.X_label])
             torch.cuda.synchronize()
             for comp in self.model_system.components:
-                with rt.lane(self.lanes[comp.name]) as stream:
+                with rt.lane(self.lanes[comp.name]):
                     X = context[comp.selector.X_label]
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph, stream=stream, capture_error_mode='thread_local'):
+                    with rt.capture(torch.cuda.MemPool()) as graph:
                         pred = comp.model.predict(X)[0]
                     self._fwd_graphs[comp.name], self._fwd_inputs[comp.name], self._fwd_preds[comp.name] = graph, X, pred
-        self._fwd_start.record(main)
+        start = self._event('fwd_start').record()
+        done = {}
         for comp in self._lane_order():
-            with rt.lane(self.lanes[comp.name]) as stream:
-                stream.wait_event(self._fwd_start)
+            with rt.lane(self.lanes[comp.name]):
+                start.wait()
                 X = context[comp.selector.X_label]
                 if self.graphs:
                     static = self._fwd_inputs[comp.name]
                     if X is not static:
-                        static.t.copy_(X.t, non_blocking=True)
+                        rt.call('uocr_d2d', static.ptr, X.ptr, static.nbytes)
                     self._fwd_graphs[comp.name].replay()
                     context[comp.selector.pred_label] = self._fwd_preds[comp.name]
                 else:
                     context[comp.selector.pred_label] = comp.model.predict(X)[0]
-                self._fwd_done[comp.name].record(stream)
+                done[comp.name] = self._event('fwd_' + comp.name).record()
         for comp in self.model_system.components:
-            main.wait_event(self._fwd_done[comp.name])
+            done[comp.name].wait()
         return context
 
 

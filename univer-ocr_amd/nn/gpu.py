@@ -111,12 +111,126 @@ class Runtime:
     def synchronize(self):
         self.call('uocr_stream_sync')
 
+    # -- events and HIP graphs of the C ABI (include/univer_hip.h) ------------------------------------------------
+    def event(self):
+        return Event(self)
+
+    def capture(self, pool=None):
+        """`with rt.capture(pool) as graph:` records the C-ABI calls made inside on the CURRENT ctx's stream into a
+        HIP graph (uocr_graph_begin_capture / uocr_graph_end_capture); `graph.replay()` launches it on the ctx that
+        is current then.  Arrays allocated inside come from `pool` (a torch.cuda.MemPool: memory only -- it keeps the
+        graph's buffers away from every other allocation for as long as the pool lives)."""
+        return _Capture(self, pool)
+
     def device_info(self):
         import ctypes as C
         name = C.create_string_buffer(256)
         cus, hbm = C.c_int(), C.c_size_t()
         self.call('uocr_device_info', name, 256, C.byref(cus), C.byref(hbm))
         return {'name': name.value.decode(), 'cu_count': cus.value, 'hbm_bytes': hbm.value}
+
+
+class Event:
+    """HIP event of the C ABI: record() on the current ctx's stream, wait() = the current ctx's stream waits for it
+    on the device, synchronize() = the host waits."""
+
+    __slots__ = ('rt', 'handle')
+
+    def __init__(self, rt):
+        import ctypes as C
+        self.rt, self.handle = rt, C.c_void_p()
+        if rt.lib.uocr_event_create(C.byref(self.handle)) != 0:
+            raise HipError('uocr_event_create failed')
+
+    def record(self):
+        self.rt.call('uocr_event_record', self.handle)
+        return self
+
+    def wait(self):
+        self.rt.call('uocr_stream_wait_event', self.handle)
+
+    def synchronize(self):
+        if self.rt.lib.uocr_event_synchronize(self.handle) != 0:
+            raise HipError('uocr_event_synchronize failed')
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.rt.lib.uocr_event_destroy(self.handle)
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+class Graph:
+    """An instantiated HIP graph of the C ABI; keeps its memory pool alive."""
+
+    __slots__ = ('rt', 'handle', 'pool')
+
+    def __init__(self, rt, handle, pool):
+        self.rt, self.handle, self.pool = rt, handle, pool
+
+    def replay(self):
+        self.rt.call('uocr_graph_launch', self.handle)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.rt.lib.uocr_graph_destroy(self.handle)
+        except Exception:   # noqa: BLE001
+            pass
+
+
+class _Capture:
+    def __init__(self, rt, pool):
+        self.rt, self.pool, self.graph = rt, pool, None
+
+    def __enter__(self):
+        self._mem = torch.cuda.use_mem_pool(self.pool) if self.pool is not None else None
+        if self._mem is not None:
+            self._mem.__enter__()
+        torch.cuda.synchronize()
+        self.rt.call('uocr_graph_begin_capture')
+        self.graph = Graph(self.rt, None, self.pool)
+        return self.graph
+
+    def __exit__(self, exc_type, exc, tb):
+        import ctypes as C
+        handle = C.c_void_p()
+        try:
+            self.rt.call('uocr_graph_end_capture', C.byref(handle))
+            self.graph.handle = handle
+        except HipError:
+            if exc_type is None:
+                raise
+        finally:
+            if self._mem is not None:
+                self._mem.__exit__(exc_type, exc, tb)
+        return False
+
+
+class LossArena:
+    """Consecutive float64 loss slots in ONE device array: the loss kernels of a captured step write side by side,
+    so one uocr_d2d snapshots all of them (no packing kernel)."""
+
+    def __init__(self, capacity=16):
+        self.array = CP.empty((capacity,), np.float64)
+        self.used = 0
+
+    def take(self):
+        if self.used >= self.array.shape[0]:
+            raise HipError('loss arena full')
+        slot = DeviceArray(self.array.t[self.used:self.used + 1])
+        self.used += 1
+        return slot
+
+    def index_of(self, tensor):
+        return (tensor.data_ptr() - self.array.ptr) // 8
+
+    def snapshot(self):
+        """a copy of the used slots, made on the current ctx's stream"""
+        out = CP.empty((self.used,), np.float64)
+        CP.runtime().call('uocr_d2d', out.ptr, self.array.ptr, 8 * self.used)
+        return out
 
 
 class _Lane:
@@ -281,6 +395,7 @@ class CP:
     is_gpu_used = True
     dtype = np.dtype(os.environ.get('UOCR_DTYPE', 'float32'))
     lazy_losses = False          # True: losses stay on the device until float() is called
+    loss_arena = None            # a LossArena: loss slots come from it (graph capture, my_model/trainer.py)
     f16_grad_scale_log2 = None   # float16 mode: None = the loss kernels pick the gradient scale, int k = 2^k
     _runtime = None
     ops = None                   # set by nn/ops.py (kernel wrappers)
@@ -327,6 +442,13 @@ class CP:
         if torch.cuda.is_available():
             return CP.runtime().device
         return torch.device('cpu')      # storage-only mode (no kernels can run)
+
+    @staticmethod
+    def loss_slot():
+        """one float64 device slot a loss / regularisation kernel writes its value to"""
+        if CP.loss_arena is not None:
+            return CP.loss_arena.take()
+        return CP.empty((1,), np.float64)
 
     # -- allocation -----------------------------------------------------------------------------
     @staticmethod

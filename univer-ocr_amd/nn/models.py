@@ -633,7 +633,7 @@ class Model(BaseModel):
             # neighbouring parameters with the same regulariser are one range of the flat pack
             # (alignment gaps hold zeros and contribute nothing): one launch per range; the first
             # range overwrites the loss slot, so the slot needs no zero-fill launch
-            slot = CP.empty((1,), np.float64)
+            slot = CP.loss_slot()
             for i, ((kind, strength), lo, hi) in enumerate(self._regularizer_ranges()):
                 ops.regularize(kind, self._pack.view_of(self._pack.value, lo, hi - lo, (hi - lo,)),
                                self._pack.view_of(self._pack.grad, lo, hi - lo, (hi - lo,)), strength, slot, i > 0)

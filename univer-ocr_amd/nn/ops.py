@@ -382,7 +382,7 @@ def u8_to_float(src_u8, scale=1.0 / 255.0, dtype=None, out=None):
 
 # ---- losses --------------------------------------------------------------------------------------------
 def _loss_slot():
-    return CP.empty((1,), np.float64)
+    return CP.loss_slot()
 
 
 def _loss_code(pred, gt, grad, kind, n):
