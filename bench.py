@@ -106,6 +106,23 @@ class EventTimer:
         return us
 
 
+    def time_us_rotating(self, fns, reps=12):
+        """mean duration of one call when the calls cycle through `fns` (the same kernel on DIFFERENT buffer sets whose
+        total footprint exceeds the 256 MiB Infinity Cache: every launch reads from HBM, not from the cache the
+        previous launch of the same buffers left behind)"""
+        for fn in fns:
+            fn()
+        self.rt.call('uocr_stream_sync')
+        a, b = self.event(), self.event()
+        self.rt.call('uocr_event_record', a)
+        for i in range(reps):
+            fns[i % len(fns)]()
+        self.rt.call('uocr_event_record', b)
+        us = self.elapsed_ms(a, b) * 1e3 / reps
+        self.pool += [a, b]
+        return us
+
+
 class KernelProbe:
     """HIP-event pairs around every launch of one C-ABI entry point; events are recorded on the stream the
     kernel is launched on (the ctx stream of its lane)."""
@@ -162,7 +179,7 @@ def cpu_baseline(cfg, args, weights, budget_s=25.0):
     from oracle import nn_oracle as O
     from univer_ocr_amd.my_model.synthetic import make_page_batch
     train = cfg['train']
-    sample = 8 if cfg['height'] * cfg['width'] <= 256 * 512 else 1
+    sample = cpu_sample_pages(cfg)
     data = make_page_batch(sample, cfg['height'], cfg['width'], args.char_width, seed=1234)
     warm = make_page_batch(1, 64, 128, args.char_width, seed=1)
     nets = {name: O.make_net(name, {k: v.copy() for k, v in weights[name].items()}) for name in cfg['nets']}
@@ -225,6 +242,28 @@ def cpu_baseline(cfg, args, weights, budget_s=25.0):
     return out
 
 
+def gpu_first_losses(cfg, args, weights, sample):
+    """The first train step of the configuration's nets on the CPU baseline's sample pages (same seed, same initial
+    weights) through the production path on the GPU: ties the timed arithmetic to the oracle's `first_losses`."""
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    from univer_ocr_amd.my_model.trainer import PageTrainer
+    data = make_page_batch(sample, cfg['height'], cfg['width'], args.char_width, seed=1234)
+    small = PageTrainer(sample, cfg['height'], cfg['width'], args.char_width, args.optimizer, args.lr, seed=0,
+                        nets=cfg['nets'], graphs=False, pipelined=False, input_grads=not args.skip_input_grads)
+    for name, model in small.models.items():
+        nested = {}
+        for key, value in weights[name].items():
+            layer, pname = key.rsplit('/', 1)
+            nested.setdefault(layer, {})[pname] = value.tolist()
+        model.set_weights(nested)
+    losses = small.step(small.make_context(data))
+    return {name: float(l['output_losses'][0]) for name, l in losses.items()}
+
+
+def cpu_sample_pages(cfg):
+    return 8 if cfg['height'] * cfg['width'] <= 256 * 512 else 1
+
+
 def secondary_rooflines(rt, timer, watchdog):
     """Kernels north_star prices besides the dominant one, measured alone right after the timed loop:
     the wide Conv2D (3x3, 64 -> 64, batch 32, 256x512: the shape of the ">= 50 % of MFMA peak on Conv2D at batch
@@ -261,34 +300,45 @@ def secondary_rooflines(rt, timer, watchdog):
                     'frac': round(tf / F32_PEAK_TFLOPS, 3), 'launch_us': round(us, 1)})
         watchdog.beat('secondary rooflines')
     del x, y
-    x4 = rand((n, h, w, 4))
-    g4 = rand((n, h, w, 4))
-    lo4 = rand((n, h // 2, w // 2, 4))
-    y4, mask = ops.maxpool2d_fwd(x4, (2, 2), (2, 2), (0, 0))
-    gy4 = rand(y4.shape)
-    p1 = CP.copy(rng.random((n, h, w, 1)).astype(np.float32))
-    t1 = CP.copy((rng.random((n, h, w, 1)) > 0.5).astype(np.float32))
-    logits = CP.copy(rng.standard_normal((2048, 162)).astype(np.float32))
-    onehot = CP.copy(np.eye(162, dtype=np.float32)[rng.integers(0, 162, 2048)])
+    # HBM-bound kernels: SETS distinct buffer sets per kernel (>= 6 x 134 MB per tensor: far beyond the 256 MiB Infinity
+    # Cache), launches cycle through them, so every launch streams its bytes from HBM (round 2 timed back-to-back
+    # launches on ONE set and read cache-assisted rates above what HBM delivers)
+    SETS = 6
     mb = lambda *arrs: sum(a.nbytes for a in arrs)   # noqa: E731
     lazy, CP.lazy_losses = CP.lazy_losses, True
+    sets = []
+    for _ in range(SETS):
+        x4, g4, lo4 = rand((n, h, w, 4)), rand((n, h, w, 4)), rand((n, h // 2, w // 2, 4))
+        y4, mask = ops.maxpool2d_fwd(x4, (2, 2), (2, 2), (0, 0))
+        gy4 = rand(y4.shape)
+        p1 = CP.copy(rng.random((n, h, w, 1)).astype(np.float32))
+        t1 = CP.copy((rng.random((n, h, w, 1)) > 0.5).astype(np.float32))
+        sets.append(dict(x4=x4, g4=g4, lo4=lo4, y4=y4, mask=mask, gy4=gy4, p1=p1, t1=t1))
+    logits = CP.copy(rng.standard_normal((2048, 162)).astype(np.float32))
+    onehot = CP.copy(np.eye(162, dtype=np.float32)[rng.integers(0, 162, 2048)])
+    s0 = sets[0]
     rows = (
-        ('MaxPool2D 2x2 fwd (x -> y + u8 mask)', lambda: ops.maxpool2d_fwd(x4, (2, 2), (2, 2), (0, 0)), mb(x4, y4, mask)),
-        ('MaxPool2D 2x2 bwd (dy, mask -> dx)', lambda: ops.maxpool2d_bwd(gy4, mask, x4.shape, (2, 2), (2, 2), (0, 0)),
-         mb(gy4, mask, x4)),
-        ('Relu fwd', lambda: ops.act_fwd('relu', x4), mb(x4, x4)),
-        ('LeakyRelu bwd from output', lambda: ops.act_bwd_from_output('leaky', x4, g4, 0.01), mb(x4, g4, x4)),
-        ('Upsample2D 2x fwd (4 ch)', lambda: ops.upsample2d_fwd(lo4, (2, 2)), mb(lo4, x4)),
-        ('Dice loss + grad (1 ch, output Sigmoid folded)', lambda: ops.seg_loss('dice', p1, t1, True, out_act='sigmoid'),
-         mb(p1, t1) + mb(t1, p1, p1)),
-        ('SoftmaxCE + grad (2048 x 162)', lambda: ops.softmax_ce(logits, onehot, True), mb(logits, onehot, logits)),
+        ('MaxPool2D 2x2 fwd (x -> y + u8 mask)', lambda s: ops.maxpool2d_fwd(s['x4'], (2, 2), (2, 2), (0, 0)),
+         mb(s0['x4'], s0['y4'], s0['mask'])),
+        ('MaxPool2D 2x2 bwd (dy, mask -> dx)', lambda s: ops.maxpool2d_bwd(s['gy4'], s['mask'], s['x4'].shape, (2, 2), (2, 2), (0, 0)),
+         mb(s0['gy4'], s0['mask'], s0['x4'])),
+        ('Relu fwd', lambda s: ops.act_fwd('relu', s['x4']), mb(s0['x4'], s0['x4'])),
+        ('LeakyRelu bwd from output', lambda s: ops.act_bwd_from_output('leaky', s['x4'], s['g4'], 0.01), mb(s0['x4'], s0['g4'], s0['x4'])),
+        ('Upsample2D 2x fwd (4 ch)', lambda s: ops.upsample2d_fwd(s['lo4'], (2, 2)), mb(s0['lo4'], s0['x4'])),
+        ('Dice loss + grad (1 ch, output Sigmoid folded)', lambda s: ops.seg_loss('dice', s['p1'], s['t1'], True, out_act='sigmoid'),
+         mb(s0['p1'], s0['t1']) + mb(s0['t1'], s0['p1'], s0['p1'])),
     )
     for label, fn, nbytes in rows:
-        us = timer.time_us(fn, 10)
+        us = timer.time_us_rotating([lambda s=s_: fn(s) for s_ in sets], 2 * SETS)
         gbs = nbytes / us / 1e3
         out.append({'kernel': label, 'bound': 'hbm', 'achieved': round(gbs, 0), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(gbs / HBM_PEAK_GBS, 3), 'launch_us': round(us, 1)})
+                    'frac': round(gbs / HBM_PEAK_GBS, 3), 'launch_us': round(us, 1), 'buffer_sets': SETS})
         watchdog.beat('secondary rooflines')
+    us = timer.time_us(lambda: ops.softmax_ce(logits, onehot, True), 10)
+    nbytes = mb(logits, onehot, logits)
+    out.append({'kernel': 'SoftmaxCE + grad (2048 x 162; 4 MB: launch-latency-bound, cache-resident)', 'bound': 'hbm',
+                'achieved': round(nbytes / us / 1e3, 0), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': round(nbytes / us / 1e3 / HBM_PEAK_GBS, 3), 'launch_us': round(us, 1), 'buffer_sets': 1})
     CP.lazy_losses = lazy
     return out
 
@@ -313,30 +363,32 @@ def secondary_rooflines_f16(rt, timer, watchdog, batch, height, width):
 
     def par(shape, s=0.2):
         return CP.copy(rng.standard_normal(shape) * s, np.float32)
-    x4, g2, g4, xl = act((n, h, w, 4)), act((n, h, w, 2)), act((n, h, w, 4)), act((n, h // 2, w // 2, 4))
+    SETS = 4             # 4 x (134 + 67 + 134 + 34 MB): every launch streams from HBM, not from the Infinity Cache
+    sets = [dict(x4=act((n, h, w, 4)), g2=act((n, h, w, 2)), g4=act((n, h, w, 4)), xl=act((n, h // 2, w // 2, 4)))
+            for _ in range(SETS)]
     w42, b2, w44, b4 = par((5, 5, 4, 2)), par((2,)), par((5, 5, 4, 4)), par((4,))
     dw42, db2 = CP.zeros((5, 5, 4, 2), np.float32), CP.zeros((2,), np.float32)
     dw44, db4 = CP.zeros((5, 5, 4, 4), np.float32), CP.zeros((4,), np.float32)
     px = n * h * w
     rows = (
         ('Line end conv 5x5 4->2 + Sigmoid fwd (f16 MFMA, Toeplitz rows)',
-         lambda: ops.conv2d_fwd(x4, w42, b2, (1, 1), (2, 2), 0.0, True, act='sigmoid'), 12 * px),
-        ('Line end conv dx + LeakyReLU mask', lambda: ops.conv2d_bwd_data(g2, w42, x4.shape, (1, 1), (2, 2), x_act=x4,
+         lambda s: ops.conv2d_fwd(s['x4'], w42, b2, (1, 1), (2, 2), 0.0, True, act='sigmoid'), 12 * px),
+        ('Line end conv dx + LeakyReLU mask', lambda s: ops.conv2d_bwd_data(s['g2'], w42, s['x4'].shape, (1, 1), (2, 2), x_act=s['x4'],
                                                                          act='leaky', alpha=0.01), 20 * px),
-        ('Line end conv dw', lambda: ops.conv2d_bwd_weight(x4, g2, dw42, db2, (1, 1), (2, 2), 0.0, True, accumulate=False),
+        ('Line end conv dw', lambda s: ops.conv2d_bwd_weight(s['x4'], s['g2'], dw42, db2, (1, 1), (2, 2), 0.0, True, accumulate=False),
          12 * px),
         ('Line up_1 (upsample 2x + conv 5x5 4->4 + LeakyReLU) fwd',
-         lambda: ops.upconv2x_fwd(xl, w44, b4, (2, 2), True, act='leaky', alpha=0.01), 10 * px),
-        ('Line up_1 dx + LeakyReLU mask', lambda: ops.upconv2x_bwd_data(g4, w44, xl.shape, (2, 2), x_act=xl, act='leaky',
+         lambda s: ops.upconv2x_fwd(s['xl'], w44, b4, (2, 2), True, act='leaky', alpha=0.01), 10 * px),
+        ('Line up_1 dx + LeakyReLU mask', lambda s: ops.upconv2x_bwd_data(s['g4'], w44, s['xl'].shape, (2, 2), x_act=s['xl'], act='leaky',
                                                                        alpha=0.01), 12 * px),
-        ('Line up_1 dw', lambda: ops.upconv2x_bwd_weight(xl, g4, dw44, db4, (2, 2), True, accumulate=False), 10 * px),
+        ('Line up_1 dw', lambda s: ops.upconv2x_bwd_weight(s['xl'], s['g4'], dw44, db4, (2, 2), True, accumulate=False), 10 * px),
     )
     out = []
     for label, fn, nbytes in rows:
-        us = timer.time_us(fn, 10)
+        us = timer.time_us_rotating([lambda s=s_: fn(s) for s_ in sets], 3 * SETS)
         gbs = nbytes / us / 1e3
         out.append({'kernel': f'{label}, {n} x {h} x {w}', 'bound': 'hbm', 'achieved': round(gbs, 0), 'peak': HBM_PEAK_GBS,
-                    'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 3), 'launch_us': round(us, 1)})
+                    'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 3), 'launch_us': round(us, 1), 'buffer_sets': SETS})
         watchdog.beat('secondary rooflines')
     return out
 
@@ -374,6 +426,8 @@ def main():
     ap.add_argument('--option', action='append', default=[],
                     help='kernel selection knob of the C ABI, key=value (uocr_ctx_set_option: split_blocks, split_min, '
                          'gemm_bm, mfma, tiled, xcd_remap); experiments only')
+    ap.add_argument('--steady-steps', type=int, default=300,
+                    help='N = 1: steps of the steady-state measurement after the timed region (0 = off)')
     ap.add_argument('--step-timeout', type=float, default=300.0,
                     help='watchdog: exit with code 3 when no step / phase completes for this many seconds')
     args = ap.parse_args()
@@ -440,7 +494,6 @@ def main():
         return PageTrainer(cfg['batch'], cfg['height'], cfg['width'], args.char_width, args.optimizer, args.lr,
                            seed=0, nets=cfg['nets'], overlap=not args.no_overlap,
                            input_grads=not args.skip_input_grads, graphs=graphs,
-                           eager_nets=('Monochrome',),    # the probed kernel's net stays eager (events in a graph are refused)
                            pipelined=not args.no_pipeline, data_parallel=use_dp,
                            dp_coalesce=args.dp_single_collective, dp_backend=dp_backend,
                            **({'lane_groups': None} if args.lane_per_net else {}))
@@ -462,6 +515,11 @@ def main():
         rt.set_option(key, int(value))          # (every lane)
     watchdog.beat('trainer built')
     initial = flat_weights(trainer.models) if rank == 0 and not args.no_cpu_baseline and world == 1 else None
+    first_gpu = None
+    if initial is not None and train:
+        # the production path on the CPU baseline's sample pages, before anything is timed (compared further down)
+        first_gpu = gpu_first_losses(cfg, args, initial, cpu_sample_pages(cfg))
+        watchdog.beat('first losses on the baseline sample')
     layers = make_page_batch(cfg['batch'], cfg['height'], cfg['width'], args.char_width, seed=1234 + rank)
     context = trainer.make_context(layers)       # inputs resident in HBM before the timed region
     watchdog.beat('inputs resident')
@@ -479,7 +537,9 @@ def main():
     if train:
         probe = KernelProbe(rt, 'uocr_conv_pair_bwd', timer)
         dominant = {'kernel': 'uocr_conv_pair_bwd: fused backward of conv3x3(1->16)+LeakyReLU+conv3x3(16->1)+Sigmoid '
-                              '(Monochrome; conv_pair_bwd_kernel + dx border + finish kernels)',
+                              '(Monochrome; ' + ('pair_strip_bwd_kernel + pair_strip_finish, csrc/conv_pair_strip.hip)'
+                                                 if cfg['dtype'] == 'float32' else
+                                                 'conv_pair_bwd_h_kernel + dx border + finish kernels, csrc/conv_pair.hip)'),
                     'flops': 2.0 * 9 * 16 * n_convs * npix, 'bytes': float(esize) * npix * n_convs}
     else:
         probe = KernelProbe(rt, 'uocr_conv_pair_fwd', timer)
@@ -531,15 +591,51 @@ def main():
         losses = one_step()
         watchdog.beat(f'warm-up step {i}')
     barrier()
-    probe.enabled = True
     t0 = time.perf_counter()
     for i in range(args.steps):
         losses = one_step()
         watchdog.beat(f'timed step {i}')
     barrier()
     elapsed = time.perf_counter() - t0
-    probe.enabled = False
     watchdog.beat('timed region done')
+    # The dominant launch inside the loop: events cannot be recorded into a captured graph on this ROCm, so the timed
+    # region above replays ALL nets from graphs, and here the probed kernel's net runs eagerly for a few more steps
+    # (same arithmetic) with a HIP-event pair around each launch of the entry point, the other lanes as before
+    if train:                                   # (every rank: the steps carry collectives)
+        probed_net = 'Monochrome'
+        if graphs:
+            trainer.set_eager_nets((probed_net,))
+        one_step()
+        barrier()
+        probe.enabled = True
+        for i in range(max(10, min(args.steps, 30))):
+            one_step()
+        barrier()
+        probe.enabled = False
+        if graphs:
+            trainer.set_eager_nets(())
+        watchdog.beat('in-loop probe done')
+
+    # steady state: the driver's run is short (20 steps = 17 ms), so the same loop once more over >= 300 steps in
+    # chunks of 10 with a full synchronisation after each; the median chunk is robust against one slow chunk
+    steady = None
+    if world == 1 and args.steady_steps > 0:
+        chunk, times = 10, []
+        for c in range(max(1, args.steady_steps // chunk)):
+            barrier()
+            c0 = time.perf_counter()
+            for _ in range(chunk):
+                losses = one_step()
+            barrier()
+            times.append((time.perf_counter() - c0) / chunk)
+            watchdog.beat(f'steady-state chunk {c}')
+        times.sort()
+        med = times[len(times) // 2]
+        steady = {'steps': chunk * len(times), 'chunk_steps': chunk,
+                  'ms_per_step_median': round(1e3 * med, 4), 'ms_per_step_mean': round(1e3 * sum(times) / len(times), 4),
+                  'ms_per_step_min': round(1e3 * times[0], 4),
+                  'images_per_s': round(cfg['batch'] / med, 2),
+                  'note': 'measured right after the timed region; every chunk of 10 steps ends with a device synchronisation'}
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -633,10 +729,29 @@ def main():
                                                                        cfg['width'])
             else:
                 out['roofline']['secondary'] = secondary_rooflines(rt, timer, watchdog)
+        if steady is not None:
+            out['steady_state'] = steady
         if world == 1 and not args.no_cpu_baseline:
             watchdog.limit = max(watchdog.limit, 600.0)      # host-only phase: no collective can hang here
             out['cpu_baseline'] = cpu_baseline(cfg, args, initial)
+            if first_gpu is not None and out['cpu_baseline'].get('first_losses'):
+                ref = out['cpu_baseline']['first_losses']
+                rel = {n: abs(first_gpu[n] - ref[n]) / max(1e-30, abs(ref[n])) for n in ref}
+                out['cpu_baseline']['gpu_first_losses'] = {n: round(v, 6) for n, v in first_gpu.items()}
+                out['cpu_baseline']['gpu_vs_cpu_first_loss_rel_diff'] = {n: float(f'{v:.3e}') for n, v in rel.items()}
+                tol = 1e-4 if cfg['dtype'] == 'float32' else 5e-3
+                if max(rel.values()) > tol:
+                    print(f'[bench] the GPU path and the CPU oracle disagree on the first train step of the baseline sample: '
+                          f'{rel} (tolerance {tol}); the timed arithmetic is not the reference\'s -- no result line',
+                          file=sys.stderr, flush=True)
+                    os._exit(4)
+        import math
+        if final and not all(math.isfinite(v) for vs in final.values() for v in vs):
+            out['invalid'] = f'non-finite final losses {final}: the run diverged, the throughput value measures nothing'
+            print('[bench] ' + out['invalid'], file=sys.stderr, flush=True)
         print(json.dumps(out), file=json_out, flush=True)
+        if out.get('invalid'):
+            os._exit(5)
     if trainer.dp is not None:
         watchdog.beat('closing the communicator')
         torch.cuda.synchronize()

@@ -156,8 +156,155 @@ def test_config2_full_size_properties(cin, cout, ks, st, pd):
     assert rel_linf(CP.asnumpy(y)[:1], ref) <= 1e-5
 
 
+# ---- the FUSED production entry points at the benchmarked batch (their grids depend on the batch size) ---------------
+def _dev(a):
+    from univer_ocr_amd.nn import CP
+    return CP.copy(np.ascontiguousarray(a), np.float32)
+
+
+def _np(a):
+    from univer_ocr_amd.nn import CP
+    return CP.asnumpy(a)
+
+
+def _split_check(run, n, exact, summed, exact_tol=0.0):
+    """run(slice) -> dict of host arrays for the images of `slice`.  `exact` keys are per-image results: the batch in
+    two halves gives the same bits (exact_tol > 0: kernels whose depth split -- hence float32 summation order --
+    depends on the number of rows: equal to rounding); `summed` keys are sums over the batch: the halves add up
+    (2e-5: different partial-sum trees)."""
+    whole, lo, hi = run(slice(0, n)), run(slice(0, n // 2)), run(slice(n // 2, n))
+    for key in exact:
+        halves = np.concatenate([lo[key], hi[key]])
+        if exact_tol:
+            err = rel_linf(halves.astype(np.float64), whole[key].astype(np.float64))
+            assert err <= exact_tol, f'{key}: batch halves differ from the whole batch by {err:.2e}'
+        else:
+            assert np.array_equal(halves, whole[key]), f'{key}: batch halves differ from the whole batch'
+    for key in summed:
+        err = rel_linf(lo[key].astype(np.float64) + hi[key].astype(np.float64), whole[key].astype(np.float64))
+        assert err <= 2e-5, f'{key}: halves do not add up ({err:.2e})'
+    return whole
+
+
+def test_config2_pair_kernels_batch32():
+    """uocr_conv_pair_fwd / uocr_conv_pair_bwd (the Monochrome block on the column-strip kernels, csrc/conv_pair_strip.hip)
+    at 32 x 256 x 512: batch-split invariance (y, dx bit for bit; dw1, db1, dw2, db2 to 2e-5) and image 0 against the
+    oracle run layer by layer."""
+    from univer_ocr_amd.hip import lib as hiplib
+    from univer_ocr_amd.nn import CP, ops
+    CP.set_dtype('float32')
+    rng = np.random.default_rng(77)
+    n, h, w = 32, 256, 512
+    X = rng.random((n, h, w, 1)).astype(np.float32)
+    G = rng.standard_normal((n, h, w, 1)).astype(np.float32)
+    w1, b1 = rng.standard_normal((3, 3, 1, 16)) * 0.4, rng.standard_normal(16) * 0.3
+    w2, b2 = rng.standard_normal((3, 3, 16, 1)) * 0.2, rng.standard_normal(1)
+    dws = [_dev(a) for a in (w1, b1, w2, b2)]
+
+    def run(sl):
+        x, g = _dev(X[sl]), _dev(G[sl])
+        y = ops.conv_pair_fwd(x, *dws, act2=hiplib.ACT_SIGMOID)
+        grads = [CP.zeros(a.shape, np.float32) for a in (w1, b1, w2, b2)]
+        dx = ops.conv_pair_bwd(x, y, g, dws[0], dws[1], dws[2], *grads, act2=hiplib.ACT_SIGMOID, accumulate=False)
+        return dict(y=_np(y), dx=_np(dx), dw1=_np(grads[0]), db1=_np(grads[1]), dw2=_np(grads[2]), db2=_np(grads[3]))
+    whole = _split_check(run, n, ('y', 'dx'), ('dw1', 'db1', 'dw2', 'db2'))
+    x0, g0 = X[:1].astype(np.float64), G[:1].astype(np.float64)
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)          # noqa: E731  (the weights the kernel saw)
+    z1 = O.conv2d_fwd(x0, f32(w1), f32(b1), 1, 1, 0.0, True)
+    a1 = O.leaky_relu_fwd(z1, 0.01)
+    z2 = O.conv2d_fwd(a1, f32(w2), f32(b2), 1, 1, 0.0, True)
+    assert rel_linf(whole['y'][:1], O.sigmoid_fwd(z2)) <= 1e-5
+    ga1, _, _ = O.conv2d_bwd(a1, f32(w2), O.sigmoid_bwd(z2, g0), 1, 1, 0.0, True)
+    ref_dx, _, _ = O.conv2d_bwd(x0, f32(w1), O.leaky_relu_bwd(z1, ga1, 0.01), 1, 1, 0.0, True)
+    assert rel_linf(whole['dx'][:1], ref_dx) <= 2e-5
+
+
+@pytest.mark.parametrize('ch', [1, 4])
+def test_config2_upconv_kernels_batch32(ch):
+    """uocr_upconv2x_* (Upsample2D(2) + conv5x5 ch -> ch + LeakyReLU on the low-res tensor: the Paragraph (1 -> 1) and
+    Line (4 -> 4) decoder blocks) at the benchmarked size, low-res 32 x 128 x 256: batch-split invariance and image 0
+    against the oracle's two layers."""
+    from univer_ocr_amd.nn import CP, ops
+    CP.set_dtype('float32')
+    rng = np.random.default_rng(78 + ch)
+    n, hl, wl = 32, 128, 256
+    X = rng.standard_normal((n, hl, wl, ch)).astype(np.float32)
+    G = rng.standard_normal((n, 2 * hl, 2 * wl, ch)).astype(np.float32)
+    wt, b = rng.standard_normal((5, 5, ch, ch)) * 0.2, rng.standard_normal(ch) * 0.1
+    dwt, dbias = _dev(wt), _dev(b)
+
+    def run(sl):
+        x, g = _dev(X[sl]), _dev(G[sl])
+        y = ops.upconv2x_fwd(x, dwt, dbias, (2, 2), True, 'leaky', 0.01)
+        dx = ops.upconv2x_bwd_data(g, dwt, x.shape, (2, 2))
+        dw, db = CP.zeros(wt.shape, np.float32), CP.zeros(b.shape, np.float32)
+        ops.upconv2x_bwd_weight(x, g, dw, db, (2, 2), True, accumulate=False)
+        return dict(y=_np(y), dx=_np(dx), dw=_np(dw), db=_np(db))
+    whole = _split_check(run, n, ('y', 'dx'), ('dw', 'db'))
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)          # noqa: E731
+    up = O.upsample2d_fwd(X[:1].astype(np.float64), (2, 2))
+    pre = O.conv2d_fwd(up, f32(wt), f32(b), 1, 2, 0.0, True)
+    assert rel_linf(whole['y'][:1], O.leaky_relu_fwd(pre, 0.01)) <= 1e-5
+    dup, _, _ = O.conv2d_bwd(up, f32(wt), G[:1].astype(np.float64), 1, 2, 0.0, True)
+    assert rel_linf(whole['dx'][:1], O.upsample2d_bwd(dup, (2, 2))) <= 2e-5
+
+
+def test_config2_windows_dense_batch32():
+    """Conv2DToBatchedFixedWidthed(8) + Flatten + FullyConnected(513 -> 1024) of the Char net as one implicit GEMM
+    (ops.windows_dense_*: split-depth MFMA GEMMs at M = 32 * 64 rows) at the benchmarked batch: batch-split invariance
+    and image 0 against the oracle's three layers."""
+    from univer_ocr_amd.nn import CP, ops
+    CP.set_dtype('float32')
+    rng = np.random.default_rng(79)
+    n, wd, c, n_out = 32, 64, 64, 1024
+    X = rng.standard_normal((n, 1, wd, c)).astype(np.float32)
+    G = rng.standard_normal((n * wd, n_out)).astype(np.float32)
+    W = (rng.standard_normal((8 * c + 1, n_out)) * 0.1).astype(np.float32)
+    dW = _dev(W)
+
+    def run(sl):
+        x = _dev(X[sl])
+        rows = slice(sl.start * wd, sl.stop * wd)
+        g = _dev(G[rows])
+        y = ops.windows_dense_fwd(x, dW, 8, 'leaky', 0.01)
+        dw = CP.zeros(W.shape, np.float32)
+        dx = ops.windows_dense_bwd(x, dW, g, dw, 8, accumulate=False, x_act=x, act='leaky', alpha=0.01)
+        return dict(y=_np(y), dx=_np(dx), dw=_np(dw))
+    # (the MFMA GEMMs split their depth until the chip is full: 16 and 32 strips get different slab counts)
+    whole = _split_check(run, n, ('y', 'dx'), ('dw',), exact_tol=2e-6)
+    windows = O.fixed_width_fwd(X[:1].astype(np.float64), 8)
+    flat = windows.reshape(wd, -1)
+    pre = O.dense_fwd(flat, W.astype(np.float64))
+    assert rel_linf(whole['y'][:wd], np.where(pre >= 0, pre, 0.01 * pre)) <= 1e-5
+    dflat, _ = O.dense_bwd(flat, W.astype(np.float64), G[:wd].astype(np.float64))
+    ref_dx = O.fixed_width_bwd(dflat.reshape(windows.shape), X[:1].shape, 8) * np.where(X[:1] >= 0, 1.0, 0.01)
+    assert rel_linf(whole['dx'][:1], ref_dx) <= 1e-5
+
+
+def test_config2_line_end_dx_batch32():
+    """Backward-data of the Line output conv (5x5, 4 <- 2) with the folded LeakyReLU' of its input, i.e. the default
+    conv_t32_kernel (float32-MFMA Toeplitz rows, csrc/conv_t32.hip) at 32 x 256 x 512: batch-split invariance and image 0
+    against the oracle."""
+    from univer_ocr_amd.nn import CP, ops
+    CP.set_dtype('float32')
+    rng = np.random.default_rng(80)
+    n, h, w = 32, 256, 512
+    A = rng.standard_normal((n, h, w, 4)).astype(np.float32)           # the conv's input = a LeakyReLU output
+    G = rng.standard_normal((n, h, w, 2)).astype(np.float32)
+    wt = (rng.standard_normal((5, 5, 4, 2)) * 0.2).astype(np.float32)
+    dwt = _dev(wt)
+
+    def run(sl):
+        a, g = _dev(A[sl]), _dev(G[sl])
+        return dict(dx=_np(ops.conv2d_bwd_data(g, dwt, a.shape, (1, 1), (2, 2), x_act=a, act='leaky', alpha=0.01)))
+    whole = _split_check(run, n, ('dx',), ())
+    ref, _, _ = O.conv2d_bwd(A[:1].astype(np.float64), wt.astype(np.float64), G[:1].astype(np.float64), 1, 2, 0.0, True)
+    assert rel_linf(whole['dx'][:1], ref * np.where(A[:1] >= 0, 1.0, 0.01)) <= 2e-5
+
+
 def test_config4_high_res_pages_fused_equals_layer_by_layer():
-    """configs[4] geometry (1024x2048 full-page scans; float32 here -- the float16 storage mode is not built):
+    """configs[4] geometry (1024x2048 full-page scans) in float32 (the float16 storage mode of the same configuration:
+    tests/test_gpu_f16.py::test_config4_highres_f16_*):
     the multi-layer kernels (conv pair, upsample+conv on the low-res tensor, loss with the folded Sigmoid)
     against the layer-by-layer kernels on the same weights and pages at full resolution: losses of two train
     steps and the weights after them.  Covers the 64-bit offsets of 2-page batches of 2M-pixel images

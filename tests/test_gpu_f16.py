@@ -351,6 +351,45 @@ def test_config4_highres_f16_train_step_vs_oracle(f16):
         assert gerr <= 1e-2, f'{name}: parameter gradients {gerr:.2e}'
 
 
+def test_config4_highres_f16_batch8_properties(f16):
+    """BASELINE configs[4] at the benchmarked per-GPU batch (8 x 1024 x 2048, float16 storage): the Monochrome net's
+    compute_loss_and_gradients through the production kernels.  The Dice loss and every parameter gradient are sums
+    over independent pages (plus one L2 term per run), so the batch in two halves must add up (float32 / float64
+    summation order only -- the binary16 roundings are per element and identical), predictions must agree bit for bit, and page 0 is checked
+    against the float64 oracle on the binary16-rounded page."""
+    from univer_ocr_amd.my_model.model import NET_MAKERS
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    from univer_ocr_amd.nn.optimizers import Momentum
+    CP = f16
+    data = make_page_batch(8, 1024, 2048, 16, seed=43, char_batch=1)
+    name, X, y = 'Monochrome', data['image'], data['monochrome']
+    net = O.make_net(name)
+    for pn in net.params:
+        net.params[pn] = net.params[pn].astype(np.float32).astype(np.float64)
+
+    def run(sl):
+        model = NET_MAKERS[name](X[sl].shape, Momentum(lr=0.01, momentum=0))
+        model.set_weights(nest(net.params))
+        model.enable_fusion(True)
+        losses = model.compute_loss_and_gradients(CP.copy(X[sl]), CP.copy(y[sl]))
+        assert len(model._pairs_used) == 1
+        return (CP.asnumpy(model.layers_outputs[0]), float(losses['output_losses'][0]),
+                {pn: CP.asnumpy(p.grad).astype(np.float64) for pn, p in model.params().items()})
+    pred, loss, grads = run(slice(0, 8))
+    pa, la, ga = run(slice(0, 4))
+    pb, lb, gb = run(slice(4, 8))
+    _, _, gc = run(slice(0, 2))
+    _, _, gd = run(slice(2, 4))
+    assert np.array_equal(np.concatenate([pa, pb]), pred)
+    assert abs(la + lb - loss) <= 2e-5 * abs(loss)
+    for pn in grads:
+        # every run adds the same L2 term r to the sum over its pages: r = C + D - A, and whole = A + B - r
+        reg = gc[pn] + gd[pn] - ga[pn]
+        assert rel_linf(ga[pn] + gb[pn] - reg, grads[pn]) <= 5e-5, pn
+    ref_pred = net.forward(r16(X[:1]))
+    assert rel_linf(pred[:1].astype(np.float64), ref_pred) <= 3e-3
+
+
 def test_f16_train_steps_track_f32(f16):
     """Three SGD steps of the Line net in float16 mode stay next to the float32 run from the same weights (loss
     within 1e-2 relative, weights within 1e-3 of their magnitude): the master weights are float32, so the

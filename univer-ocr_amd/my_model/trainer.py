@@ -82,6 +82,7 @@ class PageTrainer:
         self._event_rings = {}
         self.eager_nets = tuple(eager_nets)          # nets kept out of the graphs (e.g. to time one kernel)
         self._captured = None
+        self._eager_override = set()
         self._eager_steps = 0
         self._input_buffers = {}
         self.dp = None
@@ -284,6 +285,12 @@ class PageTrainer:
             self.step(context)
         return self
 
+    def set_eager_nets(self, names):
+        """Run these nets with eager launches from now on although they are captured (and back: an empty tuple) --
+        e.g. to bracket one of their kernels with events for a few steps; results are the same."""
+        self.join()
+        self._eager_override = set(names)
+
     def static_inputs(self):
         """{context label: the array the captured graphs read}, or None before capture.  Filling these in
         place (after join()) and passing them to step() avoids the copy into the statics."""
@@ -317,8 +324,9 @@ class PageTrainer:
                 rt.call('uocr_d2d', static.ptr, fresh.ptr, static.nbytes)
                 copied.add((id(fresh), id(static)))
         start = self._event('start').record()
+        captured = {n: e for n, e in self._captured.items() if n not in self._eager_override}
         for comp in comps:
-            entry = self._captured.get(comp.name)
+            entry = captured.get(comp.name)
             with rt.lane(self.lanes[comp.name]):
                 start.wait()
                 if entry is None:                             # eager net
@@ -332,7 +340,7 @@ class PageTrainer:
                     comp.model.grad_sync(comp.model)          # RCCL all-reduce of the flat gradient
         context['losses'] = {}
         for comp in comps:
-            entry, model = self._captured.get(comp.name), comp.model
+            entry, model = captured.get(comp.name), comp.model
             snap = None
             with rt.lane(self.lanes[comp.name]):
                 if entry is None:
