@@ -41,6 +41,8 @@ def main():
     ap.add_argument('--filter', default='')
     ap.add_argument('--option', action='append', default=[])
     ap.add_argument('--dtype', default='float32', help='activation storage (float16: pair rows only)')
+    ap.add_argument('--height', type=int, default=256, help='page height of the pair rows')
+    ap.add_argument('--width', type=int, default=512, help='page width of the pair rows')
     args = ap.parse_args()
     from univer_ocr_amd.nn import CP, ops
     CP.use_gpu(0)
@@ -70,7 +72,7 @@ def main():
         # the fused Monochrome block (csrc/conv_pair.hip): FLOPs of the layer-by-layer algorithm
         # (no recompute counted): fwd 2 convs, bwd dw1 + dw2 + conv_2 dx (+ conv_1 dx)
         from univer_ocr_amd.hip import lib as hiplib
-        n, h, w = args.batch, 256, 512
+        n, h, w = args.batch, args.height, args.width
         x = CP.copy(rng.standard_normal((n, h, w, 1)).astype(np.float32))
         w1 = CP.copy((rng.standard_normal((3, 3, 1, 16)) * 0.3), np.float32)
         w2 = CP.copy((rng.standard_normal((3, 3, 16, 1)) * 0.1), np.float32)

@@ -833,6 +833,11 @@ extern "C" int uocr_conv_pair_bwd(uocr_ctx* ctx, int dtype, const void* x, const
                                        (const float*)b1, (const float*)w2, (float*)dw1, (float*)db1, (float*)dw2,
                                        (float*)db2, (float*)dx, n, h, w, (float)pad_value1, use_bias1, use_bias2,
                                        (float)alpha1, act2 == UOCR_ACT_SIGMOID, accumulate, 1.f);
+    if (UOCR_DTYPE_BASE(dtype) == UOCR_F16 && ctx->opt_pair)
+        return uocr_pair_strip_bwd_f16(ctx, x, y, dy, (const float*)w1, (const float*)b1, (const float*)w2, (float*)dw1,
+                                       (float*)db1, (float*)dw2, (float*)db2, dx, n, h, w, (float)pad_value1, use_bias1,
+                                       use_bias2, (float)alpha1, act2 == UOCR_ACT_SIGMOID, accumulate,
+                                       (float)uocr_grad_unscale(dtype));
     const int strips = (w + RW - 1) / RW, tiles_y = (h + RH - 1) / RH;
     const int rows_per_block = pair_rows_per_block(strips, h, n, RH, dx ? 1024u : 2048u);
     const int bands = (h + rows_per_block - 1) / rows_per_block;

@@ -27,52 +27,12 @@
 #include <type_traits>
 
 #include "conv_pair.h"
+#include "conv_pair_strip.h"
 #include "uocr_common.h"
 
 namespace {
 
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-constexpr int CH = 16;
-constexpr int XROW = 80;      // floats per (ring slot, group) of the x ring: copies tx = 0, 1, 2, ones, dump
-constexpr int GROW = 64;      // ... of the g ring: copies tx = 0, 1, 2, dump
-// d_a1 transpose scratch of a group: [channel quad q][slot f(pos)][4 channels], plane stride TPL = 64 + 8 floats.
-// f sends the positions {0-3, 12-15} to the even and {4-11} to the odd slots: a ds_read_b128 lane group holds exactly
-// those two position sets of two neighbouring quads (MI355X LDS lane groups), so its 16 lanes hit 16 different 16-B
-// slots, and the 32 lanes of a ds_write_b32 group hit 32 different banks (row stride 20 floats: 2- to 3-way conflicts)
-constexpr int TPL = 72;
-constexpr int TRSZ = 4 * TPL;
-__device__ __forceinline__ int tslot(int pos) { return pos < 4 ? 2 * pos : pos >= 12 ? 2 * (pos - 12) + 8 : 2 * (pos - 4) + 1; }
-constexpr int NSLOT = 6;      // rows of the output ring: two batches of three
-constexpr int NPLANE = 3;     // tx = 0, 1, 2 (lane quarter 3 does not store)
-
-template <int G>
-struct Strip {
-    // ring slot strides = 48 mod 64 floats: the three window rows a ds_read_b128 lane group reads (tap rows ty) then
-    // fall on different 16-float bank units ((3 ty + tx) mod 4) instead of on the same one
-    static constexpr int XSLOT = (G * XROW + 63) / 64 * 64 + 48;
-    static constexpr int GSLOT = (G * GROW + 63) / 64 * 64 + 48;
-    static constexpr int XS = 3 * XSLOT;             // x ring [slot][group][XROW]
-    static constexpr int GS = 3 * GSLOT;
-    static constexpr int TR = G * TRSZ;              // one transpose scratch per group
-    static constexpr int WAVE = XS + GS + TR;        // floats of wave-private LDS
-    static constexpr int COLS = 16 * G;              // computed columns per wave
-};
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-template <int P>
-using phase_t = std::integral_constant<int, P>;
-
-// Keeps the MFMAs on either side in program order (everything else may still move across): hipcc otherwise
-// clusters the MFMAs of one accumulator back to back, and a dependent v_mfma_f32_16x16x4_f32 issues every 40
-// cycles instead of every 32 (measured here: 39.6 cycles per MFMA before, rounds of independent accumulators after)
-__device__ __forceinline__ void mfma_round() { __builtin_amdgcn_sched_barrier(0x7F6); }
-
-// partial[block][PAIR_NPART]: dW1^T (16 rows: taps 0..8, row 9 = db1) x 16 channels, dW2^T likewise, db2
-constexpr int PAIR_NPART = 2 * 256 + 1;
+using namespace pair_strip;
 
 // MODE 0: one column block whose computed columns are exactly the image's (w = 64 * waves) and a zero padding
 // value: no position is ever masked.  MODE 1: anything else (halo columns between column blocks, computed columns
@@ -578,18 +538,19 @@ __global__ __launch_bounds__(512) void pair_strip_fwd_kernel(const float* __rest
     }
 }
 
-// Sum of the block partials in float64, fixed order.  Block = 32 consecutive partial columns x 8 segments of the
+// Sum of the block partials in float64, fixed order.  Block = 32 consecutive partial columns x 32 segments of the
 // blocks (coalesced 128-byte reads, 8 loads in flight per thread), segments added in order; then the columns that
 // are outputs (dw1: 9 x 16, db1 = row 9 of dW1^T, dw2, db2) are stored.
-__global__ __launch_bounds__(256) void pair_strip_finish(const float* __restrict__ partial, float* __restrict__ dw1,
+__global__ __launch_bounds__(1024) void pair_strip_finish(const float* __restrict__ partial, float* __restrict__ dw1,
                                                         float* __restrict__ db1, float* __restrict__ dw2,
                                                         float* __restrict__ db2, int nblocks, int use_b1, int use_b2,
                                                         int accumulate, float unscale) {
-    __shared__ double seg[8][32];
+    constexpr int NSEG = 32;
+    __shared__ double seg[NSEG][32];
     const int o = threadIdx.x & 31, sg = threadIdx.x >> 5, j = blockIdx.x * 32 + o;
     double s = 0.0;
     if (j < PAIR_NPART) {
-        const int per = (nblocks + 7) / 8, b0 = sg * per, b1 = min(nblocks, b0 + per);
+        const int per = (nblocks + NSEG - 1) / NSEG, b0 = sg * per, b1 = min(nblocks, b0 + per);
         int b = b0;
         for (; b + 8 <= b1; b += 8) {
             float v[8];
@@ -604,7 +565,7 @@ __global__ __launch_bounds__(256) void pair_strip_finish(const float* __restrict
     __syncthreads();
     if (sg != 0 || j >= PAIR_NPART) return;
 #pragma unroll
-    for (int k = 1; k < 8; ++k) s += seg[k][o];
+    for (int k = 1; k < NSEG; ++k) s += seg[k][o];
     float* dst = nullptr;
     bool live = true;
     if (j < 144) dst = dw1 + j;                                           // dW1^T[tap][ch] = dw1[tap * 16 + ch]
@@ -666,10 +627,7 @@ int strip_bwd_launch(uocr_ctx* ctx, const float* x, const float* y, const float*
     if (dx) rc = sig ? pick(std::true_type{}, std::true_type{}) : pick(std::true_type{}, std::false_type{});
     else rc = sig ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{});
     if (rc != UOCR_OK) return rc;
-    hipLaunchKernelGGL(pair_strip_finish, dim3((PAIR_NPART + 31) / 32), dim3(256), 0, ctx->stream, (const float*)partial, dw1, db1, dw2,
-                       db2, (int)nblocks, use_b1, use_b2, accumulate, unscale);
-    UOCR_LAUNCH_CHECK(ctx);
-    return UOCR_OK;
+    return uocr_pair_strip_finish(ctx, partial, dw1, db1, dw2, db2, (int)nblocks, use_b1, use_b2, accumulate, unscale);
 }
 }  // namespace
 
@@ -707,6 +665,14 @@ int uocr_pair_strip_fwd_f32(uocr_ctx* ctx, const float* x, const float* w1, cons
     else
         hipLaunchKernelGGL((pair_strip_fwd_kernel<G, 1>), dim3(nbx, bands, n), dim3(nw * 64), lds, ctx->stream, x, w1, b1,
                            w2, b2, y, h, w, band_h, pad1, use_b1, use_b2, alpha, act2);
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
+}
+
+int uocr_pair_strip_finish(uocr_ctx* ctx, const float* partial, float* dw1, float* db1, float* dw2, float* db2,
+                           int nblocks, int use_b1, int use_b2, int accumulate, float unscale) {
+    hipLaunchKernelGGL(pair_strip_finish, dim3((PAIR_NPART + 31) / 32), dim3(1024), 0, ctx->stream, partial, dw1, db1, dw2,
+                       db2, nblocks, use_b1, use_b2, accumulate, unscale);
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
 }
