@@ -43,6 +43,7 @@ def main():
     ap.add_argument('--dtype', default='float32', help='activation storage (float16: pair rows only)')
     ap.add_argument('--height', type=int, default=256, help='page height of the pair rows')
     ap.add_argument('--width', type=int, default=512, help='page width of the pair rows')
+    ap.add_argument('--pair-act', default='sigmoid', choices=['sigmoid', 'none'], help='output activation of the pair rows')
     args = ap.parse_args()
     from univer_ocr_amd.nn import CP, ops
     CP.use_gpu(0)
@@ -79,7 +80,7 @@ def main():
         b1, b2 = CP.zeros((16,), np.float32), CP.zeros((1,), np.float32)
         g = CP.copy(rng.standard_normal((n, h, w, 1)).astype(np.float32))
         grads = [CP.zeros(a, np.float32) for a in (w1.shape, (16,), w2.shape, (1,))]
-        sig = hiplib.ACT_SIGMOID
+        sig = hiplib.ACT_SIGMOID if args.pair_act == 'sigmoid' else hiplib.ACT_NONE
         y = ops.conv_pair_fwd(x, w1, b1, w2, b2, act2=sig)
         px, conv = n * h * w, 2.0 * 9 * 16
         for op, fn, nbytes, flop in [

@@ -805,6 +805,9 @@ extern "C" int uocr_conv_pair_fwd(uocr_ctx* ctx, int dtype, const void* x, const
         return uocr_pair_strip_fwd_f32(ctx, (const float*)x, (const float*)w1, (const float*)b1, (const float*)w2,
                                        (const float*)b2, (float*)y, n, h, w, (float)pad_value1, use_bias1, use_bias2,
                                        (float)alpha1, act2);
+    if (UOCR_DTYPE_BASE(dtype) == UOCR_F16 && ctx->opt_pair)
+        return uocr_pair_strip_fwd_f16(ctx, x, (const float*)w1, (const float*)b1, (const float*)w2, (const float*)b2, y, n,
+                                       h, w, (float)pad_value1, use_bias1, use_bias2, (float)alpha1, act2);
     const int strips = (w + RW - 3) / (RW - 2);
     const int rows_per_block = pair_rows_per_block(strips, h, n, RH - 2, 8192u);
     const dim3 grid(strips, (h + rows_per_block - 1) / rows_per_block, n);

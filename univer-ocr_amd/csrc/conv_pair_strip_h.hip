@@ -748,8 +748,261 @@ __global__ __launch_bounds__(256) void pair_wave_bwd_h_kernel(const _Float16* __
 
 }  // namespace
 
+namespace {
+
+// Forward, binary16 storage, independent waves (any width): Z[ch, pos] = W1^T . Xcol with the window registers as the B
+// operand (one MFMA), LeakyReLU on packed binary16, P^T[tap, pos] = W2 . A1^T (one MFMA), the three row shifts of
+// y[p] = b2 + sum_tap P[p + tap - 1, tap] in rolling registers, the three column shifts through the wave's private
+// output rows.  No LDS ring for x (nothing needs 4 consecutive positions here), no barrier, ~12 vector instructions
+// and 2 MFMAs per group of 16 positions (tile kernel: 2 MFMAs + a 9-tap LDS gather per output).
+template <int G>
+__global__ __launch_bounds__(256) void pair_wave_fwd_h_kernel(const _Float16* __restrict__ x, const float* __restrict__ w1,
+                                                              const float* __restrict__ b1,
+                                                              const float* __restrict__ w2,
+                                                              const float* __restrict__ b2, _Float16* __restrict__ y,
+                                                              int h, int wd, int band_h, float pad1, int use_b1,
+                                                              int use_b2, float alpha, int act2, int nstrips) {
+    constexpr int COLS = 16 * G, OUTW = COLS + 2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kq = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = blockDim.x >> 6;
+    float* const outr = lds + wv * 3 * NPLANE * OUTW;               // [3 rows][NPLANE][OUTW], private
+    const int sidx = blockIdx.x * nw + wv;
+    if (sidx >= nstrips) return;                                    // (no barrier anywhere in this kernel)
+    const int wc0 = sidx * (COLS - 2);
+    const bool last_strip = wc0 + COLS >= wd;
+    const int own_lo = wc0 + (sidx > 0 ? 1 : 0);
+    const int own_hi = last_strip ? wd : wc0 + COLS - 1;
+    const bool ragged = wc0 + COLS > wd || pad1 != 0.f;
+    const int r0 = blockIdx.y * band_h, r1 = min(h, r0 + band_h);
+    const size_t img = (size_t)blockIdx.z * h * wd;
+    const _Float16* xb = x + img;
+
+    // Z: A[m = ch n][k = (kq, j)] = W1[tap (j, kq)][n];  P^T: A[m = n][k = ch 4kq + j] = W2[tap(m)][4kq + j], m = 4 tx + ty
+    f16x4 w1a, w2a;
+    f32x4 bias4;
+    {
+        const int txm = n >> 2, tym = n & 3;
+        const bool live = txm < 3 && tym < 3;
+        const int tapu = live ? tym * 3 + txm : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            w1a[j] = (kq < 3 && j < 3) ? (_Float16)w1[(min(j, 2) * 3 + min(kq, 2)) * CH + n] : (_Float16)0.f;
+            w2a[j] = live ? (_Float16)w2[tapu * CH + 4 * kq + j] : (_Float16)0.f;
+            bias4[j] = use_b1 ? b1[4 * kq + j] : 0.f;
+        }
+    }
+    const float bias2 = use_b2 ? b2[0] : 0.f;
+    const f16x2 alpha2 = {(_Float16)alpha, (_Float16)alpha};
+    const int ow_addr = kq * OUTW + 1 + n;
+    const int sh = min(kq, 2) - 1;
+    int xoff[G];
+    uint32_t keep_a[G];                                // a1 is zero outside the image (conv_2's padding)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        xoff[g] = max(wc0 + 16 * g + n + sh, 0) * 2;
+        keep_a[g] = wc0 + 16 * g + n < wd ? 0xFFFFFFFFu : 0u;
+    }
+    const uint32_t xkeep = wc0 + n + sh >= 0 ? 0xFFFFu : 0u;
+    const unsigned row_bytes = (unsigned)wd * 2u;
+    const unsigned y_off = (lane < COLS && wc0 + lane >= own_lo && wc0 + lane < own_hi) ? (unsigned)(wc0 + lane) * 2u : 0x7FFFFFFFu;
+
+    u32x2 xp[G];
+    float rr[G][3];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        xp[g] = u32x2{0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rr[g][j] = 0.f;
+    }
+    auto load_row = [&](int row, uint32_t (&xn)[G]) {
+        const bool in = row >= 0 && row < h;
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(xb + (size_t)min(max(row, 0), h - 1) * wd), 0,
+                                                          in ? row_bytes : 0u, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < G; ++g) xn[g] = __builtin_amdgcn_raw_buffer_load_b16(rx, xoff[g], 0, 0);
+    };
+    auto finish_row = [&](int row, uint32_t (&xn)[G]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            uint32_t xv = xn[g];
+            if (g == 0) xv &= xkeep;
+            if (ragged) {
+                const int cx = wc0 + 16 * g + n + sh;
+                xv = (row >= 0 && row < h && cx >= 0 && cx < wd) ? xv : half_bits(pad1);
+            }
+            xp[g][0] = __builtin_amdgcn_alignbit(xp[g][1], xp[g][0], 16);
+            xp[g][1] = xv;
+        }
+    };
+    for (int i = lane; i < 3 * NPLANE * OUTW; i += 64) outr[i] = 0.f;
+    uint32_t xn[G];
+    {
+        uint32_t xq[3][G];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) load_row(r0 - 2 + j, xq[j]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) finish_row(r0 - 2 + j, xq[j]);
+        load_row(r0 + 1, xn);
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // y[row][c] = act2(b2 + plane1[c] + plane0[c-1] + plane2[c+1]) of the wave's own output rows
+    auto flush_row = [&](int row, int slot) {
+        if (row < r0 || row >= r1) return;
+        const float* o = outr + slot * NPLANE * OUTW + 1 + min(lane, COLS - 1);
+        float v = bias2 + (o[OUTW] + o[-1] + o[2 * OUTW + 1]);
+        if (act2 == UOCR_ACT_SIGMOID) v = __builtin_amdgcn_rcpf(1.f + __expf(-v));         // (binary16 result)
+        const auto rd = __builtin_amdgcn_make_buffer_rsrc(y + img + (size_t)row * wd, 0, row_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), rd, y_off, 0, 0);
+    };
+    auto step = [&](auto ptag, int t) {
+        constexpr int P = decltype(ptag)::value;
+        constexpr int S0 = P, S1 = (P + 1) % 3, S2 = (P + 2) % 3;
+        float cdone[G];
+        if (t >= 0 && t < h && t <= r1) {
+            f32x4 z[G], u[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) z[g] = mfma16(w1a, __builtin_bit_cast(f16x4, xp[g]), bias4);
+            mfma_round();
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                u32x2 a4;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint32_t zb = cvt2h(z[g][2 * r], z[g][2 * r + 1]);
+                    const uint32_t neg = neg_halves(zb);
+                    a4[r] = (neg & mul2h(zb, alpha2)) | (~neg & zb);
+                    if (ragged) a4[r] &= keep_a[g];
+                }
+                u[g] = mfma16(w2a, __builtin_bit_cast(f16x4, a4), zero);
+            }
+            mfma_round();
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                cdone[g] = rr[g][S0] + u[g][2];          // y row t-1 is complete (tap row 2 of a1 row t)
+                rr[g][S1] += u[g][1];
+                rr[g][S2] = u[g][0];
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                cdone[g] = rr[g][S0];
+                rr[g][S2] = 0.f;
+            }
+        }
+        if (kq < 3) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) outr[S0 * NPLANE * OUTW + ow_addr + 16 * g] = cdone[g];     // row t-1
+        }
+        flush_row(t - 2, S2);
+#pragma unroll
+        for (int g = 0; g < G; ++g) asm volatile("" : "+v"(xn[g]));
+        finish_row(t + 2, xn);
+        load_row(t + 3, xn);
+    };
+    const int nsteps = r1 - r0 + 2;                    // t = r0-1 .. r1
+    int t0 = r0 - 1;
+    for (int ss = 0; ss * 3 < nsteps; ++ss, t0 += 3) {
+        step(phase_t<0>{}, t0);
+        step(phase_t<1>{}, t0 + 1);
+        step(phase_t<2>{}, t0 + 2);
+    }
+    flush_row(t0 - 2, 2);
+}
+
+}  // namespace
+
+// binary16 forward of the pair block: independent-wave strips for every width
+int uocr_pair_strip_fwd_f16(uocr_ctx* ctx, const void* x, const float* w1, const float* b1, const float* w2,
+                            const float* b2, void* y, int n, int h, int w, float pad1, int use_b1, int use_b2,
+                            float alpha, int act2) {
+    constexpr int G = 4, COLS = 16 * G;
+    const int nstrips = w <= COLS ? 1 : 1 + (w - COLS + (COLS - 2) - 1) / (COLS - 2);
+    const int nw = std::min(4, nstrips);
+    const int blocks_x = (nstrips + nw - 1) / nw;
+    int bands = 1;
+    {
+        const long resident = 4L * ctx->cu_count;
+        double best = 1e30;
+        for (int b = 1; b <= std::max(1, h / 8); ++b) {
+            const int bh = (h + b - 1) / b;
+            const long blocks = (long)blocks_x * ((h + bh - 1) / bh) * n;
+            const double cost = (double)((blocks + resident - 1) / resident) * (bh + 2);
+            if (cost < best * 0.999) { best = cost; bands = (h + bh - 1) / bh; }
+        }
+        if (ctx->opt_pair_band > 0) bands = (h + ctx->opt_pair_band - 1) / ctx->opt_pair_band;
+    }
+    const int band_h = (h + bands - 1) / bands;
+    bands = (h + band_h - 1) / band_h;
+    UOCR_REQUIRE(ctx, bands <= 65535 && n <= 65535);
+    const size_t lds = sizeof(float) * nw * 3 * NPLANE * (COLS + 2);
+    hipLaunchKernelGGL((pair_wave_fwd_h_kernel<G>), dim3(blocks_x, bands, n), dim3(nw * 64), lds, ctx->stream,
+                       (const _Float16*)x, w1, b1, w2, b2, (_Float16*)y, h, w, band_h, pad1, use_b1, use_b2, alpha, act2,
+                       nstrips);
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
+}
+
+namespace {
+
+// independent-wave launch (images wider than one cooperative block): strips of COLS computed columns every COLS - 2,
+// 4 strips per block, bands so that the blocks make whole rounds of what is resident at once -- a last round that is a
+// tenth full costs a full one.  G = 4: 187 registers, two blocks per CU; G = 2: four.
+template <int G>
+int wave_bwd_launch(uocr_ctx* ctx, const void* x, const void* y, const void* dy, const float* w1, const float* b1,
+                    const float* w2, float* dw1, float* db1, float* dw2, float* db2, void* dx, int n, int h, int w,
+                    float pad1, int use_b1, int use_b2, float alpha, bool sig, int accumulate, float unscale) {
+    using L = StripH<G>;
+    const int nstrips = w <= L::COLS ? 1 : 1 + (w - L::COLS + (L::COLS - 2) - 1) / (L::COLS - 2);
+    const int nw = std::min(4, nstrips);
+    const int blocks_x = (nstrips + nw - 1) / nw;
+    int bands = 1;
+    {
+        const long resident = (G == 4 ? 2L : 4L) * ctx->cu_count;
+        double best = 1e30;
+        for (int b = 1; b <= std::max(1, h / 8); ++b) {
+            const int bh = (h + b - 1) / b;
+            const long blocks = (long)blocks_x * ((h + bh - 1) / bh) * n;
+            const double cost = (double)((blocks + resident - 1) / resident) * (bh + 2);
+            if (cost < best * 0.999) { best = cost; bands = (h + bh - 1) / bh; }
+        }
+        if (ctx->opt_pair_band > 0) bands = (h + ctx->opt_pair_band - 1) / ctx->opt_pair_band;
+    }
+    const int band_h = (h + bands - 1) / bands;
+    bands = (h + band_h - 1) / band_h;
+    const size_t lds = std::max(sizeof(float) * (nw * ((L::XS + L::GS + 3 * G * TWSZ + 3) / 4 * 2 + 3 * NPLANE * (L::COLS + 2)) + G * XROWH / 2),
+                                sizeof(float) * nw * PAIR_NPART);
+    const size_t nblocks = (size_t)blocks_x * bands * n;
+    UOCR_REQUIRE(ctx, bands <= 65535 && n <= 65535);
+    int rc = uocr_need_workspace(ctx, nblocks * PAIR_NPART * sizeof(float));
+    if (rc != UOCR_OK) return rc;
+    float* partial = (float*)ctx->workspace;
+    auto run = [&](auto dxtag, auto sigtag) -> int {
+        constexpr bool D = decltype(dxtag)::value, S = decltype(sigtag)::value;
+        static bool attr_set = false;
+        if (!attr_set) {
+            UOCR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pair_wave_bwd_h_kernel<G, D, S>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((pair_wave_bwd_h_kernel<G, D, S>), dim3(blocks_x, bands, n), dim3(nw * 64), lds, ctx->stream,
+                           (const _Float16*)x, (const _Float16*)y, (const _Float16*)dy, w1, b1, w2, partial, (_Float16*)dx,
+                           h, w, band_h, pad1, use_b1, alpha, nstrips);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
+    };
+    if (dx) rc = sig ? run(std::true_type{}, std::true_type{}) : run(std::true_type{}, std::false_type{});
+    else rc = sig ? run(std::false_type{}, std::true_type{}) : run(std::false_type{}, std::false_type{});
+    if (rc != UOCR_OK) return rc;
+    return uocr_pair_strip_finish(ctx, partial, dw1, db1, dw2, db2, (int)nblocks, use_b1, use_b2, accumulate, unscale);
+}
+
+}  // namespace
+
 // binary16 backward of the pair block on the strip kernels (float32 parameters and gradients; unscale = 2^-k of
-// UOCR_F16_SCALED(k))
+// UOCR_F16_SCALED(k)): one block of cooperating waves where it spans the image (no halo columns at all), independent
+// waves for wider pages
 int uocr_pair_strip_bwd_f16(uocr_ctx* ctx, const void* x, const void* y, const void* dy, const float* w1,
                             const float* b1, const float* w2, float* dw1, float* db1, float* dw2, float* db2,
                             void* dx, int n, int h, int w, float pad1, int use_b1, int use_b2, float alpha,
@@ -758,75 +1011,41 @@ int uocr_pair_strip_bwd_f16(uocr_ctx* ctx, const void* x, const void* y, const v
     using L = StripH<G>;
     const int nw = std::min(8, (w + L::COLS - 1) / L::COLS);
     const int bwc = nw * L::COLS;
-    const int nbx = w <= bwc ? 1 : 1 + (w - bwc + (bwc - 2) - 1) / (bwc - 2);
-    int bands = std::max(1, (ctx->cu_count + n * nbx - 1) / (n * nbx));
+    if (w > bwc) {
+        if (ctx->opt_pair_g == 2)
+            return wave_bwd_launch<2>(ctx, x, y, dy, w1, b1, w2, dw1, db1, dw2, db2, dx, n, h, w, pad1, use_b1, use_b2, alpha,
+                                      sig, accumulate, unscale);
+        return wave_bwd_launch<4>(ctx, x, y, dy, w1, b1, w2, dw1, db1, dw2, db2, dx, n, h, w, pad1, use_b1, use_b2, alpha, sig,
+                                  accumulate, unscale);
+    }
+    int bands = std::max(1, (ctx->cu_count + n - 1) / n);
     if (ctx->opt_pair_band > 0) bands = (h + ctx->opt_pair_band - 1) / ctx->opt_pair_band;
     int band_h = std::min(h, std::max(4, (h + bands - 1) / bands));
     bands = (h + band_h - 1) / band_h;
-    // independent-wave geometry (images wider than one cooperative block): strips of COLS computed columns every
-    // COLS - 2, 2..4 strips per block (the count that leaves the fewest idle wave slots), bands so that the blocks make
-    // whole rounds of what is resident at once (2 blocks per CU) -- a last round that is a tenth full costs a full one
-    const int nstrips = w <= L::COLS ? 1 : 1 + (w - L::COLS + (L::COLS - 2) - 1) / (L::COLS - 2);
-    // 4 waves per block: two resident blocks put two waves on every SIMD (3-wave blocks left a quarter of the SIMD slots
-    // empty: 232 -> see DESIGN.md); narrow images take what they need
-    const int wave_nw = std::min(4, nstrips);
-    const int wave_blocks = (nstrips + wave_nw - 1) / wave_nw;
-    int wave_bands = 1;
-    {
-        const long resident = 2L * ctx->cu_count;
-        double best = 1e30;
-        for (int b = 1; b <= std::max(1, h / 8); ++b) {
-            const int bh = (h + b - 1) / b;
-            const long blocks = (long)wave_blocks * ((h + bh - 1) / bh) * n;
-            const double cost = (double)((blocks + resident - 1) / resident) * (bh + 2);
-            if (cost < best * 0.999) { best = cost; wave_bands = (h + bh - 1) / bh; }
-        }
-        if (ctx->opt_pair_band > 0) wave_bands = (h + ctx->opt_pair_band - 1) / ctx->opt_pair_band;
-    }
-    const int wave_band_h = (h + wave_bands - 1) / wave_bands;
-    wave_bands = (h + wave_band_h - 1) / wave_band_h;
-    const size_t wave_lds = std::max(sizeof(float) * (wave_nw * ((L::XS + L::GS + 3 * G * TWSZ + 3) / 4 * 2 + 3 * NPLANE * (L::COLS + 2)) + G * XROWH / 2),
-                                     sizeof(float) * wave_nw * PAIR_NPART);
-    const size_t nblocks = nbx == 1 ? (size_t)bands * n : (size_t)wave_blocks * wave_bands * n;
-    UOCR_REQUIRE(ctx, bands <= 65535 && wave_bands <= 65535 && n <= 65535);
+    const size_t nblocks = (size_t)bands * n;
+    UOCR_REQUIRE(ctx, bands <= 65535 && n <= 65535);
     int rc = uocr_need_workspace(ctx, nblocks * PAIR_NPART * sizeof(float));
     if (rc != UOCR_OK) return rc;
     float* partial = (float*)ctx->workspace;
     const size_t ring = dx ? sizeof(float) * NSLOT * NPLANE * (bwc + 16) : 0;
     const size_t lds = std::max(sizeof(float) * ((nw * L::WAVE + 1) / 2) + ring, sizeof(float) * nw * PAIR_NPART);
-    auto launch = [&](auto kernel, int bx0, int count) -> int {
+    auto launch = [&](auto kernel) -> int {
         static bool attr_set = false;
         if (!attr_set) {
             UOCR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL(kernel, dim3(count, bands, n), dim3(nw * 64), lds, ctx->stream, (const _Float16*)x,
+        hipLaunchKernelGGL(kernel, dim3(1, bands, n), dim3(nw * 64), lds, ctx->stream, (const _Float16*)x,
                            (const _Float16*)y, (const _Float16*)dy, w1, b1, w2, partial, (_Float16*)dx, h, w, band_h, pad1,
-                           use_b1, alpha, bx0, nbx);
+                           use_b1, alpha, 0, 1);
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     };
-    // one block of cooperating waves spans the image: the cooperative kernel (no halo columns at all); wider images:
-    // independent waves (pair_wave_bwd_h_kernel)
-    const bool exact_end = (nbx - 1) * (bwc - 2) + bwc == w;
+    const bool plain = w == bwc && pad1 == 0.f;
     auto run = [&](auto dxtag, auto sigtag) -> int {
         constexpr bool D = decltype(dxtag)::value, S = decltype(sigtag)::value;
-        if (nbx == 1) {
-            if (pad1 != 0.f || !exact_end) return launch(pair_strip_bwd_h_kernel<G, D, S, 1>, 0, 1);
-            return launch(pair_strip_bwd_h_kernel<G, D, S, 0>, 0, 1);
-        }
-        static bool attr_set = false;
-        if (!attr_set) {
-            UOCR_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pair_wave_bwd_h_kernel<G, D, S>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((pair_wave_bwd_h_kernel<G, D, S>), dim3(wave_blocks, wave_bands, n), dim3(wave_nw * 64), wave_lds,
-                           ctx->stream, (const _Float16*)x, (const _Float16*)y, (const _Float16*)dy, w1, b1, w2, partial,
-                           (_Float16*)dx, h, w, wave_band_h, pad1, use_b1, alpha, nstrips);
-        UOCR_LAUNCH_CHECK(ctx);
-        return UOCR_OK;
+        return plain ? launch(pair_strip_bwd_h_kernel<G, D, S, 0>) : launch(pair_strip_bwd_h_kernel<G, D, S, 1>);
     };
     if (dx) rc = sig ? run(std::true_type{}, std::true_type{}) : run(std::true_type{}, std::false_type{});
     else rc = sig ? run(std::false_type{}, std::true_type{}) : run(std::false_type{}, std::false_type{});
