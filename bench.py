@@ -450,6 +450,7 @@ def main():
     # RCCL shares device buffers between the ranks' processes through dmabuf IPC; the host driver of this pool
     # supports no other mode (without it: hipIpcGetMemHandle: invalid argument)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.setdefault('NCCL_DEBUG', 'WARN')       # RCCL's own warnings go to stderr next to this script's
 
     import torch
     import torch.distributed as dist
@@ -536,11 +537,12 @@ def main():
     esize = 2 if cfg['dtype'] == 'float16' else 4
     if train:
         probe = KernelProbe(rt, 'uocr_conv_pair_bwd', timer)
-        dominant = {'kernel': 'uocr_conv_pair_bwd: fused backward of conv3x3(1->16)+LeakyReLU+conv3x3(16->1)+Sigmoid '
-                              '(Monochrome; ' + ('pair_strip_bwd_kernel + pair_strip_finish, csrc/conv_pair_strip.hip)'
-                                                 if cfg['dtype'] == 'float32' else
-                                                 'conv_pair_bwd_h_kernel + dx border + finish kernels, csrc/conv_pair.hip)'),
-                    'flops': 2.0 * 9 * 16 * n_convs * npix, 'bytes': float(esize) * npix * n_convs}
+        # (the output Sigmoid' is applied by the Dice gradient kernel: the launch reads x and g = dLoss/d(conv_2 output) and
+        # writes dx)
+        dominant = {'kernel': 'uocr_conv_pair_bwd: fused backward of conv3x3(1->16)+LeakyReLU+conv3x3(16->1) (Monochrome; ' +
+                              ('pair_strip_bwd_kernel + pair_strip_finish, csrc/conv_pair_strip.hip)' if cfg['dtype'] == 'float32'
+                               else 'pair_wave_bwd_h_kernel + pair_strip_finish, csrc/conv_pair_strip_h.hip)'),
+                    'flops': 2.0 * 9 * 16 * n_convs * npix, 'bytes': float(esize) * npix * (n_convs - 1)}
     else:
         probe = KernelProbe(rt, 'uocr_conv_pair_fwd', timer)
         dominant = {'kernel': 'uocr_conv_pair_fwd: fused forward of conv3x3(1->16)+LeakyReLU+conv3x3(16->1)+Sigmoid '
@@ -608,10 +610,22 @@ def main():
         one_step()
         barrier()
         probe.enabled = True
-        for i in range(max(10, min(args.steps, 30))):
+        probe_steps = max(10, min(args.steps, 30))
+        if trainer.dp is not None:
+            trainer.dp.profile, dp_before = True, trainer.dp.collectives
+        for i in range(probe_steps):
             one_step()
         barrier()
         probe.enabled = False
+        dp_stats = None
+        if trainer.dp is not None:
+            trainer.dp.profile = False
+            dp_stats = trainer.dp.stats() or {}
+            dp_stats['collectives_per_step'] = round((trainer.dp.collectives - dp_before) / probe_steps, 2)
+            dp_stats['backend'] = trainer.dp.backend
+            ver = ctypes.c_int()
+            if trainer.dp.backend == 'rccl' and rt.lib.uocr_dp_version(ctypes.byref(ver)) == 0:
+                dp_stats['rccl_version'] = ver.value
         if graphs:
             trainer.set_eager_nets(())
         watchdog.beat('in-loop probe done')
@@ -731,6 +745,8 @@ def main():
                 out['roofline']['secondary'] = secondary_rooflines(rt, timer, watchdog)
         if steady is not None:
             out['steady_state'] = steady
+        if train and dp_stats is not None:
+            out['dp'] = dp_stats       # (rank 0's view: per-collective device times of the probe steps)
         if world == 1 and not args.no_cpu_baseline:
             watchdog.limit = max(watchdog.limit, 600.0)      # host-only phase: no collective can hang here
             out['cpu_baseline'] = cpu_baseline(cfg, args, initial)

@@ -301,6 +301,7 @@ int uocr_dp_info(uocr_ctx* ctx, int* rank, int* world /* 0 = no communicator */)
 int uocr_dp_allreduce_sum(uocr_ctx* ctx, void* buf, size_t count, int dtype);
 int uocr_dp_broadcast(uocr_ctx* ctx, void* buf, size_t count, int dtype, int root);
 int uocr_dp_finalize(uocr_ctx* ctx);
+int uocr_dp_version(int* out_version);   /* ncclGetVersion of the RCCL this process bound (e.g. 22703), for run records */
 
 #ifdef __cplusplus
 }

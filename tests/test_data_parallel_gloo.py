@@ -113,6 +113,84 @@ def test_flat_gradient_allreduce_world2(coalesce):
         assert out['sync1'] is False
 
 
+def _split_worker(rank, world, port, results):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from univer_ocr_amd.my_model.model import make_char, make_monochrome
+        from univer_ocr_amd.nn.optimizers import Momentum
+        from univer_ocr_amd.parallel import DataParallel
+
+        mono = make_monochrome((2, 8, 8, 1), Momentum(lr=0.1))
+        char = make_char((1, 32, 8, 1), Momentum(lr=0.1))
+        dp = DataParallel({'Monochrome': mono, 'Char': char}, overlap=True)
+        out = {}
+        node = dp.split_node(char)
+        lo_rel = dp._split[id(char)][1]
+        names = {id(p): n for n, p in char.params().items()}
+        tail = sorted(names[id(p)] for p, off, size in char.pack.entries if off >= lo_rel)
+        head = sorted(names[id(p)] for p, off, size in char.pack.entries if off < lo_rel)
+        out['node'], out['tail'], out['head'] = str(node), tail, head
+        out['mono_unsplit'] = dp.split_node(mono) is None and mono.bucket_hook is None
+        out['tail_share'] = (char.pack.total - lo_rel) / char.pack.total
+        # the hook fires after EVERY node of the backward pass; only the split node issues a collective
+        char.defer_grad_sync = mono.defer_grad_sync = True
+        char.pack.grad.t.fill_(float(10 * (rank + 1)))
+        mono.pack.grad.t.fill_(float(rank + 1))
+        for other in reversed([n for n in char._toposort() if n != node]):
+            char.bucket_hook(char, other)
+        out['quiet'] = dp.collectives
+        sizes = []
+        real = dp.comm.all_reduce
+        dp.comm.all_reduce = lambda arr: (sizes.append(arr.size), real(arr))[1]
+        char.bucket_hook(char, node)                                       # tail out NOW: (10 + 20) / 2 = 15
+        out['after_tail'] = (dp.collectives, float(char.pack.grad.t[-1].item()), float(char.pack.grad.t[0].item()))
+        char.grad_sync(char)                                               # the rest is queued ...
+        mono.grad_sync(mono)
+        dp.wait(mono)                                                      # ... and goes out in construction order
+        dp.wait(char)
+        dp.comm.all_reduce = real
+        out['sizes'] = sizes
+        out['expected'] = [char.pack.total - lo_rel, mono.pack.total, lo_rel]
+        out['final'] = (float(char.pack.grad.t[0].item()), float(char.pack.grad.t[-1].item()), float(mono.pack.grad.t[0].item()))
+        out['drained'] = not dp._queue and not dp._reduced and not dp._tail_done
+        # next step without the hook (a step that does not run the backward through Model.backward): one collective again
+        char.pack.grad.t.fill_(float(rank + 1))
+        sizes2 = []
+        dp.comm.all_reduce = lambda arr: (sizes2.append(arr.size), real(arr))[1]
+        char.grad_sync(char)
+        dp.wait(char)
+        dp.comm.all_reduce = real
+        out['sizes2'], out['whole'] = sizes2, [char.pack.total]
+        results[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_tail_goes_out_early_world2():
+    """Within-net overlap (parallel.DataParallel._bucket): the Char net's dense block -- the tail of its pack, 84 % of its
+    parameters -- is reduced from Model.backward's bucket_hook as soon as it is final, the conv block with the net's
+    regular grad_sync; MEAN semantics on both parts, the same collectives in the same order on both ranks."""
+    if torch.cuda.is_available():
+        pytest.skip('CPU (gloo) rehearsal of the data-parallel logic')
+    world, port = 2, _free_port()
+    with mp.Manager() as manager:
+        results = manager.dict()
+        mp.spawn(_split_worker, args=(world, port, results), nprocs=world, join=True)
+        results = dict(results)
+    assert set(results) == {0, 1}
+    assert results[0]['node'] == results[1]['node'] and results[0]['sizes'] == results[1]['sizes']
+    for out in results.values():
+        assert all('dense' in n for n in out['tail']) and all('conv' in n for n in out['head']), (out['tail'], out['head'])
+        assert out['mono_unsplit'] and out['tail_share'] > 0.8
+        assert out['quiet'] == 0
+        assert out['after_tail'] == (1, 15.0, 10.0 * (out is results[0] and 1 or 2)) or out['after_tail'][:2] == (1, 15.0)
+        assert out['sizes'] == out['expected']
+        assert out['final'] == (15.0, 15.0, 3.0) and out['drained']
+        assert out['sizes2'] == out['whole']
+
+
 def _rank_mean_worker(rank, world, port, results):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)

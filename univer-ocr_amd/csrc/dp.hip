@@ -36,6 +36,7 @@ struct Rccl {
     int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
     char why[256] = {0};
 };
 
@@ -67,6 +68,7 @@ bool load_rccl() {
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
     g_rccl.Broadcast = (decltype(g_rccl.Broadcast))sym("ncclBroadcast");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    g_rccl.GetVersion = (decltype(g_rccl.GetVersion))sym("ncclGetVersion");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce ||
         !g_rccl.Broadcast) {
         snprintf(g_rccl.why, sizeof(g_rccl.why), "librccl.so.1 lacks a required symbol");
@@ -172,6 +174,15 @@ int uocr_dp_finalize(uocr_ctx* ctx) {
     const int r = g_rccl.CommDestroy(c.comm);
     c = Comm{};
     if (r != ncclSuccess) UOCR_FAIL(ctx, UOCR_ERR_RCCL, "ncclCommDestroy failed: %s", rccl_error(r));
+    return UOCR_OK;
+}
+
+int uocr_dp_version(int* out_version) {
+    if (!out_version) return UOCR_ERR_ARG;
+    *out_version = 0;
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!load_rccl()) return UOCR_ERR_RCCL;
+    if (!g_rccl.GetVersion || g_rccl.GetVersion(out_version) != ncclSuccess) return UOCR_ERR_RCCL;
     return UOCR_OK;
 }
 

@@ -119,6 +119,7 @@ _PROTOS = {
 _SPECIAL = {
     'uocr_abi_version': (C.c_int, []),
     'uocr_dp_get_unique_id': (C.c_int, [_vp]),
+    'uocr_dp_version': (C.c_int, [C.POINTER(C.c_int)]),
     'uocr_last_error': (C.c_char_p, [_ctx]),
     'uocr_ctx_get_stream': (C.c_void_p, [_ctx]),
 }

@@ -26,6 +26,17 @@ def make_optimizer(name, lr):
     raise ValueError(f'unknown optimizer {name}')
 
 
+class GraphSequence:
+    """The graphs of one net's forward + loss + backward, in order (two when its gradient tail is reduced early)."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+
+    def replay(self):
+        for part in self.parts:
+            part.replay()
+
+
 class PageTrainer:
     def __init__(self, batch, height=256, width=512, char_width=64, optimizer='sgd', lr=0.0015, seed=0,
                  nets=('Monochrome', 'Paragraph', 'Line', 'Char'), data_parallel=None, overlap=True,
@@ -252,13 +263,32 @@ class PageTrainer:
             labels = (comp.selector.X_label, comp.selector.y_label)
             X, y = (self._static_input(label, context[label]) for label in labels)
             pool = torch.cuda.MemPool()
+            # data parallel, a net whose gradient tail is final early (parallel.DataParallel.split_node: the Char net's
+            # dense block): graph A is cut there, so that the replay can reduce the tail while the rest of A runs
+            split = self.dp.split_node(model) if self.dp is not None else None
+            parts = []
             try:
                 with rt.lane(self.lanes[comp.name]):
                     with torch.cuda.use_mem_pool(pool):
                         arena = CP.loss_arena = LossArena(16)
-                    with rt.capture(pool) as begin:
+                    cap = [rt.capture(pool)]
+                    cap[0].__enter__()
+
+                    def cut(_model, node, cap=cap, parts=parts, split=split):
+                        if node == split:
+                            cap[0].__exit__(None, None, None)
+                            parts.append(cap[0].graph)
+                            cap[0] = rt.capture(pool)
+                            cap[0].__enter__()
+                    model.bucket_hook = cut if split is not None else None
+                    try:
                         model.train_begin(X, y)
                         comp._publish()
+                    finally:
+                        model.bucket_hook = None
+                        cap[0].__exit__(None, None, None)
+                    parts.append(cap[0].graph)
+                    begin = GraphSequence(parts)
                     pending = model._pending_losses
                     with rt.capture(pool) as finish:
                         losses = model.train_finish()
@@ -274,7 +304,7 @@ class PageTrainer:
                                        regularization_loss=losses['regularization_loss'].t,
                                        prediction=context.get(comp.selector.pred_label))
             model.grad_sync = sync
-            del hook                                              # stays off: the backward now lives in the graph
+            model.bucket_hook = hook                              # (eager steps of this net keep reducing the tail early)
         self._captured = captured
 
     def capture(self, context):
@@ -335,9 +365,13 @@ class PageTrainer:
                     comp.model.train_begin(X, y)
                     comp._publish()
                     continue
-                entry['begin'].replay()
+                parts = entry['begin'].parts
+                parts[0].replay()
+                if len(parts) == 2:                           # the gradient tail is final: its all-reduce starts now
+                    comp.model.grad_sync.__self__.tail_ready(comp.model)
+                    parts[1].replay()
                 if comp.model.grad_sync is not None:
-                    comp.model.grad_sync(comp.model)          # RCCL all-reduce of the flat gradient
+                    comp.model.grad_sync(comp.model)          # RCCL all-reduce of the (rest of the) flat gradient
         context['losses'] = {}
         for comp in comps:
             entry, model = captured.get(comp.name), comp.model

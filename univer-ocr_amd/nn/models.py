@@ -303,9 +303,9 @@ class Model(BaseModel):
                 grads_mem.setdefault(node, [None])
             elif node in pairs:                         # dW of both convs and dX of the first in one kernel
                 first, act_a, act_b = pairs[node]
+                folded = act_b is None or act_b in getattr(self, '_loss_folded', ())    # Sigmoid' already in the loss gradient
                 dx = self.layers[node].backward_pair(
-                    incoming(node), self.layers[first], self.layers[act_a],
-                    None if act_b is None else self.layers[act_b])
+                    incoming(node), self.layers[first], self.layers[act_a], None if folded else self.layers[act_b])
                 grads_mem[node] = [None]
                 grads_mem[first] = [dx]
             elif node in pair_first or (node in fused_act and fused_act[node] in pair_first):
@@ -481,14 +481,16 @@ class Model(BaseModel):
             any(a == act_node for _, _, a in getattr(self, '_wins_used', {}).values())
 
     def _foldable_output_sigmoid(self, key):
-        """Model output `key` = a Sigmoid fused into its conv (not a pair kernel, which applies Sigmoid'
-        itself) and consumed by nothing else: its backward can move into the loss-gradient kernel."""
+        """Model output `key` = a Sigmoid fused into its conv (or into a pair kernel) and consumed by nothing else: its
+        backward can move into the loss-gradient kernel (an elementwise, HBM-bound kernel that reads the prediction
+        anyway; the pair backward is bound by vector issue and saves the loads of y and three instructions per
+        position: 181 -> 167 us at 8 x 1024 x 2048 in float16)."""
         from .layers import Sigmoid
         node = self.relations[key][0]
         fused_act = self._fusion[1] if self._fusion else {}
         if isinstance(node, int) or node not in fused_act or not isinstance(self.layers[node], Sigmoid):
             return None
-        if fused_act[node] in getattr(self, '_pairs_used', {}) or len(self.relations_backward.get(node, {})) != 1:
+        if len(self.relations_backward.get(node, {})) != 1:
             return None
         return node
 

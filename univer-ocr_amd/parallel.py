@@ -191,7 +191,8 @@ class _Gloo:
 
 
 class DataParallel:
-    def __init__(self, models, process_group=None, overlap=True, coalesce=False, backend=None, rendezvous=None):
+    def __init__(self, models, process_group=None, overlap=True, coalesce=False, backend=None, rendezvous=None,
+                 split_buckets=True, split_min_elements=100_000):
         self.models = list(models.values()) if isinstance(models, dict) else list(models)
         if not self.models or any(m.pack is None for m in self.models):
             raise RuntimeError('data parallel needs initialised models with a ParamPack')
@@ -206,6 +207,8 @@ class DataParallel:
         self.overlap = overlap
         self.coalesce = coalesce
         self.collectives = 0                     # issued so far (tests, bench diagnostics)
+        self.profile = False                     # True: keep an event triple per collective (see stats())
+        self._prof = []
         self._order = {id(m): i for i, m in enumerate(self.models)}
         self._queue = []                         # (model, "gradient complete" event) of the current step
         self._reduced = {}                       # id(model) -> "reduced" event its lane still has to wait for
@@ -213,9 +216,24 @@ class DataParallel:
         self.comm.broadcast(self.flat_value)     # identical replicas: rank 0's weights
         self._ev_ready = {id(m): self.comm.event() for m in self.models}
         self._ev_done = {id(m): self.comm.event() for m in self.models}
+        # Within-net overlap: a net whose backward finishes the gradients of a large TAIL of its pack early (the Char
+        # net: its dense block holds 84 % of its 801 442 parameters and is differentiated before the three conv layers)
+        # reduces that tail as soon as it is final, while the rest of its backward runs: Model.backward calls
+        # bucket_hook(model, node) after every node
+        self._split = {}                          # id(model) -> (node after whose backward the tail is final, tail offset)
+        self._tail_done = {}                      # id(model) -> "tail reduced" event of the current step
+        self._ev_tail_ready = {}
+        self._ev_tail_done = {}
+        if split_buckets and overlap:
+            for m in self.models:
+                found = self._find_split(m, split_min_elements)
+                if found is not None:
+                    self._split[id(m)] = found
+                    self._ev_tail_ready[id(m)] = self.comm.event()
+                    self._ev_tail_done[id(m)] = self.comm.event()
         for model in self.models:
             model.grad_sync = self._sync
-            model.bucket_hook = None
+            model.bucket_hook = self._bucket if id(model) in self._split else None
 
     # -- one flat value / gradient buffer for all models ------------------------------------------------------------
     def _rehome(self):
@@ -236,11 +254,69 @@ class DataParallel:
     def _view(self, lo, hi):
         return DeviceArray(self.flat_grad.t[lo:hi])
 
+    def _find_split(self, model, min_elements):
+        """(node, offset): once `node` has run in the backward pass, every parameter at pack offsets >= offset has its
+        gradient -- the first such point where that tail is at least `min_elements` and half of the pack."""
+        pack = model.pack
+        where = {id(p): (off, size) for p, off, size in pack.entries}
+        plan = model._plan if getattr(model, '_plan', None) is not None else model._toposort()
+        done, first = set(), min(off for _, off, _ in pack.entries)
+        for node in reversed(plan):
+            layer = model.layers.get(node) if hasattr(model.layers, 'get') else None
+            params = layer.params() if layer is not None else {}
+            if not params:
+                continue
+            done.update(id(p) for p in params.values())
+            lo = pack.total
+            for p, off, size in sorted(pack.entries, key=lambda e: -e[1]):      # grow the tail downwards
+                if id(p) not in done:
+                    break
+                lo = off
+            tail = pack.total - lo
+            if lo > first and tail >= min_elements and 2 * tail >= pack.total:
+                return node, lo
+        return None
+
+    def split_node(self, model):
+        found = self._split.get(id(model))
+        return None if found is None else found[0]
+
+    def _bucket(self, model, node):
+        """bucket_hook of Model.backward: after the split node, reduce the tail of the model's gradient right away (on
+        the communication lane; the call order is the host's program order, the same on every rank)."""
+        found = self._split.get(id(model))
+        if found is None or node != found[0]:
+            return
+        self.tail_ready(model)
+
+    def tail_ready(self, model):
+        """The tail [offset, end) of the model's gradient is final on the CURRENT lane: issue its all-reduce."""
+        lo_rel = self._split[id(model)][1]
+        lo, hi = self._slice[id(model)]
+        ready = self.comm.event() if self.profile else self._ev_tail_ready[id(model)]
+        self.comm.record(ready)
+        with self.comm.comm_lane():
+            self.comm.wait(ready)
+            begin = self.comm.event() if self.profile else None
+            if begin is not None:
+                self.comm.record(begin)
+            self.comm.all_reduce(self._view(lo + lo_rel, hi))
+            self.collectives += 1
+            if begin is not None:
+                end = self.comm.event()
+                self.comm.record(end)
+                self._prof.append((ready, begin, end, hi - lo - lo_rel))
+            if mean_type_loss(model):
+                self.comm.scale(self._view(lo + lo_rel, hi), 1.0 / self.world)
+            done = self._ev_tail_done[id(model)]
+            self.comm.record(done)
+        self._tail_done[id(model)] = done
+
     # -- the step -----------------------------------------------------------------------------------------------------
     def _sync(self, model):
         """Called by the model right after its backward, from the model's lane: the gradient is complete once
         everything enqueued on this lane so far has run."""
-        ev = self._ev_ready[id(model)]
+        ev = self.comm.event() if self.profile else self._ev_ready[id(model)]     # (profiling: events are read later)
         self.comm.record(ev)
         self._queue.append((model, ev))
         if not (self.overlap and model.defer_grad_sync):
@@ -256,6 +332,8 @@ class DataParallel:
         runs = []                                # [(lo, hi, [models])]: neighbours merge when coalescing
         for model, _ in queue:
             lo, hi = self._slice[id(model)]
+            if id(model) in self._tail_done:          # its tail went out from bucket_hook already
+                hi = lo + self._split[id(model)][1]
             if self.coalesce and runs and runs[-1][1] == lo:
                 runs[-1] = (runs[-1][0], hi, runs[-1][2] + [model])
             else:
@@ -265,11 +343,21 @@ class DataParallel:
             for lo, hi, members in runs:
                 for m in members:
                     self.comm.wait(ready[id(m)])
+                begin = self.comm.event() if self.profile else None
+                if begin is not None:
+                    self.comm.record(begin)
                 self.comm.all_reduce(self._view(lo, hi))
                 self.collectives += 1
+                if begin is not None:
+                    end = self.comm.event()
+                    self.comm.record(end)
+                    self._prof.append((ready[id(members[0])], begin, end, hi - lo))
                 for m in members:
                     if mean_type_loss(m):
-                        self.comm.scale(self._view(*self._slice[id(m)]), 1.0 / self.world)
+                        mlo, mhi = self._slice[id(m)]
+                        if id(m) in self._tail_done:
+                            mhi = mlo + self._split[id(m)][1]
+                        self.comm.scale(self._view(mlo, mhi), 1.0 / self.world)
                 done = self._ev_done[id(members[-1])]
                 self.comm.record(done)
                 for m in members:
@@ -281,6 +369,33 @@ class DataParallel:
         done = self._reduced.pop(id(model), None)
         if done is not None:
             self.comm.wait(done)
+        tail = self._tail_done.pop(id(model), None)
+        if tail is not None:
+            self.comm.wait(tail)
+
+    def stats(self):
+        """Profile mode: per-collective device times from the events kept since `profile` was switched on --
+        allreduce = first to last instruction of the collective on the communication lane, lane_wait = from "gradient
+        complete" on the net's lane to "reduced" (what the net's optimizer tail waits for).  Synchronises."""
+        import ctypes as C
+        rows = []
+        lib = getattr(getattr(self.comm, 'rt', None), 'lib', None)
+        for ready, begin, end, count in self._prof:
+            if lib is None or begin is None:
+                continue
+            a, w = C.c_float(), C.c_float()
+            if lib.uocr_event_elapsed_ms_sync(begin, end, C.byref(a)) == 0 and \
+                    lib.uocr_event_elapsed_ms_sync(ready, end, C.byref(w)) == 0:
+                rows.append((a.value * 1e3, w.value * 1e3, count))
+        self._prof = []
+        if not rows:
+            return None
+        return {'collectives_timed': len(rows),
+                'allreduce_us_mean': round(sum(r[0] for r in rows) / len(rows), 1),
+                'allreduce_us_max': round(max(r[0] for r in rows), 1),
+                'lane_wait_us_mean': round(sum(r[1] for r in rows) / len(rows), 1),
+                'lane_wait_us_max': round(max(r[1] for r in rows), 1),
+                'elements_mean': int(sum(r[2] for r in rows) / len(rows))}
 
     def replicas_in_sync(self, model, tol=0.0):
         """Debug check: every rank holds the same weights (host-side compare over torch.distributed)."""
@@ -296,4 +411,5 @@ class DataParallel:
     def close(self):
         for model in self.models:
             model.grad_sync = None
+            model.bucket_hook = None
         self.comm.close()
