@@ -260,6 +260,15 @@ def gpu_first_losses(cfg, args, weights, sample):
     return {name: float(l['output_losses'][0]) for name, l in losses.items()}
 
 
+def parse_xcds(spec):
+    """'0-2,3-5,6-7' -> ((0, 1, 2), (3, 4, 5), (6, 7))"""
+    groups = []
+    for part in spec.split(','):
+        lo, _, hi = part.partition('-')
+        groups.append(tuple(range(int(lo), int(hi or lo) + 1)))
+    return tuple(groups)
+
+
 def cpu_sample_pages(cfg):
     return 8 if cfg['height'] * cfg['width'] <= 256 * 512 else 1
 
@@ -423,6 +432,8 @@ def main():
                     help='upload every batch as uint8 from pinned host memory on a copy stream and convert on the '
                          'device (PCIe-inclusive rate; flagged in metric and config, never the headline value)')
     ap.add_argument('--lane-per-net', action='store_true', help='one lane per net instead of the balanced groups')
+    ap.add_argument('--lane-xcds', default=None,
+                    help='EXPERIMENT: CU-partitioned lanes, XCDs per lane group, e.g. "0-2,3-5,6-7" (Monochrome+Paragraph | Line | Char)')
     ap.add_argument('--option', action='append', default=[],
                     help='kernel selection knob of the C ABI, key=value (uocr_ctx_set_option: split_blocks, split_min, '
                          'gemm_bm, mfma, tiled, xcd_remap); experiments only')
@@ -497,7 +508,8 @@ def main():
                            input_grads=not args.skip_input_grads, graphs=graphs,
                            pipelined=not args.no_pipeline, data_parallel=use_dp,
                            dp_coalesce=args.dp_single_collective, dp_backend=dp_backend,
-                           **({'lane_groups': None} if args.lane_per_net else {}))
+                           **({'lane_groups': None} if args.lane_per_net else {}),
+                           **({'lane_xcds': parse_xcds(args.lane_xcds)} if args.lane_xcds else {}))
     dp_fallback = None
     try:
         trainer = build_trainer('gloo' if rehearsal else None)

@@ -64,6 +64,11 @@ enum {
 /* ---- context, memory, events (stand in for CP / cupy, gpu.py:5-29) ------------------------- */
 int uocr_abi_version(void);
 int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out);
+/* a context whose own stream runs on a subset of the compute units (hipExtStreamCreateWithCUMask; bit i of the mask =
+ * compute unit i in the driver's numbering, which deals consecutive bits round-robin over the 8 XCDs of an MI355X: bits
+ * with i % 8 in a set = those whole XCDs).  Independent nets trained on concurrent lanes (PageTrainer) can be given
+ * disjoint partitions; kernels that size their grid by the CU count use the partition's. */
+int uocr_ctx_create_cu_mask(int device, size_t workspace_bytes, const uint32_t* cu_mask, int mask_words, uocr_ctx** out);
 int uocr_ctx_destroy(uocr_ctx* ctx);
 /* run on a caller-owned hipStream_t (0 = the legacy default stream) instead of the ctx's own */
 int uocr_ctx_set_stream(uocr_ctx* ctx, void* hip_stream);

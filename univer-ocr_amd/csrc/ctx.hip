@@ -29,7 +29,6 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->opt_t32 = 2;    // measured: only the 4-channel backward-data beats its vector kernel in the step (conv_t32.hip,
                          // conv_t32w.hip: bits 64 / 128 = the float32-MFMA weight gradients, 37.0 -> 36.1 k images/s with both)
     ctx->opt_xcd = 1;
-    ctx->opt_pair = 1;
     ctx->opt_pair_band = 0;
     ctx->opt_pair_g = 4;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -48,6 +47,25 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
         ctx->workspace_bytes = workspace_bytes;
     }
     *out = ctx;
+    return UOCR_OK;
+}
+
+int uocr_ctx_create_cu_mask(int device, size_t workspace_bytes, const uint32_t* cu_mask, int mask_words, uocr_ctx** out) {
+    if (!out || !cu_mask || mask_words <= 0) return UOCR_ERR_ARG;
+    int rc = uocr_ctx_create(device, workspace_bytes, out);
+    if (rc != UOCR_OK) return rc;
+    uocr_ctx* ctx = *out;
+    hipStream_t masked = nullptr;
+    if (hipExtStreamCreateWithCUMask(&masked, (uint32_t)mask_words, cu_mask) != hipSuccess) {
+        uocr_ctx_destroy(ctx);
+        *out = nullptr;
+        return UOCR_ERR_HIP;
+    }
+    hipStreamDestroy(ctx->stream);
+    ctx->stream = masked;
+    int cus = 0;
+    for (int i = 0; i < mask_words; ++i) cus += __builtin_popcount(cu_mask[i]);
+    if (cus > 0 && cus < ctx->cu_count) ctx->cu_count = cus;     // grids of persistent kernels follow the partition
     return UOCR_OK;
 }
 
@@ -84,7 +102,6 @@ int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "xcd_remap")) ctx->opt_xcd = value;
     else if (!strcmp(key, "h16")) ctx->opt_h16 = value;
     else if (!strcmp(key, "t32")) ctx->opt_t32 = value;
-    else if (!strcmp(key, "pair")) ctx->opt_pair = value;
     else if (!strcmp(key, "pair_band")) ctx->opt_pair_band = value;
     else if (!strcmp(key, "pair_g")) ctx->opt_pair_g = value;
     else UOCR_FAIL(ctx, UOCR_ERR_ARG, "unknown option '%s'", key);

@@ -23,7 +23,6 @@ struct uocr_ctx {
     int opt_bm;          // 0 = choose the MFMA GEMM row tile automatically, 64 / 128 = force it (experiments)
     int opt_h16;         // 1 = binary16-MFMA kernels for the small-channel convs in UOCR_F16 mode (default)
     int opt_t32;         // float32 vertical-Toeplitz MFMA kernels for the small-channel convs: bit 0 forward, bit 1 backward-data
-    int opt_pair;        // fused Monochrome block, float32: 1 = column-strip kernels (conv_pair_strip.hip, default), 0 = tile kernels
     int opt_pair_band;   // rows per band of the strip kernels (0 = about one block per CU)
     int opt_pair_g;      // groups of 16 columns per wave of the strip kernels: 4 (8 waves per block) or 2 (16 waves)
     char err[512];

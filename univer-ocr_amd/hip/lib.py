@@ -46,6 +46,7 @@ _ctx = C.c_void_p
 # name -> argument types (after the implicit return type int)
 _PROTOS = {
     'uocr_ctx_create': [_i, _sz, C.POINTER(_ctx)],
+    'uocr_ctx_create_cu_mask': [_i, _sz, C.POINTER(C.c_uint32), _i, C.POINTER(_ctx)],
     'uocr_ctx_destroy': [_ctx],
     'uocr_ctx_set_stream': [_ctx, _vp],
     'uocr_ctx_reserve_workspace': [_ctx, _sz],

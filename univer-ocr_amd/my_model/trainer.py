@@ -43,7 +43,7 @@ class PageTrainer:
                  dp_coalesce=False, dp_backend=None,
                  init='kaiming_normal', fuse=True, lanes=True, input_grads=True, graphs=False, eager_nets=(), pipelined=False,
                  snapshot_losses=True,
-                 lane_groups=(('Monochrome', 'Paragraph'), ('Line',), ('Char',))):
+                 lane_groups=(('Monochrome', 'Paragraph'), ('Line',), ('Char',)), lane_xcds=None):
         np.random.seed(seed)                        # kaiming_uniform draws from the NumPy global RNG
         self.batch = batch
         self.optimizer = make_optimizer(optimizer, lr)
@@ -68,10 +68,11 @@ class PageTrainer:
             # a time, and with 4 lanes the 5th stream that has work (main in the joined mode, RCCL's stream
             # under data parallelism) gets time-sliced against them (1.3 -> 2.6 ms/step measured)
             self.lanes = {}
-            for group in lane_groups or [(name,) for name in self.models]:
+            # lane_xcds: one tuple of XCD numbers per lane group -- CU-partitioned lanes (uocr_ctx_create_cu_mask)
+            for gi, group in enumerate(lane_groups or [(name,) for name in self.models]):
                 members = [name for name in group if name in self.models]
                 if members:
-                    lane = rt.add_lane()
+                    lane = rt.add_lane(xcds=None if not lane_xcds else lane_xcds[gi])
                     self.lanes.update({name: lane for name in members})
             for name in self.models:                   # nets not named in any group: a lane each
                 if name not in self.lanes:

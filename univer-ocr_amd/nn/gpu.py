@@ -61,12 +61,27 @@ class Runtime:
         self._lanes = [(self.ctx, self.stream)]      # lane 0 = the main stream
 
     # -- lanes: extra (context, stream) pairs so independent models run concurrently ---------------
-    def add_lane(self, workspace_mb=256, priority=0):
+    def add_lane(self, workspace_mb=256, priority=0, xcds=None):
         """A further HIP context of the library with its own stream and workspace.  The four my_model
         nets are independent, so each trains on its own lane: the latency-bound kernels of the small
-        nets run under the bandwidth-bound kernels of the large ones."""
+        nets run under the bandwidth-bound kernels of the large ones.
+        xcds: an iterable of XCD numbers (0..7) -- the lane's stream is created by the library on those XCDs only
+        (uocr_ctx_create_cu_mask); torch merely wraps it (ExternalStream) for its allocator's bookkeeping."""
         import ctypes as C
         handle = C.c_void_p()
+        if xcds is not None:
+            cus = self.device_info()['cu_count']
+            words = (cus + 31) // 32
+            mask = (C.c_uint32 * words)()
+            for i in range(cus):
+                if i % 8 in set(xcds):
+                    mask[i // 32] |= 1 << (i % 32)
+            rc = self.lib.uocr_ctx_create_cu_mask(self.device_index, int(workspace_mb) << 20, mask, words, C.byref(handle))
+            if rc != 0:
+                raise HipError(f'uocr_ctx_create_cu_mask (lane on XCDs {sorted(set(xcds))}) failed with code {rc}')
+            stream = torch.cuda.ExternalStream(self.lib.uocr_ctx_get_stream(handle), device=self.device)
+            self._lanes.append((handle, stream))
+            return len(self._lanes) - 1
         rc = self.lib.uocr_ctx_create(self.device_index, int(workspace_mb) << 20, C.byref(handle))
         if rc != 0:
             raise HipError(f'uocr_ctx_create (lane) failed with code {rc}')
