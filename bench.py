@@ -26,7 +26,6 @@ import ctypes
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -48,30 +47,6 @@ CONFIGS = {
 }
 FEEDS = {'Monochrome': ('image', 'monochrome'), 'Paragraph': ('monochrome', 'paragraph'),
          'Line': ('monochrome', 'line'), 'Char': ('char_lines', 'char_labels')}
-
-
-class Watchdog(threading.Thread):
-    """Multi-rank runs can only hang in a collective or a rendezvous; a hung run would burn the driver's whole
-    timeout.  The main thread calls beat() after every step and phase; if nothing beats for `limit` seconds the
-    process says where it was and exits non-zero (never re-execs: the GPU is initialised)."""
-
-    def __init__(self, limit, rank):
-        super().__init__(daemon=True)
-        self.limit, self.rank = limit, rank
-        self.last, self.where = time.monotonic(), 'start'
-        self.start()
-
-    def beat(self, where):
-        self.last, self.where = time.monotonic(), where
-
-    def run(self):
-        while True:
-            time.sleep(1.0)
-            idle = time.monotonic() - self.last
-            if idle > self.limit:
-                print(f'[bench watchdog] rank {self.rank}: no progress for {idle:.0f} s in "{self.where}" '
-                      f'(limit {self.limit:.0f} s): giving up', file=sys.stderr, flush=True)
-                os._exit(3)
 
 
 class EventTimer:
@@ -473,7 +448,8 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit('--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
         args.gpus = world
-    watchdog = Watchdog(args.step_timeout, rank)
+    from univer_ocr_amd.watchdog import Watchdog
+    watchdog = Watchdog(args.step_timeout, rank, 'bench watchdog')
     graphs = not args.no_graphs
     # UOCR_BENCH_REHEARSAL=1: several ranks on ONE card, gradients through gloo staged over the host
     # (parallel.DataParallel(backend='gloo')) -- exercises this file's multi-rank path where RCCL would refuse

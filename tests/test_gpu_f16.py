@@ -291,6 +291,23 @@ def test_seg_loss_f16_needs_the_scale_at_page_size(f16):
     assert scaled_err <= TOL_STORE < plain_err, (scaled_err, plain_err)
 
 
+def test_seg_loss_f16_gradient_saturates_instead_of_overflowing(f16):
+    """A sparse channel early in training: three positive label pixels and a prediction of almost nothing on a
+    1024 x 2048 page.  Without the folded Sigmoid the Dice gradient is ~2 / (sum p + sum g); times the static 2^17 scale
+    it exceeds binary16's largest number.  The loss kernels clamp to +-65504 (an inf would turn dw and the weights
+    into NaN on the next step); the loss value itself is exact."""
+    from univer_ocr_amd.nn import ops
+    CP = f16
+    pred = np.full((1, 1024, 2048, 1), 1e-7)
+    gt = np.zeros_like(pred)
+    gt[0, 5, 7, 0] = gt[0, 600, 900, 0] = gt[0, 1023, 2047, 0] = 1.0
+    loss, grad = ops.seg_loss('dice', CP.copy(pred), CP.copy(gt), True)
+    g = CP.asnumpy(grad).astype(np.float64)
+    assert grad.gscale == 17 and np.all(np.isfinite(g))
+    assert np.max(np.abs(g)) == 65504.0                   # saturated, where the unclamped value is 2^17 * O(1)
+    assert np.isfinite(float(loss))
+
+
 def nest(flat):
     out = {}
     for key, value in flat.items():

@@ -11,6 +11,19 @@
 
 namespace {
 
+// store a gradient value: binary16 saturates at its largest finite number instead of overflowing to inf (the power-of-two
+// gradient scale of UOCR_F16 is static; a sparse channel early in training can exceed 65504 / 2^k -- an inf would
+// become NaN in dw and in the weights)
+template <typename T, typename V>
+__device__ __forceinline__ T grad_store(V v) {
+    if constexpr (std::is_same<T, _Float16>::value) {
+        const float f = (float)v;
+        return (T)fminf(fmaxf(f, -65504.f), 65504.f);
+    } else {
+        return (T)v;
+    }
+}
+
 constexpr double SEG_EPS = 1e-8;   // losses.py:17,36
 
 template <typename T, int V>
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(256) void seg_grad_kernel(const T* __restrict__ pre
                 }
                 VecOf<T, V> out;
 #pragma unroll
-                for (int k = 0; k < V; ++k) out.v[k] = (T)r[k];
+                for (int k = 0; k < V; ++k) out.v[k] = grad_store<T>(r[k]);
                 o4[q] = out;
             }
             p1 = p0;
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(256) void seg_grad_kernel(const T* __restrict__ pre
             const double pv = (double)pred[idx];
             r *= pv * (1.0 - pv);
         }
-        grad[idx] = (T)r;
+        grad[idx] = grad_store<T>(r);
     }
 }
 
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(256) void seg_grad_vec_kernel(const T* __restrict__
         }
         VecOf<T, V> out;
 #pragma unroll
-        for (int k = 0; k < V; ++k) out.v[k] = (T)r[k];
+        for (int k = 0; k < V; ++k) out.v[k] = grad_store<T>(r[k]);
         o4[q] = out;
     }
 }
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const T* __restrict__ p
         if (gv != CT(0)) loss -= (double)(gv * (z - lse));
         if (grad && live) {
             const CT e = std::is_same<CT, float>::value ? (CT)expf((float)z) : (CT)exp((double)z);
-            grad[(size_t)row * c + j] = (T)((e * inv - gv) * scale);
+            grad[(size_t)row * c + j] = grad_store<T>((e * inv - gv) * scale);
         }
     }
 #pragma unroll
@@ -361,7 +374,7 @@ __global__ __launch_bounds__(256) void sigmoid_ce_kernel(const T* __restrict__ p
         const double x = (double)pred[idx], g = (double)gt[idx];
         const double p = 1.0 / (1.0 + exp(-x));
         acc -= g * log(p) + (1.0 - g) * log(1.0 - p);
-        if (grad) grad[idx] = (T)((g * (p - 1.0) + (1.0 - g) * p) * inv_m * gscale);
+        if (grad) grad[idx] = grad_store<T>((g * (p - 1.0) + (1.0 - g) * p) * inv_m * gscale);
     }
     acc = block_reduce_sum(acc, smem);
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;

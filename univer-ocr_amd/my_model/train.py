@@ -77,6 +77,7 @@ def train_model(use_gpu=True, show_progress_bar=False, save_train_progress=False
     train_set = SyntheticPages(batch, height, width, seed=1234 + 1000 * rank, length=4)
     val_set = SyntheticPages(batch, height, width, seed=9999 + 1000 * rank, length=2)
     results = {}
+    watchdog = None
     for mode, lr, lr_step, epochs in stages:
         epochs = max(1, int(round(epochs * scale)))
         message(f'Training mode: {mode.name}')
@@ -97,10 +98,13 @@ def train_model(use_gpu=True, show_progress_bar=False, save_train_progress=False
         dp = None
         if world > 1:
             from ..parallel import DataParallel
+            from ..watchdog import Watchdog
+            if watchdog is None:                  # a rank stuck in a collective must not hang the whole job silently
+                watchdog = Watchdog(float(os.environ.get('UOCR_STEP_TIMEOUT', '600')), rank, 'train watchdog')
             # rank 0's weights everywhere; UOCR_DP_BACKEND=gloo: several ranks on one card (rehearsal)
             dp = DataParallel(models, overlap=False, backend=dp_backend or os.environ.get('UOCR_DP_BACKEND'))
         trainer = Trainer(model_system, make_context_maker(mode), models, train_set, val_set, tracker,
-                          show_progress_bar, optimizer, lr_step, save_weights, data_parallel=dp)
+                          show_progress_bar, optimizer, lr_step, save_weights, data_parallel=dp, watchdog=watchdog)
         results[mode.name] = trainer.train(epochs)
         if dp is not None:
             dp.close()

@@ -511,7 +511,7 @@ class Trainer:
 
     def __init__(self, model_system, make_context_func, models, train_dataset, validation_dataset,
                  progress_tracker=None, show_progress_bar=False, optimizer=None, learning_rate_step=0.995,
-                 save_weights_func=None, save_pictures_func=None, data_parallel=None):
+                 save_weights_func=None, save_pictures_func=None, data_parallel=None, watchdog=None):
         from ..nn.progress_tracker import BaseProgressTracker
         self.model_system, self.make_context_func, self.models = model_system, make_context_func, models
         self.train_dataset, self.validation_dataset = train_dataset, validation_dataset
@@ -525,6 +525,7 @@ class Trainer:
         # averaged over the ranks so that every rank also takes the same "better weights" decisions, and only
         # rank 0 writes model_weights.json
         self.dp = data_parallel
+        self.watchdog = watchdog                     # watchdog.Watchdog or None: beaten after every iteration
 
     def _rank_mean(self, losses):
         """Average the normalised epoch losses over the ranks (host side, a few floats per epoch)."""
@@ -534,7 +535,7 @@ class Trainer:
         for table in (losses.train_losses, losses.val_losses):
             names = sorted(table)
             flat = torch.tensor([v for n in names for v in table[n]], dtype=torch.float64)
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=getattr(self.dp, 'group', None))
             flat /= self.dp.world
             it = iter(flat.tolist())
             for n in names:
@@ -552,6 +553,8 @@ class Trainer:
             if self.save_pictures_func is not None:
                 self.save_pictures_func(epoch, stage, i, context)
             self.progress_tracker.message(f'{stage}_iteration', {'current': i + 1, 'total': len(order)})
+            if self.watchdog is not None:
+                self.watchdog.beat(f'epoch {epoch} {stage} iteration {i + 1}')
 
     def train(self, num_epochs):
         from random import shuffle

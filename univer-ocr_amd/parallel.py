@@ -55,7 +55,8 @@ def torch_rendezvous(id_bytes, group=None):
         raise RuntimeError('no rendezvous: initialise torch.distributed (torch.distributed.run + '
                            'init_process_group("gloo")) or pass rendezvous=callable to DataParallel')
     box = [id_bytes]
-    dist.broadcast_object_list(box, src=0, group=group)
+    src = dist.get_global_rank(group, 0) if group is not None else 0      # rank 0 OF THE GROUP, as a global rank
+    dist.broadcast_object_list(box, src=src, group=group)
     return dist.get_rank(group), dist.get_world_size(group), box[0]
 
 
@@ -201,6 +202,7 @@ class DataParallel:
             backend = 'rccl' if on_gpu else 'gloo'
         if backend == 'rccl' and not on_gpu:
             raise RuntimeError('the RCCL backend needs the models on a GPU')
+        self.group = process_group
         self.comm = _Rccl(rendezvous, process_group) if backend == 'rccl' else _Gloo(process_group)
         self.backend = backend
         self.rank, self.world = self.comm.rank, self.comm.world
@@ -316,6 +318,12 @@ class DataParallel:
     def _sync(self, model):
         """Called by the model right after its backward, from the model's lane: the gradient is complete once
         everything enqueued on this lane so far has run."""
+        # Deadlock freedom rests on every rank issuing the same collectives in the same order: ONE grad_sync per model
+        # between two waits.  A second one (e.g. a ModelSystem list path that trains a model once per crop with a
+        # data-dependent crop count) would give the ranks different collective counts: refuse it here, on every rank.
+        if any(m is model for m, _ in self._queue) or id(model) in self._reduced:
+            raise RuntimeError(f'data parallel: grad_sync called twice for one model within a step '
+                               f'(accumulate the gradients of all crops locally and reduce once)')
         ev = self.comm.event() if self.profile else self._ev_ready[id(model)]     # (profiling: events are read later)
         self.comm.record(ev)
         self._queue.append((model, ev))
@@ -403,9 +411,10 @@ class DataParallel:
         if not dist.is_initialized() or self.world == 1:
             return True
         ref = mine.clone()
-        dist.broadcast(ref, src=0)
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast(ref, src=src, group=self.group)
         diff = (mine - ref).abs().max()
-        dist.all_reduce(diff, op=dist.ReduceOp.MAX)
+        dist.all_reduce(diff, op=dist.ReduceOp.MAX, group=self.group)
         return float(diff.item()) <= tol
 
     def close(self):
