@@ -487,18 +487,31 @@ def main():
                            **({'lane_groups': None} if args.lane_per_net else {}),
                            **({'lane_xcds': parse_xcds(args.lane_xcds)} if args.lane_xcds else {}))
     dp_fallback = None
+    trainer, failure = None, None
     try:
         trainer = build_trainer('gloo' if rehearsal else None)
     except Exception as exc:       # noqa: BLE001
         if not (use_dp and world > 1 and not rehearsal):
             raise
-        # The RCCL communicator could not be created (library missing, ncclCommInitRank failed ...): a number with
-        # the gradients staged through the host (gloo) and a LOUD flag beats no number -- config.grad_allreduce
-        # says so and the JSON line carries the error.  All ranks take the same branch (the failure is collective).
-        dp_fallback = f'{type(exc).__name__}: {exc}'
-        print(f'[bench] rank {rank}: RCCL data-parallel setup failed ({dp_fallback}); FALLING BACK to gloo staging',
-              file=sys.stderr, flush=True)
-        trainer = build_trainer('gloo')
+        failure = f'{type(exc).__name__}: {exc}'
+    if use_dp and world > 1 and not rehearsal:
+        # The RCCL communicator may have failed on ONE rank only (its self-test, its memory ...): the ranks agree over the
+        # gloo control plane before anybody takes the fallback branch -- a rank that went on alone would sit in RCCL
+        # while the others sit in gloo.  A number with the gradients staged through the host and a LOUD flag beats no
+        # number: config.grad_allreduce says so and the JSON line carries the error.
+        ok = torch.tensor([0 if failure else 1], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            reasons = [None] * world
+            dist.all_gather_object(reasons, failure)
+            dp_fallback = '; '.join(f'rank {i}: {r}' for i, r in enumerate(reasons) if r) or 'unknown'
+            print(f'[bench] rank {rank}: RCCL data-parallel setup failed somewhere ({dp_fallback}); ALL ranks FALL BACK to '
+                  f'gloo staging', file=sys.stderr, flush=True)
+            if trainer is not None and trainer.dp is not None:
+                trainer.dp.close()                   # uocr_dp_finalize: no half-open communicator stays behind
+            trainer = None
+            torch.cuda.synchronize()
+            trainer = build_trainer('gloo')
     for opt in args.option:
         key, value = opt.split('=')
         rt.set_option(key, int(value))          # (every lane)

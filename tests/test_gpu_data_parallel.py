@@ -98,6 +98,72 @@ def test_two_ranks_equal_one_process_on_the_whole_batch(graphs, steps, pipelined
         CP.set_dtype('float32')
 
 
+def _rccl_worker(rank, world, port, results, graphs, coalesce):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from univer_ocr_amd.my_model.synthetic import make_page_batch
+        from univer_ocr_amd.my_model.trainer import PageTrainer
+        from univer_ocr_amd.nn import CP
+        CP.use_gpu(rank)                                   # one rank per GPU
+        CP.set_dtype('float64')
+        CP.lazy_losses = graphs
+        per = BATCH // world
+        trainer = PageTrainer(per, H, W, CW, optimizer='sgd', lr=0.01, seed=5 + rank, overlap=True, graphs=graphs,
+                              pipelined=True, dp_backend='rccl', dp_coalesce=coalesce)
+        assert trainer.dp.backend == 'rccl' and trainer.dp.world == world
+        layers = make_page_batch(BATCH, H, W, CW, seed=77)
+        context = trainer.make_context(_slice(layers, rank * per, (rank + 1) * per, CW))
+        for _ in range(5):
+            trainer.step(context)
+        trainer.join()
+        ok = all(trainer.dp.replicas_in_sync(m) for m in trainer.models.values())
+        results[rank] = (ok, {n: p.value.numpy() for m in trainer.models.values() for n, p in m.params().items()})
+        trainer.dp.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL with more than one rank needs one GPU per rank '
+                                                          '(the test boxes of this pool have one: the path is UNVERIFIED '
+                                                          'on hardware until a multi-GPU node runs this test)')
+@pytest.mark.parametrize('graphs,coalesce', [(False, False), (True, False), (True, True)])
+def test_rccl_two_ranks_equal_one_process_on_the_whole_batch(graphs, coalesce):
+    """The N > 1 data path on real RCCL: two ranks on two GPUs, the gradient all-reduces (incl. the Char net's early
+    tail) through uocr_dp_allreduce_sum, weights broadcast from rank 0, SUM / MEAN scaling -- both ranks must end with
+    identical weights, equal to one process training on the whole batch."""
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    with ctx.Manager() as manager:
+        results = manager.dict()
+        mp.spawn(_rccl_worker, args=(world, port, results, graphs, coalesce), nprocs=world, join=True)
+        results = dict(results)
+    assert results[0][0] and results[1][0], 'replicas diverged'
+    for name in results[0][1]:
+        assert np.array_equal(results[0][1][name], results[1][1][name])
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    from univer_ocr_amd.my_model.trainer import PageTrainer
+    from univer_ocr_amd.nn import CP
+    CP.use_gpu(0)
+    CP.set_dtype('float64')
+    try:
+        trainer = PageTrainer(BATCH, H, W, CW, optimizer='sgd', lr=0.01, seed=5, data_parallel=False)
+        context = trainer.make_context(make_page_batch(BATCH, H, W, CW, seed=77))
+        for _ in range(5):
+            trainer.step(context)
+        for model in trainer.models.values():
+            for name, p in model.params().items():
+                ref, got = p.value.numpy(), results[0][1][name]
+                err = np.max(np.abs(ref - got)) / max(1e-30, np.max(np.abs(ref)))
+                assert err <= 1e-11, f'{name}: {err:.2e}'
+    finally:
+        CP.set_dtype('float32')
+
+
 @pytest.mark.parametrize('graphs,coalesce', [(False, False), (True, False), (True, True)])
 def test_rccl_c_abi_one_rank_communicator(graphs, coalesce):
     """The REAL data path of N > 1 -- uocr_dp_get_unique_id / uocr_dp_init / uocr_dp_broadcast /

@@ -80,18 +80,29 @@ class _Rccl:
             self.rank, self.world, raw = torch_rendezvous(ident.raw if rank == 0 else None, group)
         else:
             self.rank, self.world, raw = 0, 1, ident.raw          # a ONE-rank communicator (rehearsal)
-        self.lane = rt.add_lane(workspace_mb=1)
+        # one communication lane per process, reused by every communicator made later (train.py builds a DataParallel per
+        # stage: a lane per stage would leak a context, a stream and a workspace each time)
+        if getattr(rt, '_comm_lane', None) is None:
+            rt._comm_lane = rt.add_lane(workspace_mb=1)
+        self.lane = rt._comm_lane
         with rt.lane(self.lane):
             rt.call('uocr_dp_init', self.rank, self.world, C.c_char_p(raw))
-            # known-answer check of the fresh communicator: a SUM of ones over the ranks must read `world` everywhere
-            # (a mis-bound library or a half-initialised ring otherwise shows up as silently wrong gradients)
-            probe = CP.full((8,), 1.0, np.float32)
-            rt.call('uocr_dp_allreduce_sum', probe.ptr, probe.size, probe.code & 0xff)
-            rt.call('uocr_stream_sync')
-            got = CP.asnumpy(probe)
-            if not np.all(got == float(self.world)):
-                raise hiplib.HipError(f'RCCL all-reduce self-test failed on rank {self.rank}: sum of ones over '
-                                      f'{self.world} ranks read {got.tolist()}')
+            try:
+                # known-answer check of the fresh communicator: a SUM of ones over the ranks must read `world` everywhere
+                # (a mis-bound library or a half-initialised ring otherwise shows up as silently wrong gradients)
+                probe = CP.full((8,), 1.0, np.float32)
+                rt.call('uocr_dp_allreduce_sum', probe.ptr, probe.size, probe.code & 0xff)
+                rt.call('uocr_stream_sync')
+                got = CP.asnumpy(probe)
+                if not np.all(got == float(self.world)):
+                    raise hiplib.HipError(f'RCCL all-reduce self-test failed on rank {self.rank}: sum of ones over '
+                                          f'{self.world} ranks read {got.tolist()}')
+            except Exception:
+                try:
+                    rt.call('uocr_dp_finalize')          # no half-open communicator stays behind in the library
+                except hiplib.HipError:
+                    pass
+                raise
         self._events = []
 
     def event(self):
