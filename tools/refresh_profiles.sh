@@ -13,9 +13,9 @@ cd /tmp && export TMPDIR=/tmp
 case "$1" in
   stats)
     timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats" --output-format csv -- \
-        python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > "$OUT/bench_under_rocprofv3.json" 2> "$OUT/stats.err"
+        python3 "$R/bench.py" --steps 20 --warmup 5 --steady-steps 0 --no-cpu-baseline --no-secondary > "$OUT/bench_under_rocprofv3.json" 2> "$OUT/stats.err"
     timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_hr" --output-format csv -- \
-        python3 "$R/bench.py" --config highres-fp16 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > "$OUT/bench_hr_under_rocprofv3.json" 2> "$OUT/stats_hr.err"
+        python3 "$R/bench.py" --config highres-fp16 --steps 20 --warmup 5 --steady-steps 0 --no-cpu-baseline --no-secondary > "$OUT/bench_hr_under_rocprofv3.json" 2> "$OUT/stats_hr.err"
     cd "$R"
     timeout -k 10 500 python3 bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench.err"
     timeout -k 10 500 python3 bench.py --config highres-fp16 > "$OUT/bench_hr_n1.json" 2> "$OUT/bench_hr.err"
@@ -24,14 +24,16 @@ case "$1" in
     timeout -k 10 400 python3 tools/bench_conv.py > "$OUT/conv_microbench.txt" 2>&1
     timeout -k 10 300 python3 tools/bench_membw.py > "$OUT/membw.txt" 2>&1
     timeout -k 10 300 python3 tools/bench_h16.py > "$OUT/bench_h16.txt" 2>&1
+    timeout -k 10 200 python3 tools/bench_conv.py --filter mono.pair --dtype float16 --batch 8 --height 1024 --width 2048 --pair-act none > "$OUT/pair_f16_microbench.txt" 2>&1
+    timeout -k 10 200 python3 tools/bench_nets.py --graphs > "$OUT/bench_nets.txt" 2>&1
     hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_valu_coexec.hip -o /tmp/coexec 2> /dev/null && timeout -k 5 60 /tmp/coexec > "$OUT/ubench_coexec.txt"
     hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_switch.hip -o /tmp/sw 2> /dev/null && timeout -k 5 60 /tmp/sw > "$OUT/ubench_switch.txt"
     ;;
   pmc)
     timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" --output-format csv -- \
-        python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
+        python3 "$R/bench.py" --steps 3 --warmup 1 --steady-steps 0 --no-cpu-baseline --no-secondary > "$OUT/pmc_fetch.json" 2> "$OUT/pmc_fetch.err"
     timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_write" --output-format csv -- \
-        python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"
+        python3 "$R/bench.py" --steps 3 --warmup 1 --steady-steps 0 --no-cpu-baseline --no-secondary > "$OUT/pmc_write.json" 2> "$OUT/pmc_write.err"
     cd "$R"
     bash tools/pmc_pair.sh refresh pair > "$OUT/pmc_pair_summary.txt" 2>&1
     ;;
