@@ -41,6 +41,81 @@ def test_library_loaded_is_in_tree():
     assert lib_path().endswith('univer-ocr_amd/libuniver_hip.so')
 
 
+def test_graph_capture_and_replay_with_ctypes_only():
+    """INTEGRATION.md section 7 as a reference-side binding would write it: ctypes, a context and buffers of the library
+    itself (no torch tensor, stream or graph anywhere) -- one SGD step of conv3x3 (1 -> 4) + Dice loss is captured with
+    uocr_graph_begin_capture / end_capture and replayed with uocr_graph_launch on new inputs; every replay equals the
+    same calls made eagerly, and the oracle."""
+    import ctypes as C
+    from oracle import nn_oracle as O
+    from univer_ocr_amd.hip import lib as hiplib
+    lib = hiplib.get_lib()
+    ctx = C.c_void_p()
+    assert lib.uocr_ctx_create(0, 64 << 20, C.byref(ctx)) == 0
+    n, h, w, cout = 2, 24, 40, 4
+    rng = np.random.default_rng(5)
+    wt = (rng.standard_normal((3, 3, 1, cout)) * 0.3).astype(np.float32)
+    bias = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+
+    def buf(nbytes):
+        p = C.c_void_p()
+        assert lib.uocr_malloc(ctx, nbytes, C.byref(p)) == 0
+        return p
+
+    def up(ptr, a):
+        a = np.ascontiguousarray(a)
+        assert lib.uocr_h2d(ctx, ptr, a.ctypes.data_as(C.c_void_p), a.nbytes) == 0
+
+    def down(ptr, shape, dtype=np.float32):
+        out = np.empty(shape, dtype)
+        assert lib.uocr_d2h_sync(ctx, out.ctypes.data_as(C.c_void_p), ptr, out.nbytes) == 0
+        return out
+    px, py = n * h * w, n * h * w * cout
+    X, G, Y, DY, W, B, DW, DB, V, slot = (buf(4 * px), buf(4 * py), buf(4 * py), buf(4 * py), buf(wt.nbytes), buf(bias.nbytes),
+                                          buf(wt.nbytes), buf(bias.nbytes), buf(wt.nbytes), buf(8))
+    dims = (n, h, w, 1, cout, 3, 3, 1, 1, 1, 1, h, w)
+
+    def step():
+        assert lib.uocr_conv2d_fwd(ctx, hiplib.F32, X, W, B, Y, *dims, 0.0, 1, hiplib.ACT_SIGMOID, 0.0) == 0
+        assert lib.uocr_seg_loss(ctx, hiplib.F32, hiplib.LOSS_DICE, Y, G, DY, slot, n, h * w, cout, hiplib.ACT_SIGMOID) == 0
+        assert lib.uocr_conv2d_bwd_weight(ctx, hiplib.F32, X, DY, DW, DB, *dims, 0.0, 1, 0) == 0
+        assert lib.uocr_momentum_step(ctx, hiplib.F32, W, DW, V, wt.size, 0.05, 0.0) == 0
+
+    def reset():
+        up(W, wt), up(B, bias)
+        assert lib.uocr_memset_zero(ctx, V, wt.nbytes) == 0
+    reset()
+    graph = C.c_void_p()
+    assert lib.uocr_graph_begin_capture(ctx) == 0
+    step()                                               # recorded, not run
+    assert lib.uocr_graph_end_capture(ctx, C.byref(graph)) == 0 and graph.value
+    batches = [(rng.random((n, h, w, 1)).astype(np.float32), (rng.random((n, h, w, cout)) > 0.6).astype(np.float32))
+               for _ in range(3)]
+    replayed, eager = [], []
+    for x, g in batches:                                 # three replays on three batches: the weights move every time
+        up(X, x), up(G, g)
+        assert lib.uocr_graph_launch(ctx, graph) == 0
+        replayed.append((down(slot, (1,), np.float64)[0], down(W, wt.shape)))
+    reset()
+    for x, g in batches:
+        up(X, x), up(G, g)
+        step()
+        eager.append((down(slot, (1,), np.float64)[0], down(W, wt.shape)))
+    for (lr, wr), (le, we) in zip(replayed, eager):
+        assert lr == le and np.array_equal(wr, we)
+    # and the first step against the oracle
+    x, g = batches[0]
+    z = O.conv2d_fwd(x.astype(np.float64), wt.astype(np.float64), bias.astype(np.float64), 1, 1, 0.0, True)
+    loss, grad = O.dice_loss(O.sigmoid_fwd(z), g.astype(np.float64))
+    assert abs(replayed[0][0] - loss) <= 1e-5 * abs(loss)
+    _, dw, _ = O.conv2d_bwd(x.astype(np.float64), wt.astype(np.float64), O.sigmoid_bwd(z, grad), 1, 1, 0.0, True)
+    assert rel_linf(replayed[0][1].astype(np.float64), wt - 0.05 * dw) <= 1e-5
+    assert lib.uocr_graph_destroy(graph) == 0
+    for p in (X, G, Y, DY, W, B, DW, DB, V, slot):
+        assert lib.uocr_free(ctx, p) == 0
+    assert lib.uocr_ctx_destroy(ctx) == 0
+
+
 @pytest.mark.parametrize('tag', [str(n) for n in load_golden('conv2d')['names']])
 def test_conv2d(tag, dt):
     from univer_ocr_amd.nn import CP, ops
