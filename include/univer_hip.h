@@ -143,14 +143,15 @@ int uocr_conv2d_bwd_weight(uocr_ctx* ctx, int dtype, const void* x, const void* 
                            int ph, int pw, int oh, int ow, double pad_value, int use_bias,
                            int accumulate);
 
-/* The Monochrome block (my_model/model.py:108-135) as one forward and one backward kernel, float32:
+/* The Monochrome block (my_model/model.py:108-135) as one forward and one backward kernel, float32 / UOCR_F16:
  *   y = act2( conv3x3( LeakyReLU_alpha1( conv3x3(x; w1,b1) ); w2,b2 ) ),  x,y: (n,h,w,1), w1: (3,3,1,16),
  *   w2: (3,3,16,1), both convs stride 1 / padding 1 (convolutional.py:62-99 twice + layers.py:377-418),
  *   conv_2's padding value 0.  The 16-channel activation and its gradient are recomputed in registers /
  *   LDS instead of crossing HBM.  act2 = UOCR_ACT_NONE or UOCR_ACT_SIGMOID.
  * bwd: dy = gradient w.r.t. y (AFTER act2; the kernel multiplies by act2'(y)); dw/db as
  *   uocr_conv2d_bwd_weight (accumulate!=0 adds), dx may be NULL (page-input gradient not wanted).
- * UOCR_ERR_UNSUPPORTED for float64 or cmid != 16: the caller then runs the layers one by one. */
+ * UOCR_ERR_UNSUPPORTED for float64, cmid != 16 or a LeakyReLU slope outside [0, 1] (the kernels take it as
+ * max(z, alpha z)): the caller then runs the layers one by one. */
 int uocr_conv_pair_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w1, const void* b1,
                        const void* w2, const void* b2, void* y, int n, int h, int wd, int cmid,
                        double pad_value1, int use_bias1, int use_bias2, double alpha1, int act2);
@@ -207,7 +208,8 @@ int uocr_act_bwd_from_output(uocr_ctx* ctx, int dtype, int kind, double alpha, c
 /* ---- FullyConnected (layers/layers.py:307-363) -------------------------------------------- */
 int uocr_dense_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, void* y,
                    int m, int n_in, int n_out);
-/* dx = dy . w[:-1]^T ; dw (+)= [x,1]^T . dy ; dx may be NULL to skip it */
+/* dx = dy . w[:-1]^T ; dw (+)= [x,1]^T . dy ; dx or dw may be NULL to skip it (the two halves may then run on
+ * different ctx: the weight gradient is off the critical path of a backward pass) */
 int uocr_dense_bwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* dy,
                    void* dx, void* dw, int m, int n_in, int n_out, int accumulate);
 /* FullyConnected followed by LeakyRelu / Sigmoid (my_model/model.py:250-304: dense_1, dense_2) as one

@@ -267,6 +267,42 @@ def test_skip_input_grads_leaves_losses_and_updates_unchanged():
         assert np.array_equal(np.asarray(w), np.asarray(results[1][1][name])), name
 
 
+@pytest.mark.parametrize('graphs', [False, True], ids=['eager', 'graphs'])
+def test_weight_gradients_on_side_streams_change_nothing(graphs):
+    """PageTrainer(side_wgrad=...): the weight-gradient kernels of a net run on a side stream of its lane
+    (Runtime.side) and rejoin before anything reads a parameter gradient -- the same kernels on the same data, so
+    losses and weights after six steps are bit-identical to the single-stream backward pass."""
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    from univer_ocr_amd.my_model.trainer import PageTrainer
+    from univer_ocr_amd.nn import CP
+    CP.use_gpu(0)
+    CP.set_dtype('float32')
+    batches = [make_page_batch(2, 32, 64, 16, seed=s) for s in (7, 8)]
+    results = []
+    lazy = CP.lazy_losses
+    CP.lazy_losses = True
+    try:
+        for side in ((), ('all',)):
+            trainer = PageTrainer(2, 32, 64, 16, optimizer='adam', lr=0.001, seed=3, graphs=graphs, side_wgrad=side)
+            assert all(m.side_wgrad == bool(side) for m in trainer.models.values())
+            history = []
+            for i in range(6):
+                losses = trainer.step(trainer.make_context(batches[i % 2]))
+                history.append({n: [float(v) for v in l['output_losses']] + [float(l['regularization_loss'])]
+                                for n, l in losses.items()})
+            weights = {}
+            for model in trainer.models.values():
+                weights.update(model.get_weights())
+            results.append((history, weights))
+            if side:
+                assert len(CP.runtime()._sides) >= 3           # one side stream per lane was really used
+    finally:
+        CP.lazy_losses = lazy
+    assert results[0][0] == results[1][0]
+    for name, w in results[0][1].items():
+        assert np.array_equal(np.asarray(w), np.asarray(results[1][1][name])), name
+
+
 def test_graph_replay_matches_eager_steps():
     """PageTrainer(graphs=True): per-net HIP graphs replayed == the eager multi-stream step, bit for bit
     (same kernels, same order per stream), including a change of the input batch after capture."""

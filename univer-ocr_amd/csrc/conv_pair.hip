@@ -18,12 +18,15 @@ namespace {
 
 constexpr int C = 16;
 
-int check_pair(uocr_ctx* ctx, int dtype, int n, int h, int w, int cmid, int act2) {
+int check_pair(uocr_ctx* ctx, int dtype, int n, int h, int w, int cmid, int act2, double alpha1) {
     if (UOCR_DTYPE_BASE(dtype) != UOCR_F32 && UOCR_DTYPE_BASE(dtype) != UOCR_F16)
         UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "conv_pair: float32 / float16 only");
     if (cmid != C) UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "conv_pair: 16 middle channels only (got %d)", cmid);
     if (act2 != UOCR_ACT_NONE && act2 != UOCR_ACT_SIGMOID)
         UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "conv_pair: output activation must be none or sigmoid");
+    // the forward kernels take LeakyReLU as max(z, alpha z)
+    if (!(alpha1 >= 0.0 && alpha1 <= 1.0))
+        UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "conv_pair: LeakyReLU slope must lie in [0, 1] (got %g)", alpha1);
     UOCR_REQUIRE(ctx, n > 0 && h > 0 && w > 0 && n <= 65535);
     return UOCR_OK;
 }
@@ -35,7 +38,7 @@ extern "C" int uocr_conv_pair_fwd(uocr_ctx* ctx, int dtype, const void* x, const
                                   double pad_value1, int use_bias1, int use_bias2, double alpha1, int act2) {
     UOCR_CHECK_CTX(ctx);
     UOCR_REQUIRE(ctx, x && w1 && b1 && w2 && b2 && y);
-    int rc = check_pair(ctx, dtype, n, h, w, cmid, act2);
+    int rc = check_pair(ctx, dtype, n, h, w, cmid, act2, alpha1);
     if (rc != UOCR_OK) return rc;
     if (UOCR_DTYPE_BASE(dtype) == UOCR_F32)
         return uocr_pair_strip_fwd_f32(ctx, (const float*)x, (const float*)w1, (const float*)b1, (const float*)w2,
@@ -51,7 +54,7 @@ extern "C" int uocr_conv_pair_bwd(uocr_ctx* ctx, int dtype, const void* x, const
                                   int use_bias1, int use_bias2, double alpha1, int act2, int accumulate) {
     UOCR_CHECK_CTX(ctx);
     UOCR_REQUIRE(ctx, x && y && dy && w1 && b1 && w2 && dw1 && db1 && dw2 && db2);
-    int rc = check_pair(ctx, dtype, n, h, w, cmid, act2);
+    int rc = check_pair(ctx, dtype, n, h, w, cmid, act2, alpha1);
     if (rc != UOCR_OK) return rc;
     if (UOCR_DTYPE_BASE(dtype) == UOCR_F32)
         return uocr_pair_strip_bwd_f32(ctx, (const float*)x, (const float*)y, (const float*)dy, (const float*)w1,

@@ -368,7 +368,9 @@ __global__ __launch_bounds__(G <= 2 ? 1024 : 512) void pair_strip_bwd_kernel(con
 // column c of lane quarter tx feeds column c - tx + 1 (one LDS row per tx).  7 MFMAs per group of 16 positions
 // (tile kernel: 7 + a 9-tap LDS gather per output), 3 window registers per group instead of an LDS tile with halo.
 // Band rows overlap by one row of a1 on each side.  MODE as in the backward kernel.
-template <int G, int MODE>
+// PF: how the rows are prefetched.  0: one step ahead, rows pinned inside the loop; 1: one step ahead, only the rows
+// loaded in front of the loop pinned; 2: three steps ahead (one register set per phase).
+template <int G, int MODE, int PF>
 __global__ __launch_bounds__(512) void pair_strip_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
                                                              const float* __restrict__ b1,
                                                              const float* __restrict__ w2,
@@ -443,14 +445,30 @@ __global__ __launch_bounds__(512) void pair_strip_fwd_kernel(const float* __rest
 #pragma unroll
         for (int j = 0; j < 3; ++j) rr[g][j] = 0.f;
     for (int i = tid; i < NSLOT * NPLANE * outw; i += blockDim.x) outr[i] = 0.f;
-    float xn[G];
+    float xq[3][G];                                    // rows in flight, loaded three steps ahead (one set per phase)
     if (active) {
         float xp[3][G];
 #pragma unroll
         for (int j = 0; j < 3; ++j) load_row(r0 - 2 + j, xp[j]);
 #pragma unroll
         for (int j = 0; j < 3; ++j) finish_row(r0 - 2 + j, j, xp[j]);
-        load_row(r0 + 1, xn);
+        // The window registers ARE the load destinations (no instruction in between): make these loads complete here.
+        // Left pending into the loop, the wait-count pass has to assume them in flight on the paths that skip a step's
+        // tail and puts an s_waitcnt vmcnt(0) -- i.e. a wait for the NEXT row's loads, issued a moment ago -- in
+        // front of the MFMAs of every step.  (Pinning the rows inside the loop instead does the same harm: the
+        // loads then keep fixed registers that the skip paths see as in flight.  Rows are loaded three steps ahead.)
+        if constexpr (PF >= 1) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int g = 0; g < G; ++g) asm volatile("" : "+v"(xw[g][j]));
+        }
+        if constexpr (PF == 2) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) load_row(r0 + 1 + j, xq[j]);
+        } else {
+            load_row(r0 + 1, xq[0]);
+        }
     }
     __syncthreads();
 
@@ -479,7 +497,7 @@ __global__ __launch_bounds__(512) void pair_strip_fwd_kernel(const float* __rest
             for (int g = 0; g < G; ++g) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float a = z[g][i] >= 0.f ? z[g][i] : alpha * z[g][i];
+                    float a = fmaxf(z[g][i], alpha * z[g][i]);     // LeakyReLU for 0 <= alpha <= 1 (checked by the entry point)
                     if constexpr (MODE == 1) a = wc0 + 16 * g + n < wd ? a : 0.f;     // conv_2 pads a1 with zeros
                     z[g][i] = a;
                 }
@@ -508,10 +526,17 @@ __global__ __launch_bounds__(512) void pair_strip_fwd_kernel(const float* __rest
             for (int g = 0; g < G; ++g) outr[oslot * NPLANE * outw + ow_addr + 16 * g] = cdone[g];
         }
         if (active) {
+            if constexpr (PF == 2) {
+                finish_row(t + 2, S0, xq[P]);
+                load_row(t + 5, xq[P]);
+            } else {
+                if constexpr (PF == 0) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) asm volatile("" : "+v"(xn[g]));
-            finish_row(t + 2, S0, xn);
-            load_row(t + 3, xn);
+                    for (int g = 0; g < G; ++g) asm volatile("" : "+v"(xq[0][g]));
+                }
+                finish_row(t + 2, S0, xq[0]);
+                load_row(t + 3, xq[0]);
+            }
         }
     };
 
@@ -531,7 +556,9 @@ __global__ __launch_bounds__(512) void pair_strip_fwd_kernel(const float* __rest
             for (int cc = lane; cc < L::COLS; cc += 64) {
                 const int c = wc0 + cc;
                 float v = bias2 + (o[outw + cc] + o[cc - 1] + o[2 * outw + cc + 1]);
-                if (act2 == UOCR_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+                // v_exp_f32 + v_rcp_f32 (1 ulp each; the argument's scaling by log2 e adds |v| * 6e-8 relative to e^-v:
+                // <= 3e-7 absolute on y for |v| <= 20) instead of the ~25 instructions of expf and an IEEE division
+                if (act2 == UOCR_ACT_SIGMOID) v = __builtin_amdgcn_rcpf(1.f + __expf(-v));
                 if (c >= own_lo && c < own_hi) y[img + (size_t)row * wd + c] = v;
             }
         }
@@ -659,12 +686,18 @@ int uocr_pair_strip_fwd_f32(uocr_ctx* ctx, const float* x, const float* w1, cons
     UOCR_REQUIRE(ctx, bands <= 65535 && n <= 65535);
     const size_t lds = sizeof(float) * NSLOT * NPLANE * (bwc + 16);
     const bool plain = nbx == 1 && w == bwc && pad1 == 0.f;
-    if (plain)
-        hipLaunchKernelGGL((pair_strip_fwd_kernel<G, 0>), dim3(nbx, bands, n), dim3(nw * 64), lds, ctx->stream, x, w1, b1,
-                           w2, b2, y, h, w, band_h, pad1, use_b1, use_b2, alpha, act2);
-    else
-        hipLaunchKernelGGL((pair_strip_fwd_kernel<G, 1>), dim3(nbx, bands, n), dim3(nw * 64), lds, ctx->stream, x, w1, b1,
-                           w2, b2, y, h, w, band_h, pad1, use_b1, use_b2, alpha, act2);
+    auto go = [&](auto mode, auto pf) {
+        hipLaunchKernelGGL((pair_strip_fwd_kernel<G, decltype(mode)::value, decltype(pf)::value>), dim3(nbx, bands, n),
+                           dim3(nw * 64), lds, ctx->stream, x, w1, b1, w2, b2, y, h, w, band_h, pad1, use_b1, use_b2, alpha,
+                           act2);
+    };
+    auto by_pf = [&](auto mode) {
+        if (ctx->opt_pair_pf == 0) go(mode, phase_t<0>{});
+        else if (ctx->opt_pair_pf == 2) go(mode, phase_t<2>{});
+        else go(mode, phase_t<1>{});
+    };
+    if (plain) by_pf(phase_t<0>{});
+    else by_pf(phase_t<1>{});
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
 }

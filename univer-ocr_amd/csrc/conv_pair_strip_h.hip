@@ -412,6 +412,9 @@ __device__ __forceinline__ uint32_t neg_halves(uint32_t packed) {
 __device__ __forceinline__ uint32_t mul2h(uint32_t a, f16x2 b) {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, a) * b);
 }
+__device__ __forceinline__ uint32_t max2h(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)));
+}
 
 template <int G, bool DX, bool SIG>
 __global__ __launch_bounds__(256) void pair_wave_bwd_h_kernel(const _Float16* __restrict__ x,
@@ -755,7 +758,7 @@ namespace {
 // y[p] = b2 + sum_tap P[p + tap - 1, tap] in rolling registers, the three column shifts through the wave's private
 // output rows.  No LDS ring for x (nothing needs 4 consecutive positions here), no barrier, ~12 vector instructions
 // and 2 MFMAs per group of 16 positions (tile kernel: 2 MFMAs + a 9-tap LDS gather per output).
-template <int G>
+template <int G, int PF>
 __global__ __launch_bounds__(256) void pair_wave_fwd_h_kernel(const _Float16* __restrict__ x, const float* __restrict__ w1,
                                                               const float* __restrict__ b1,
                                                               const float* __restrict__ w2,
@@ -837,14 +840,18 @@ __global__ __launch_bounds__(256) void pair_wave_fwd_h_kernel(const _Float16* __
         }
     };
     for (int i = lane; i < 3 * NPLANE * OUTW; i += 64) outr[i] = 0.f;
-    uint32_t xn[G];
-    {
-        uint32_t xq[3][G];
+    // rows are loaded THREE steps ahead of their use (one register set per phase of the unrolled loop): a step of this
+    // kernel is 8 MFMAs of 16 cycles, far shorter than a load round trip
+    uint32_t xq[3][G];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) load_row(r0 - 2 + j, xq[j]);
+    for (int j = 0; j < 3; ++j) load_row(r0 - 2 + j, xq[j]);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) finish_row(r0 - 2 + j, xq[j]);
-        load_row(r0 + 1, xn);
+    for (int j = 0; j < 3; ++j) finish_row(r0 - 2 + j, xq[j]);
+    if constexpr (PF == 2) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) load_row(r0 + 1 + j, xq[j]);
+    } else {
+        load_row(r0 + 1, xq[0]);
     }
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     // y[row][c] = act2(b2 + plane1[c] + plane0[c-1] + plane2[c+1]) of the wave's own output rows
@@ -871,8 +878,7 @@ __global__ __launch_bounds__(256) void pair_wave_fwd_h_kernel(const _Float16* __
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const uint32_t zb = cvt2h(z[g][2 * r], z[g][2 * r + 1]);
-                    const uint32_t neg = neg_halves(zb);
-                    a4[r] = (neg & mul2h(zb, alpha2)) | (~neg & zb);
+                    a4[r] = max2h(zb, mul2h(zb, alpha2));            // LeakyReLU for 0 <= alpha <= 1: v_pk_mul + v_pk_max
                     if (ragged) a4[r] &= keep_a[g];
                 }
                 u[g] = mfma16(w2a, __builtin_bit_cast(f16x4, a4), zero);
@@ -896,10 +902,17 @@ __global__ __launch_bounds__(256) void pair_wave_fwd_h_kernel(const _Float16* __
             for (int g = 0; g < G; ++g) outr[S0 * NPLANE * OUTW + ow_addr + 16 * g] = cdone[g];     // row t-1
         }
         flush_row(t - 2, S2);
+        if constexpr (PF == 2) {
+            finish_row(t + 2, xq[P]);
+            load_row(t + 5, xq[P]);
+        } else {
+            if constexpr (PF == 0) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) asm volatile("" : "+v"(xn[g]));
-        finish_row(t + 2, xn);
-        load_row(t + 3, xn);
+                for (int g = 0; g < G; ++g) asm volatile("" : "+v"(xq[0][g]));
+            }
+            finish_row(t + 2, xq[0]);
+            load_row(t + 3, xq[0]);
+        }
     };
     const int nsteps = r1 - r0 + 2;                    // t = r0-1 .. r1
     int t0 = r0 - 1;
@@ -937,9 +950,14 @@ int uocr_pair_strip_fwd_f16(uocr_ctx* ctx, const void* x, const float* w1, const
     bands = (h + band_h - 1) / band_h;
     UOCR_REQUIRE(ctx, bands <= 65535 && n <= 65535);
     const size_t lds = sizeof(float) * nw * 3 * NPLANE * (COLS + 2);
-    hipLaunchKernelGGL((pair_wave_fwd_h_kernel<G>), dim3(blocks_x, bands, n), dim3(nw * 64), lds, ctx->stream,
-                       (const _Float16*)x, w1, b1, w2, b2, (_Float16*)y, h, w, band_h, pad1, use_b1, use_b2, alpha, act2,
-                       nstrips);
+    auto go = [&](auto pf) {
+        hipLaunchKernelGGL((pair_wave_fwd_h_kernel<G, decltype(pf)::value>), dim3(blocks_x, bands, n), dim3(nw * 64), lds,
+                           ctx->stream, (const _Float16*)x, w1, b1, w2, b2, (_Float16*)y, h, w, band_h, pad1, use_b1,
+                           use_b2, alpha, act2, nstrips);
+    };
+    if (ctx->opt_pair_pf == 0) go(pair_strip::phase_t<0>{});
+    else if (ctx->opt_pair_pf == 2) go(pair_strip::phase_t<2>{});
+    else go(pair_strip::phase_t<1>{});
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
 }

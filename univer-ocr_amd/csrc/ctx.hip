@@ -1,6 +1,8 @@
 // Context, memory and event entry points of the C ABI (include/univer_hip.h).
 // These stand in for the reference's `CP` backend switch (nn/gpu.py:5-29): CP.copy = H2D,
 // CP.asnumpy = D2H, cupy.zeros = malloc + memset, cuda.synchronize() = stream sync.
+#include <cstdlib>
+
 #include "uocr_common.h"
 
 extern "C" {
@@ -31,6 +33,8 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->opt_xcd = 1;
     ctx->opt_pair_band = 0;
     ctx->opt_pair_g = 4;
+    ctx->opt_pair_pf = 1;
+    if (const char* e = getenv("UOCR_PAIR_PF")) ctx->opt_pair_pf = atoi(e);   // development override (tools/dev/pf_ab.sh)
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return UOCR_ERR_HIP;
@@ -104,6 +108,7 @@ int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "t32")) ctx->opt_t32 = value;
     else if (!strcmp(key, "pair_band")) ctx->opt_pair_band = value;
     else if (!strcmp(key, "pair_g")) ctx->opt_pair_g = value;
+    else if (!strcmp(key, "pair_pf")) ctx->opt_pair_pf = value;
     else UOCR_FAIL(ctx, UOCR_ERR_ARG, "unknown option '%s'", key);
     return UOCR_OK;
 }

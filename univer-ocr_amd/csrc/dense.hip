@@ -115,7 +115,7 @@ int uocr_dense_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, void*
 int uocr_dense_bwd_act(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* dy, void* dx, void* dw,
                        int m, int n_in, int n_out, int accumulate, int x_act, double x_act_alpha) {
     UOCR_CHECK_CTX(ctx);
-    UOCR_REQUIRE(ctx, x && w && dy && dw && m > 0 && n_in > 0 && n_out > 0);
+    UOCR_REQUIRE(ctx, x && w && dy && (dx || dw) && m > 0 && n_in > 0 && n_out > 0);
     UOCR_REQUIRE(ctx, x_act == UOCR_ACT_NONE || x_act == UOCR_ACT_SIGMOID || (x_act == UOCR_ACT_LEAKY && x_act_alpha > 0));
     if (dx) {   // dx[m, n_in] = dy[m, n_out] . w[:n_in, :]^T  (* act'(x) when x is the output of a fused activation)
         GemmArgs g{};
@@ -129,6 +129,7 @@ int uocr_dense_bwd_act(uocr_ctx* ctx, int dtype, const void* x, const void* w, c
         int rc = uocr_gemm(ctx, dtype, g);
         if (rc) return rc;
     }
+    if (!dw) return UOCR_OK;
     GemmArgs g{};   // dw[n_in + 1, n_out] (+)= [x, 1]^T . dy
     g.a = x; g.a_rs = 1; g.a_cs = n_in; g.a_ones_row = 1;
     g.b = dy; g.b_rs = n_out; g.b_cs = 1;

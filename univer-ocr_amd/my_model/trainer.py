@@ -43,7 +43,7 @@ class PageTrainer:
                  dp_coalesce=False, dp_backend=None,
                  init='kaiming_normal', fuse=True, lanes=True, input_grads=True, graphs=False, eager_nets=(), pipelined=False,
                  snapshot_losses=True,
-                 lane_groups=(('Monochrome', 'Paragraph'), ('Line',), ('Char',)), lane_xcds=None):
+                 lane_groups=(('Monochrome', 'Paragraph'), ('Line',), ('Char',)), lane_xcds=None, side_wgrad=None):
         np.random.seed(seed)                        # kaiming_uniform draws from the NumPy global RNG
         self.batch = batch
         self.optimizer = make_optimizer(optimizer, lr)
@@ -58,6 +58,15 @@ class PageTrainer:
         for model in self.models.values():
             model.enable_fusion(fuse, windows=os.environ.get('UOCR_WINDOWS_FUSION', '1') != '0')   # conv + LeakyReLU / Sigmoid as one forward kernel
             model.skip_input_grads(not input_grads)   # False: drop the page-input gradient nobody reads
+        # side_wgrad: nets whose weight-gradient kernels run on a side stream of their lane (Runtime.side): the dX chain of
+        # the backward pass does not wait for them.  Measured (tools/dev/side_ab.sh): the Char net
+        # ALONE gains (0.433 -> 0.397 ms/step), but the page step with its three lanes loses badly (0.845 -> 1.18 ms with
+        # the Char net forked, 2.3 ms with all nets): every fork adds a stream to the captured graphs and the device
+        # time-slices the hardware queues beyond the few it runs at once.  Off by default; results are bit-identical.
+        if side_wgrad is None:
+            side_wgrad = tuple(n for n in os.environ.get('UOCR_SIDE_WGRAD', '').split(',') if n)
+        for name, model in self.models.items():
+            model.side_wgrad = CP.has_device() and (name in side_wgrad or 'all' in side_wgrad)
         # one stream (lane) per net: the nets are independent until the optimizer step
         self.lanes = None
         if lanes and CP.has_device() and len(self.models) > 1:

@@ -59,6 +59,8 @@ class Runtime:
         self.launches = 0
         self.call('uocr_ctx_set_stream', C.c_void_p(self.stream.cuda_stream))
         self._lanes = [(self.ctx, self.stream)]      # lane 0 = the main stream
+        self._sides = {}                             # lane ctx -> its side stream (weight gradients), made on demand
+        self.side_on = False                         # Model.backward turns it on for models with side_wgrad
 
     # -- lanes: extra (context, stream) pairs so independent models run concurrently ---------------
     def add_lane(self, workspace_mb=256, priority=0, xcds=None):
@@ -118,10 +120,33 @@ class Runtime:
         """Kernel selection knobs of the C ABI: 'mfma' (0 never / 1 auto / 2 whenever eligible),
         'fast_paths' (0 generic kernels only / 1 shape-specialised).  Applied to every lane."""
         current = self.ctx
-        for handle, _ in self._lanes:
+        self._options = getattr(self, '_options', {})
+        self._options[key] = int(value)
+        for handle in [h for h, _ in self._lanes] + [s.handle for s in self._sides.values()]:
             self.ctx = handle
             self.call('uocr_ctx_set_option', key.encode(), int(value))
         self.ctx = current
+
+    # -- side stream of a lane: kernels nobody waits for until the end of the backward pass (weight gradients) --------
+    def side(self, *keep):
+        """`with rt.side(x, dy):` -- the C-ABI calls inside go to the side stream of the current lane, ordered behind
+        everything enqueued on the lane so far (device-side event); the lane does not wait for them until
+        `join_side()`.  `keep`: the arrays the side kernels read -- held until the join so that the allocator cannot
+        hand their memory to a later kernel of the lane.  No-op (the calls stay on the lane) unless `side_on`."""
+        return _SideScope(self, keep)
+
+    def join_side(self):
+        """The current lane waits (on the device) for its side stream."""
+        side = self._sides.get(self.ctx.value)
+        if side is None or not side.dirty:
+            return
+        lane = self.ctx
+        self.ctx = side.handle
+        side.join_ev.record()
+        self.ctx = lane
+        side.join_ev.wait()
+        side.dirty = False
+        side.keep.clear()
 
     def synchronize(self):
         self.call('uocr_stream_sync')
@@ -212,6 +237,7 @@ class _Capture:
         import ctypes as C
         handle = C.c_void_p()
         try:
+            self.rt.join_side()                      # a forked side stream must be back before the capture ends
             self.rt.call('uocr_graph_end_capture', C.byref(handle))
             self.graph.handle = handle
         except HipError:
@@ -246,6 +272,52 @@ class LossArena:
         out = CP.empty((self.used,), np.float64)
         CP.runtime().call('uocr_d2d', out.ptr, self.array.ptr, 8 * self.used)
         return out
+
+
+class _Side:
+    """Side stream of one lane: its own uocr_ctx (stream + workspace)."""
+
+    def __init__(self, rt):
+        import ctypes as C
+        self.handle = C.c_void_p()
+        rc = rt.lib.uocr_ctx_create(rt.device_index, int(os.environ.get('UOCR_SIDE_WORKSPACE_MB', '128')) << 20,
+                                    C.byref(self.handle))
+        if rc != 0:
+            raise HipError(f'uocr_ctx_create (side stream) failed with code {rc}')
+        self.stream = torch.cuda.Stream(device=rt.device)
+        lane = rt.ctx
+        rt.ctx = self.handle
+        rt.call('uocr_ctx_set_stream', C.c_void_p(self.stream.cuda_stream))
+        for key, value in getattr(rt, '_options', {}).items():
+            rt.call('uocr_ctx_set_option', key.encode(), value)
+        rt.ctx = lane
+        self.fork_ev, self.join_ev = Event(rt), Event(rt)
+        self.keep, self.dirty = [], False
+
+
+class _SideScope:
+    def __init__(self, rt, keep):
+        self.rt, self.keep = rt, keep
+
+    def __enter__(self):
+        rt = self.rt
+        self.lane = None
+        if not rt.side_on:
+            return
+        side = rt._sides.get(rt.ctx.value)
+        if side is None:
+            side = rt._sides[rt.ctx.value] = _Side(rt)
+        side.fork_ev.record()                      # on the lane
+        self.lane = rt.ctx
+        rt.ctx = side.handle
+        side.fork_ev.wait()                        # the side stream waits for the lane up to here
+        side.keep.extend(self.keep)
+        side.dirty = True
+
+    def __exit__(self, *exc):
+        if self.lane is not None:
+            self.rt.ctx = self.lane
+        return False
 
 
 class _Lane:

@@ -112,6 +112,7 @@ class Model(BaseModel):
         self.defer_grad_sync = False     # True: the all-reduce is waited for in train_finish()
         self._pending_losses = None
         self.bucket_hook = None
+        self.side_wgrad = False          # weight-gradient kernels on the lane's side stream (Runtime.side)
         self._receptive_fields = {}
         self.layers, self.relations = None, None
         self.unravel_model()
@@ -257,6 +258,19 @@ class Model(BaseModel):
 
     @track_method('backward')
     def backward(self, grads):
+        rt = CP.runtime() if self.side_wgrad and CP.has_device() else None
+        if rt is None:
+            return self._backward_pass(grads)
+        # weight gradients go to the side stream of this lane: the chain of dX kernels does not wait for them;
+        # they are back before anything reads a parameter gradient (here, and in front of a bucket hook)
+        rt.side_on = True
+        try:
+            return self._backward_pass(grads)
+        finally:
+            rt.side_on = False
+            rt.join_side()
+
+    def _backward_pass(self, grads):
         grads = [ops.as_device(g) for g in make_list_if_not(grads)]
         grads_mem = {}
 
@@ -506,6 +520,8 @@ class Model(BaseModel):
             conv_a = self._fusion[1][act_a]
             a, b, act = self.layers[conv_a], self.layers[conv_b], self.layers[act_a]
             if not isinstance(act, LeakyRelu) or not (isinstance(a, Convolutional2D) and isinstance(b, Convolutional2D)):
+                continue
+            if not 0.0 <= act.alpha <= 1.0:               # the fused kernels take LeakyReLU as max(z, alpha z)
                 continue
             same = all(l.kernel_size == (3, 3) and l.stride == (1, 1) and l.padding == (1, 1) for l in (a, b))
             if not (same and (a.in_channels, a.out_channels, b.in_channels, b.out_channels) == (1, 16, 16, 1)

@@ -104,8 +104,9 @@ def conv2d_bwd_data(dy, w, x_shape, stride, padding, x_act=None, act=None, alpha
 def conv2d_bwd_weight(x, dy, dw, db, stride, padding, pad_value=0.0, bias=True, accumulate=True):
     dims = _conv_dims(x.shape, dw.shape, stride, padding)
     code = _same_dtype(x, dy, dw, db, grad=dy)
-    _rt().call('uocr_conv2d_bwd_weight', code, x.ptr, dy.ptr, dw.ptr, db.ptr, *dims, float(pad_value),
-               int(bool(bias)), int(bool(accumulate)))
+    with _rt().side(x, dy):               # nothing on the lane reads dw before the end of the backward pass
+        _rt().call('uocr_conv2d_bwd_weight', code, x.ptr, dy.ptr, dw.ptr, db.ptr, *dims, float(pad_value),
+                   int(bool(bias)), int(bool(accumulate)))
 
 
 def conv_pair_fwd(x, w1, b1, w2, b2, pad_value1=0.0, bias1=True, bias2=True, alpha=0.01, act2=hiplib.ACT_NONE):
@@ -158,8 +159,9 @@ def upconv2x_bwd_data(dy, w, x_low_shape, padding, x_act=None, act=None, alpha=0
 def upconv2x_bwd_weight(x_low, dy, dw, db, padding, bias=True, accumulate=True):
     dims = _up_dims(x_low.shape, dw.shape, padding)
     code = _same_dtype(x_low, dy, dw, db, grad=dy)
-    _rt().call('uocr_upconv2x_bwd_weight', code, x_low.ptr, dy.ptr, dw.ptr, db.ptr, *dims, int(bool(bias)),
-               int(bool(accumulate)))
+    with _rt().side(x_low, dy):
+        _rt().call('uocr_upconv2x_bwd_weight', code, x_low.ptr, dy.ptr, dw.ptr, db.ptr, *dims, int(bool(bias)),
+                   int(bool(accumulate)))
 
 
 # ---- MaxPool2D ------------------------------------------------------------------------------------
@@ -247,8 +249,16 @@ def dense_bwd(x, w, dy, dw, accumulate=True, need_dx=True, x_act=None, x_alpha=0
     n_out = w.shape[1]
     code = _same_dtype(x, w, dy, dw, grad=dy)
     dx = _like_grad(CP.empty((m, n_in), dy.dtype), dy) if need_dx else None
-    _rt().call('uocr_dense_bwd_act', code, x.ptr, w.ptr, dy.ptr, dx.ptr if need_dx else None, dw.ptr, m, n_in,
-               n_out, int(bool(accumulate)), ACT_CODES[x_act], float(x_alpha))
+    rt = _rt()
+    if rt.side_on and need_dx:            # dw on the lane's side stream, dx (the critical path) on the lane
+        with rt.side(x, dy):
+            rt.call('uocr_dense_bwd_act', code, x.ptr, w.ptr, dy.ptr, None, dw.ptr, m, n_in, n_out,
+                    int(bool(accumulate)), ACT_CODES[None], 0.0)
+        rt.call('uocr_dense_bwd_act', code, x.ptr, w.ptr, dy.ptr, dx.ptr, None, m, n_in, n_out, 0, ACT_CODES[x_act],
+                float(x_alpha))
+        return dx
+    rt.call('uocr_dense_bwd_act', code, x.ptr, w.ptr, dy.ptr, dx.ptr if need_dx else None, dw.ptr, m, n_in,
+            n_out, int(bool(accumulate)), ACT_CODES[x_act], float(x_alpha))
     return dx
 
 
@@ -285,8 +295,9 @@ def windows_dense_bwd(x, w, dy, dw, width, accumulate=True, x_act=None, act=None
     code = _same_dtype(x, w, dy, dw, grad=dy)
     if dy.shape != (dims[0] * dims[2], dims[4]):
         raise AssertionError(f'grad shape {dy.shape} does not match the layer output')
-    _rt().call('uocr_conv2d_bwd_weight', code, x.ptr, dy.ptr, dw.ptr, dw.ptr + bias_off, *dims, 0.0, 1,
-               int(bool(accumulate)))
+    with _rt().side(x, dy):
+        _rt().call('uocr_conv2d_bwd_weight', code, x.ptr, dy.ptr, dw.ptr, dw.ptr + bias_off, *dims, 0.0, 1,
+                   int(bool(accumulate)))
     dx = _like_grad(CP.empty(x.shape, dy.dtype), dy)
     _rt().call('uocr_conv2d_bwd_data', code, dy.ptr, w.ptr, dx.ptr, *dims, None if x_act is None else x_act.ptr,
                ACT_CODES[act if x_act is not None else None], float(alpha))
