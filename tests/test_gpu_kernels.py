@@ -415,6 +415,29 @@ def test_seg_loss_with_folded_output_sigmoid(kind, shape, f32):
     assert none is None and float(loss3) == float(loss)
 
 
+def test_cross_entropy_single_launch_sums(f32):
+    """SoftmaxCrossEntropy / SigmoidCrossEntropy add their per-block partials in the last block to arrive (one launch
+    each): value against the oracle over many blocks, repeated calls (counter back at zero), odd row counts."""
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    for m, c in ((256, 162), (1001, 37), (3, 162), (4097, 70)):
+        rng = np.random.default_rng(m + c)
+        z = rng.standard_normal((m, c)) * 3
+        gt = np.zeros((m, c))
+        gt[np.arange(m), rng.integers(0, c, m)] = 1.0
+        ref_loss, ref_grad = O.softmax_ce_loss(z, gt)
+        zd, gd = CP.copy(z), CP.copy(gt)
+        for _ in range(3):
+            loss, grad = ops.softmax_ce(zd, gd)
+            assert abs(float(loss) - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (m, c)
+            check(grad, ref_grad, 1e-5, f'softmax grad {m}x{c}')
+        ref_loss, ref_grad = O.sigmoid_ce_loss(z, gt)
+        for _ in range(3):
+            loss, grad = ops.sigmoid_ce(zd, gd)
+            assert abs(float(loss) - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (m, c)
+            check(grad, ref_grad, 1e-5, f'sigmoid grad {m}x{c}')
+
+
 @pytest.mark.parametrize('shape', [(2, 6, 8, 4), (3, 10, 14, 8), (1, 2, 2, 4), (2, 64, 96, 16)])
 def test_maxpool2_vector_kernels_match_generic(shape, f32):
     """2x2 / stride 2 max pooling with c % 4 == 0 (16-byte kernels) == the oracle, with ties inside windows

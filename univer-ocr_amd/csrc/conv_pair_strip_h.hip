@@ -956,8 +956,8 @@ int uocr_pair_strip_fwd_f16(uocr_ctx* ctx, const void* x, const float* w1, const
                            use_b2, alpha, act2, nstrips);
     };
     if (ctx->opt_pair_pf == 0) go(pair_strip::phase_t<0>{});
-    else if (ctx->opt_pair_pf == 2) go(pair_strip::phase_t<2>{});
-    else go(pair_strip::phase_t<1>{});
+    else if (ctx->opt_pair_pf == 1) go(pair_strip::phase_t<1>{});
+    else go(pair_strip::phase_t<2>{});
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
 }

@@ -20,6 +20,7 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->err[0] = 0;
     ctx->workspace = nullptr;
     ctx->workspace_bytes = 0;
+    ctx->sync = nullptr;
     ctx->owns_stream = true;
     ctx->opt_mfma = 1;
     ctx->opt_fast = 1;
@@ -33,7 +34,7 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->opt_xcd = 1;
     ctx->opt_pair_band = 0;
     ctx->opt_pair_g = 4;
-    ctx->opt_pair_pf = 1;
+    ctx->opt_pair_pf = -1;   // auto: float32 one step ahead (49.5 us; 50.8 pinned in the loop, 51.8 three ahead), binary16 three (72.1; 73.8 / 75.5)
     if (const char* e = getenv("UOCR_PAIR_PF")) ctx->opt_pair_pf = atoi(e);   // development override (tools/dev/pf_ab.sh)
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -49,6 +50,16 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
             return UOCR_ERR_HIP;
         }
         ctx->workspace_bytes = workspace_bytes;
+    }
+    // arrival counters: zeroed once here; every kernel that uses them leaves them at zero
+    if (hipMalloc((void**)&ctx->sync, UOCR_SYNC_WORDS * sizeof(unsigned)) != hipSuccess ||
+        hipMemsetAsync(ctx->sync, 0, UOCR_SYNC_WORDS * sizeof(unsigned), ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        if (ctx->sync) hipFree(ctx->sync);
+        if (ctx->workspace) hipFree(ctx->workspace);
+        hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return UOCR_ERR_HIP;
     }
     *out = ctx;
     return UOCR_OK;
@@ -78,6 +89,7 @@ int uocr_ctx_destroy(uocr_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->workspace) hipFree(ctx->workspace);
+    if (ctx->sync) hipFree(ctx->sync);
     if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return UOCR_OK;

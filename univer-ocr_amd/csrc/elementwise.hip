@@ -340,8 +340,8 @@ __device__ __forceinline__ void opt_fused_one(T& wi, T& gi, T& vi, T& ai, long l
 template <typename T, int OPT, int VEC>
 __global__ __launch_bounds__(256) void opt_fused_kernel(T* __restrict__ w, T* __restrict__ g, T* __restrict__ s1,
                                                         T* __restrict__ s2, size_t n, T p0, T p1, T p2, T p3,
-                                                        RegRanges rr, double* __restrict__ partial /* [grid][4] */,
-                                                        double* __restrict__ loss_out /* used when gridDim.x == 1 */,
+                                                        RegRanges rr, double* partial /* [grid][4] */,
+                                                        double* __restrict__ loss_out, unsigned* counter,
                                                         int zero_grad, const double* __restrict__ hyper) {
     if (hyper) {      // hyper-parameters from device memory: a captured HIP graph follows lr / beta changes
         p0 = (T)hyper[0];
@@ -404,24 +404,28 @@ __global__ __launch_bounds__(256) void opt_fused_kernel(T* __restrict__ w, T* __
         }
         return;
     }
+    // several blocks: publish the block's four sums; the last block to arrive adds all of them up (block order) --
+    // no finish launch
+    __shared__ int last;
     if (threadIdx.x < 4)
-        partial[(size_t)blockIdx.x * 4 + threadIdx.x] =
-            smem[0][threadIdx.x] + smem[1][threadIdx.x] + smem[2][threadIdx.x] + smem[3][threadIdx.x];
-}
-
-// out = sum_r strength_r * sum_blocks partial[block][r]   (one block)
-__global__ __launch_bounds__(256) void fused_reg_finish_kernel(const double* partial, int nblocks, RegRanges rr,
-                                                               double* out) {
-    __shared__ double smem[16];
+        pub_store(partial + (size_t)blockIdx.x * 4 + threadIdx.x,
+                  smem[0][threadIdx.x] + smem[1][threadIdx.x] + smem[2][threadIdx.x] + smem[3][threadIdx.x]);
+    if (threadIdx.x == 0) last = sync_arrive(counter) == gridDim.x - 1;       // (threads 0-3 are one wave: drained together)
+    __syncthreads();
+    if (!last) return;
+    __shared__ double red[16];
     double total = 0.0;
     for (int r = 0; r < rr.n; ++r) {
-        double acc = 0.0;
-        for (int i = threadIdx.x; i < nblocks; i += blockDim.x) acc += partial[(size_t)i * 4 + r];
-        acc = block_reduce_sum(acc, smem);
+        double a = 0.0;
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) a += pub_load(partial + (size_t)i * 4 + r);
+        a = block_reduce_sum(a, red);
         __syncthreads();
-        total += rr.strength[r] * acc;
+        total += rr.strength[r] * a;
     }
-    if (threadIdx.x == 0) *out = total;
+    if (threadIdx.x == 0) {
+        *loss_out = total;
+        sync_clear(counter);
+    }
 }
 
 template <typename T>
@@ -696,7 +700,7 @@ static int launch_opt_fused(uocr_ctx* ctx, int dtype, int opt, void* w, void* g,
     UOCR_DISPATCH(ctx, dtype, {
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, ctx->stream, (T*)w, (T*)g, (T*)s1, (T*)s2, count, (T)p0,
-                               (T)p1, (T)p2, (T)p3, rr, partial, reg_loss_out, zero_grad, hyper_dev);
+                               (T)p1, (T)p2, (T)p3, rr, partial, reg_loss_out, ctx->sync + 3, zero_grad, hyper_dev);
         };
         if (opt == 0 && vec) launch(opt_fused_kernel<T, 0, 4>);
         else if (opt == 0) launch(opt_fused_kernel<T, 0, 1>);
@@ -704,11 +708,6 @@ static int launch_opt_fused(uocr_ctx* ctx, int dtype, int opt, void* w, void* g,
         else launch(opt_fused_kernel<T, 1, 1>);
         UOCR_LAUNCH_CHECK(ctx);
     });
-    if (nranges > 0 && grid > 1) {
-        hipLaunchKernelGGL(fused_reg_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)partial, (int)grid,
-                           rr, reg_loss_out);
-        UOCR_LAUNCH_CHECK(ctx);
-    }
     return UOCR_OK;
 }
 

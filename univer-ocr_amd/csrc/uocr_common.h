@@ -13,6 +13,7 @@ struct uocr_ctx {
     bool owns_stream;
     void* workspace;
     size_t workspace_bytes;
+    unsigned* sync;      // UOCR_SYNC_WORDS arrival counters of the single-launch reductions (loss.hip): zero between launches
     int cu_count;
     int opt_mfma;        // 0 = never, 1 = auto (default), 2 = whenever eligible (tests)
     int opt_fast;        // 0 = generic kernels only, 1 = shape-specialised fast paths (default)
@@ -24,10 +25,12 @@ struct uocr_ctx {
     int opt_h16;         // 1 = binary16-MFMA kernels for the small-channel convs in UOCR_F16 mode (default)
     int opt_t32;         // float32 vertical-Toeplitz MFMA kernels for the small-channel convs: bit 0 forward, bit 1 backward-data
     int opt_pair_band;   // rows per band of the strip kernels (0 = about one block per CU)
-    int opt_pair_pf;     // row prefetch of the pair forward kernels (0 / 1 / 2, see conv_pair_strip.hip)
+    int opt_pair_pf;     // row prefetch of the pair forward kernels (-1 auto / 0 / 1 / 2, see conv_pair_strip.hip)
     int opt_pair_g;      // groups of 16 columns per wave of the strip kernels: 4 (8 waves per block) or 2 (16 waves)
     char err[512];
 };
+
+constexpr int UOCR_SYNC_WORDS = 1 << 18;   // 1 MB
 
 #define UOCR_FAIL(ctx, code, ...)                                   \
     do {                                                            \
@@ -143,6 +146,48 @@ __device__ __forceinline__ double block_reduce_sum(double v, double* smem /* >= 
     v = (threadIdx.x < (unsigned)nw) ? smem[threadIdx.x] : 0.0;
     if (wid == 0) v = wave_reduce_sum(v);
     return v;
+}
+
+// ---- single-launch sums (loss.hip: the cross-entropies; elementwise.hip: the regulariser sums of the fused optimizer tail)
+// Blocks hand small float64 partials to each other INSIDE a launch.  gfx950 has one L2 per XCD and they are not
+// coherent with each other, so every handed-off word is written by an agent-scope atomic store (write-through, sc1),
+// drained (s_waitcnt vmcnt(0)) before the writer's arrival is counted, and read by agent-scope atomic loads (sc1:
+// past this CU's L1 and this XCD's L2 copy); no fences.  Counters live in ctx->sync, are zero between launches and
+// are put back to zero by the last block that touches them.
+__device__ __forceinline__ void pub_store(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double pub_load(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned sync_arrive(unsigned* c) {            // the payload stores of this thread are drained first
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned sync_peek(unsigned* c) {
+    return __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sync_clear(unsigned* c) {
+    __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The last block of a launch to arrive at `counter` adds up `count` published partials (block-strided, fixed order)
+// and stores scale * sum; every thread of every block calls this (it contains barriers).
+__device__ __forceinline__ void last_block_sum(unsigned* counter, double* partial, double mine, int count, double scale,
+                                               double* out, double* smem /* >= 17 doubles */) {
+    if (threadIdx.x == 0) {
+        pub_store(partial + blockIdx.x, mine);
+        const unsigned t = sync_arrive(counter);
+        smem[16] = t == gridDim.x - 1 ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (smem[16] == 0.0) return;                       // block-uniform
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) acc += pub_load(partial + i);
+    acc = block_reduce_sum(acc, smem);
+    if (threadIdx.x == 0) {
+        *out = scale * acc;
+        sync_clear(counter);
+    }
 }
 
 // ---- activation-tensor element access ---------------------------------------------------------------------
