@@ -415,6 +415,43 @@ def test_seg_loss_with_folded_output_sigmoid(kind, shape, f32):
     assert none is None and float(loss3) == float(loss)
 
 
+@pytest.mark.parametrize('shape,pad_value,act', [((2, 40, 128, 4), 0.0, None), ((1, 37, 130, 4), 0.0, 'sigmoid'),
+                                                 ((3, 16, 60, 4), 0.0, None), ((2, 21, 61, 4), 0.25, 'leaky'),
+                                                 ((1, 5, 3, 4), 0.0, None), ((2, 64, 512, 4), 0.0, 'sigmoid')])
+def test_conv_h3_error_compensated_f16_mfma_forward(shape, pad_value, act, f32):
+    """ctx option h3 = 1: the float32 5x5 4 -> 2 convolution (the Line net's output layer) computed as
+    x_hi w_hi + x_hi w_lo + x_lo w_hi on binary16 MFMAs (csrc/conv_h3.hip) holds the float32 tolerance against
+    the oracle (1e-5 of the tensor's largest value): strips of 60 columns, bands of rows, ragged widths and heights,
+    a non-zero padding value, fused activations; values over five orders of magnitude in one tensor."""
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    rt = CP.runtime()
+    rng = np.random.default_rng(sum(shape))
+    X = rng.standard_normal(shape) * np.exp(rng.uniform(-6, 2, shape))
+    w = rng.standard_normal((5, 5, 4, 2)) * 0.2
+    b = rng.standard_normal(2)
+    ref = O.conv2d_fwd(X, w, b, (1, 1), (2, 2), pad_value, True)
+    alpha = 0.0
+    if act == 'sigmoid':
+        ref = O.sigmoid_fwd(ref)
+    elif act == 'leaky':
+        alpha = 0.1
+        ref = np.where(ref >= 0, ref, alpha * ref)
+    Xd, wd, bd = CP.copy(X), CP.copy(w), CP.copy(b)
+    try:
+        rt.set_option('h3', 1)
+        for band in (0, 16):
+            rt.set_option('pair_band', band)
+            y = ops.conv2d_fwd(Xd, wd, bd, (1, 1), (2, 2), pad_value, True, act=act, alpha=alpha)
+            check(y, ref, 1e-5, f'h3 forward, band {band}')
+        rt.set_option('h3', 0)
+        y0 = ops.conv2d_fwd(Xd, wd, bd, (1, 1), (2, 2), pad_value, True, act=act, alpha=alpha)
+        assert rel_linf(CP.asnumpy(y), CP.asnumpy(y0).astype(np.float64)) <= 5e-6     # against the float32 vector kernel
+    finally:
+        rt.set_option('h3', 0)
+        rt.set_option('pair_band', 0)
+
+
 def test_cross_entropy_single_launch_sums(f32):
     """SoftmaxCrossEntropy / SigmoidCrossEntropy add their per-block partials in the last block to arrive (one launch
     each): value against the oracle over many blocks, repeated calls (counter back at zero), odd row counts."""

@@ -33,6 +33,8 @@ int uocr_conv2d_fwd(uocr_ctx* ctx, int dtype, const void* x, const void* w, cons
         return uocr_conv_fwd_h16(ctx, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
     if (uocr_conv_t32_eligible(ctx, dtype, d, 0) && aligned16(x) && aligned16(y))
         return uocr_conv_fwd_t32(ctx, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
+    if (uocr_conv_h3_eligible(ctx, dtype, d) && aligned16(x) && aligned16(y))
+        return uocr_conv_fwd_h3(ctx, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
     if (uocr_conv_tiled_eligible(ctx, dtype, d) && uocr_aligned_act(x, dtype) && uocr_aligned_act(y, dtype))
         return uocr_conv_fwd_tiled(ctx, dtype, x, w, b, y, d, pad_value, use_bias, act, act_alpha);
     if (uocr_conv_fast_eligible(ctx, dtype, d, x, y, w))

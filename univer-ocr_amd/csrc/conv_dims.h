@@ -54,6 +54,10 @@ int uocr_conv_wgrad_t32(uocr_ctx* ctx, const void* x, const void* dy, void* dw, 
 bool uocr_upconv_t32_eligible(uocr_ctx* ctx, int dtype, int cin, int cout);
 int uocr_upconv_dgrad_t32(uocr_ctx* ctx, const void* dy, const void* w, void* dx_low, int n, int hl, int wl, int ch,
                           const void* mask_y, int mask_act, double mask_alpha);
+// float32 5x5 4 -> 2 forward on error-compensated binary16 MFMAs (conv_h3.hip; experiment, ctx option h3)
+bool uocr_conv_h3_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d);
+int uocr_conv_fwd_h3(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
+                     double pad_value, int use_bias, int act, double act_alpha);
 // LDS-tiled forward for the 5x5 stride-1 4-channel convs (conv_tiled.hip), f32 / f16 storage
 bool uocr_conv_tiled_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d);
 int uocr_conv_fwd_tiled(uocr_ctx* ctx, int dtype, const void* x, const void* w, const void* b, void* y, const ConvDims& d,

@@ -1,0 +1,207 @@
+// hipcc-flags: -mllvm -amdgpu-mfma-vgpr-form=1
+// EXPERIMENT (round 3, verdict item 7): a float32 layer on error-compensated binary16 MFMAs.
+//
+// The Line net's output conv (5x5, 4 -> 2 channels, stride 1, padding 2; my_model/model.py:194-247 built from
+// nn/layers/convolutional.py:62-99) in float32 storage, computed as
+//     x = x_hi + x_lo,  w = w_hi + w_lo   (hi = round16(v), lo = round16(v - hi): 22 significant bits together)
+//     x . w  ~  x_hi w_hi + x_hi w_lo + x_lo w_hi      (x_lo w_lo, 2^-22 relative, dropped; sums in float32)
+// on v_mfma_f32_16x16x16_f16, which covers four times the depth of the float32 MFMA in half the cycles.
+//
+// Layout (the column strips of conv_pair_strip.hip): a wave owns 60 output columns (64 computed) and walks down the
+// rows of its band.  Per input row r: every lane loads ONE pixel (4 channels, 16 bytes) of columns c0-2 .. c0+61,
+// splits it into hi / lo halves once (12 vector instructions) and writes both to a wave-private LDS row; the B
+// operand of a group of 16 columns is then three 8-byte LDS reads per lane: K slot (kq, j) = (dx = kq, channel j) of
+// x_hi, the same of x_lo, and the dx = 4 column (hi, hi, lo in lane quarters 0, 1, 2).  A = the weights, constant:
+// M row m = 4 q + i -> tap row ky = q (i = 0, 1: the two output channels), ky = 4 in rows 14, 15.  Four MFMAs per
+// group and row:  x_hi w_hi,  x_hi w_lo,  x_lo w_hi  over dx = 0..3, and one for dx = 4 holding all three terms.
+// D[m][n]: lane quarter q of column n holds the row's contribution through tap row q to output row r + 2 - q.  The
+// five tap rows are added along a chain of lane quarters, one ds_bpermute per output channel and row:
+//     quarter 0: bias + P0[t-2] -> quarter 1: + P1[t-1] -> quarter 2: + P2[t] -> quarter 3: + P3[t+1], then + P4[t+2]
+// and quarter 3 stores y[t] (8 bytes per lane, 128 contiguous bytes per group).
+#include <algorithm>
+#include <type_traits>
+
+#include "conv_dims.h"
+
+namespace {
+
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+
+constexpr int G = 4, COLS = 16 * G, OWN = COLS - 4;      // computed / owned columns of a strip
+constexpr int LROW = COLS + 4;                           // pixels per LDS row (the last group reads 4 past the loaded ones)
+
+__device__ __forceinline__ f32x4 mfma16(f16x4 a, f16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+template <int ACT>
+__device__ __forceinline__ float act_apply(float v, float alpha) {
+    if constexpr (ACT == UOCR_ACT_RELU) return fmaxf(v, 0.f);
+    else if constexpr (ACT == UOCR_ACT_LEAKY) return v >= 0.f ? v : alpha * v;
+    else if constexpr (ACT == UOCR_ACT_SIGMOID) return __builtin_amdgcn_rcpf(1.f + __expf(-v));     // 1 ulp each
+    else return v;
+}
+// v -> (hi, lo) binary16 pairs
+__device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+    const f16x2 h01 = __builtin_convertvector(f32x2{v[0], v[1]}, f16x2), h23 = __builtin_convertvector(f32x2{v[2], v[3]}, f16x2);
+    const f32x2 r01 = f32x2{v[0], v[1]} - __builtin_convertvector(h01, f32x2);
+    const f32x2 r23 = f32x2{v[2], v[3]} - __builtin_convertvector(h23, f32x2);
+    hi = u32x2{__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23)};
+    lo = u32x2{__builtin_bit_cast(uint32_t, __builtin_convertvector(r01, f16x2)),
+               __builtin_bit_cast(uint32_t, __builtin_convertvector(r23, f16x2))};
+}
+
+template <bool PADNZ, int ACT>
+__global__ __launch_bounds__(256) void conv_h3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int h,
+                                                          int wd, int band_h, int nstrips, float pad, int use_bias,
+                                                          float alpha) {
+    extern __shared__ __attribute__((aligned(16))) u32x2 lds_h3[];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, kq = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sidx = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (sidx >= nstrips) return;                                    // (no barrier in this kernel)
+    u32x2* const hi_row = lds_h3 + wv * 2 * LROW;                   // [LROW] pixels: 4 channels as binary16
+    u32x2* const lo_row = hi_row + LROW;
+    const int c0 = sidx * OWN;
+    const int r0 = blockIdx.y * band_h, r1 = min(h, r0 + band_h);
+    const size_t img = (size_t)blockIdx.z * h * wd;
+    const float* xb = x + img * 4;
+    float* yb = y + img * 2;
+
+    // A operands: lane (m = n, kq) holds the 4 channels of tap (ky(m), dx) for output channel co(m)
+    const int mq = n >> 2, mi = n & 3;
+    const bool second = mq == 3 && mi >= 2;                          // rows 14, 15: tap row 4
+    const bool live = mi < 2 || second;
+    const int ky = second ? 4 : mq, co = mi & 1;
+    f16x4 a_hi, a_lo, a_4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float wv0 = live ? w[((ky * 5 + kq) * 4 + j) * 2 + co] : 0.f;            // dx = kq
+        const float wv4 = live && kq < 3 ? w[((ky * 5 + 4) * 4 + j) * 2 + co] : 0.f;   // dx = 4
+        const _Float16 h0 = (_Float16)wv0, h4 = (_Float16)wv4;
+        a_hi[j] = h0;
+        a_lo[j] = (_Float16)(wv0 - (float)h0);
+        a_4[j] = kq == 1 ? (_Float16)(wv4 - (float)h4) : h4;       // quarters 0, 2: w_hi (x_hi, x_lo); quarter 1: w_lo (x_hi)
+    }
+    const float b0 = use_bias ? bias[0] : 0.f, b1 = use_bias ? bias[1] : 0.f;
+
+    // load: lane l <-> column c0 - 2 + l
+    const int lcol = c0 - 2 + lane;
+    const bool col_in = lcol >= 0 && lcol < wd;
+    const unsigned xoff = col_in ? (unsigned)lcol * 16u : 0x7FFFFFFFu;
+    const unsigned row_bytes = (unsigned)wd * 16u;
+    auto load_row = [&](int row) {
+        const bool in = row >= 0 && row < h;
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb + (size_t)min(max(row, 0), h - 1) * wd * 4), 0,
+                                                          in ? row_bytes : 0u, 0x00020000);
+        f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff, 0, 0));
+        if constexpr (PADNZ) {
+            if (!(in && col_in)) v = f32x4{pad, pad, pad, pad};
+        }
+        return v;
+    };
+    // B reads (pixel index relative to column c0 - 2)
+    int rd[G], rd4[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        rd[g] = 16 * g + n + kq;
+        rd4[g] = 16 * g + n + 4;
+    }
+    if (lane < 4) {
+        hi_row[COLS + lane] = u32x2{0u, 0u};
+        lo_row[COLS + lane] = u32x2{0u, 0u};
+    }
+    // output: quarter 3 of group g stores column c0 + 16 g + n
+    unsigned yoff[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int c = c0 + 16 * g + n;
+        yoff[g] = (kq == 3 && 16 * g + n < OWN && c < wd) ? (unsigned)c * 8u : 0x7FFFFFFFu;
+    }
+    const unsigned yrow_bytes = (unsigned)wd * 8u;
+    const int src_lane = (lane - 16) * 4;                           // ds_bpermute address: the lane a quarter below
+
+    float cin[G][2], rprev[G][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        cin[g][0] = b0, cin[g][1] = b1;
+        rprev[g][0] = rprev[g][1] = 0.f;
+    }
+    f32x4 xn = load_row(r0 - 2);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0 - 2; r < r1 + 2; ++r) {
+        u32x2 xh, xl;
+        split4(xn, xh, xl);
+        xn = load_row(r + 1);
+        hi_row[lane] = xh;
+        lo_row[lane] = xl;
+        const auto ry = __builtin_amdgcn_make_buffer_rsrc(yb + (size_t)min(max(r - 2, 0), h - 1) * wd * 2, 0,
+                                                          (r - 2 >= r0 && r - 2 < r1) ? yrow_bytes : 0u, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const f16x4 bh = __builtin_bit_cast(f16x4, hi_row[rd[g]]);
+            const f16x4 bl = __builtin_bit_cast(f16x4, lo_row[rd[g]]);
+            const f16x4 b4 = __builtin_bit_cast(f16x4, (kq == 2 ? lo_row : hi_row)[rd4[g]]);
+            f32x4 d = mfma16(a_hi, bh, zero);
+            d = mfma16(a_lo, bh, d);
+            d = mfma16(a_hi, bl, d);
+            d = mfma16(a_4, b4, d);
+            // the chain of tap rows along the lane quarters
+            const float c0v = cin[g][0] + d[0], c1v = cin[g][1] + d[1];
+            const float y0 = rprev[g][0] + d[2], y1 = rprev[g][1] + d[3];        // (quarter 3) output row r - 2 complete
+            rprev[g][0] = c0v, rprev[g][1] = c1v;
+            const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane, __builtin_bit_cast(int, c0v)));
+            const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane, __builtin_bit_cast(int, c1v)));
+            cin[g][0] = kq == 0 ? b0 : s0;
+            cin[g][1] = kq == 0 ? b1 : s1;
+            const f32x2 out = {act_apply<ACT>(y0, alpha), act_apply<ACT>(y1, alpha)};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, out), ry, yoff[g], 0, 0);
+        }
+    }
+}
+
+}  // namespace
+
+bool uocr_conv_h3_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d) {
+    return ctx->opt_h3 && UOCR_DTYPE_BASE(dtype) == UOCR_F32 && d.kh == 5 && d.kw == 5 && d.cin == 4 && d.cout == 2 &&
+           d.sh == 1 && d.sw == 1 && d.ph == 2 && d.pw == 2 && d.oh == d.h && d.ow == d.w && d.n <= 65535 &&
+           (size_t)d.w * 16 < 0x7FFFFFFFu;
+}
+
+int uocr_conv_fwd_h3(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
+                     double pad_value, int use_bias, int act, double act_alpha) {
+    const int nstrips = (d.w + OWN - 1) / OWN;
+    const int nw = std::min(4, nstrips);
+    const int blocks_x = (nstrips + nw - 1) / nw;
+    // bands: about 12 waves per CU, at least 16 rows each (4 extra rows of input per band)
+    const long want = 12L * ctx->cu_count;
+    int bands = (int)std::max(1L, want / std::max(1L, (long)blocks_x * nw * d.n));
+    bands = std::min(bands, std::max(1, d.h / 16));
+    if (ctx->opt_pair_band > 0) bands = (d.h + ctx->opt_pair_band - 1) / ctx->opt_pair_band;
+    const int band_h = (d.h + bands - 1) / bands;
+    bands = (d.h + band_h - 1) / band_h;
+    UOCR_REQUIRE(ctx, bands <= 65535);
+    const size_t lds = (size_t)nw * 2 * LROW * sizeof(u32x2);
+    const dim3 grid(blocks_x, bands, d.n), block(nw * 64);
+    auto go = [&](auto padnz, auto atag) {
+        hipLaunchKernelGGL((conv_h3_fwd_kernel<decltype(padnz)::value, decltype(atag)::value>), grid, block, lds, ctx->stream,
+                           (const float*)x, (const float*)w, (const float*)b, (float*)y, d.h, d.w, band_h, nstrips,
+                           (float)pad_value, use_bias, (float)act_alpha);
+    };
+    auto by_act = [&](auto padnz) {
+        switch (act) {
+            case UOCR_ACT_RELU: go(padnz, std::integral_constant<int, UOCR_ACT_RELU>{}); break;
+            case UOCR_ACT_LEAKY: go(padnz, std::integral_constant<int, UOCR_ACT_LEAKY>{}); break;
+            case UOCR_ACT_SIGMOID: go(padnz, std::integral_constant<int, UOCR_ACT_SIGMOID>{}); break;
+            default: go(padnz, std::integral_constant<int, UOCR_ACT_NONE>{}); break;
+        }
+    };
+    if (pad_value != 0.0) by_act(std::true_type{});
+    else by_act(std::false_type{});
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
+}

@@ -34,6 +34,8 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->opt_xcd = 1;
     ctx->opt_pair_band = 0;
     ctx->opt_pair_g = 4;
+    ctx->opt_h3 = 0;
+    if (const char* e = getenv("UOCR_H3")) ctx->opt_h3 = atoi(e);            // development override (tools/dev/h3_ab.sh)
     ctx->opt_pair_pf = -1;   // auto: float32 one step ahead (49.5 us; 50.8 pinned in the loop, 51.8 three ahead), binary16 three (72.1; 73.8 / 75.5)
     if (const char* e = getenv("UOCR_PAIR_PF")) ctx->opt_pair_pf = atoi(e);   // development override (tools/dev/pf_ab.sh)
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -120,6 +122,7 @@ int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "t32")) ctx->opt_t32 = value;
     else if (!strcmp(key, "pair_band")) ctx->opt_pair_band = value;
     else if (!strcmp(key, "pair_g")) ctx->opt_pair_g = value;
+    else if (!strcmp(key, "h3")) ctx->opt_h3 = value;
     else if (!strcmp(key, "pair_pf")) ctx->opt_pair_pf = value;
     else UOCR_FAIL(ctx, UOCR_ERR_ARG, "unknown option '%s'", key);
     return UOCR_OK;

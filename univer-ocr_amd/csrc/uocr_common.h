@@ -26,6 +26,7 @@ struct uocr_ctx {
     int opt_t32;         // float32 vertical-Toeplitz MFMA kernels for the small-channel convs: bit 0 forward, bit 1 backward-data
     int opt_pair_band;   // rows per band of the strip kernels (0 = about one block per CU)
     int opt_pair_pf;     // row prefetch of the pair forward kernels (-1 auto / 0 / 1 / 2, see conv_pair_strip.hip)
+    int opt_h3;          // 1 = the float32 Line output conv forward on error-compensated binary16 MFMAs (conv_h3.hip; experiment)
     int opt_pair_g;      // groups of 16 columns per wave of the strip kernels: 4 (8 waves per block) or 2 (16 waves)
     char err[512];
 };
