@@ -22,6 +22,20 @@ def f32():
     CP.runtime().set_option('t32', 2)
 
 
+def force_t32(CP, bits, fallback=None):
+    """Force conv_t32 / conv_t32w kernels through the 't32' option.  The default library holds only the forms that are
+    on by default (bit 2); the rest needs UOCR_BUILD_EXPERIMENTS=1 ./build.sh -- then `fallback` bits, or skip."""
+    from univer_ocr_amd.hip.lib import HipError
+    try:
+        CP.runtime().set_option('t32', bits)
+    except HipError as e:
+        if 'built without' not in str(e):
+            raise
+        if fallback is None:
+            pytest.skip('library built without UOCR_BUILD_EXPERIMENTS')
+        CP.runtime().set_option('t32', fallback)
+
+
 def check(a, b, tol, what):
     from univer_ocr_amd.nn import CP
     err = rel_linf(CP.asnumpy(a), b)
@@ -180,10 +194,11 @@ TOEPLITZ_SHAPES = [
 @pytest.mark.parametrize('pad_value,bias', [(0.0, True), (0.75, False)])
 def test_toeplitz_f32_conv_kernels(case, pad_value, bias, f32):
     """conv_t32.hip (vertical-Toeplitz float32 MFMA forward / backward-data, every instantiation forced through the
-    't32' option) against the oracle, with the fused activation and the backward mask of a consumer."""
+    't32' option; the default library: the backward-data forms that are on by default) against the oracle, with the
+    fused activation and the backward mask of a consumer."""
     from univer_ocr_amd.nn import ops
     CP = f32
-    CP.runtime().set_option('t32', 63)
+    force_t32(CP, 63, fallback=2)
     xs, cout = TOEPLITZ_SHAPES[case]
     rng = np.random.default_rng(700 + case)
     X = rng.standard_normal(xs)
@@ -207,7 +222,7 @@ def test_toeplitz_f32_upconv_dgrad(ch, hl, wl, f32):
     of the oracle."""
     from univer_ocr_amd.nn import ops
     CP = f32
-    CP.runtime().set_option('t32', 63)
+    force_t32(CP, 63)
     rng = np.random.default_rng(ch * 10 + hl)
     xl = rng.standard_normal((2, hl, wl, ch))
     w = rng.standard_normal((5, 5, ch, ch)) * 0.2
@@ -238,7 +253,7 @@ def test_toeplitz_f32_weight_gradients(case, pad_value, bias, f32):
     option) against the oracle, accumulating into non-zero dw / db."""
     from univer_ocr_amd.nn import ops
     CP = f32
-    CP.runtime().set_option('t32', 255)
+    force_t32(CP, 255)
     xs, cout, s = T32W_SHAPES[case]
     rng = np.random.default_rng(900 + case)
     X = rng.standard_normal(xs)

@@ -295,10 +295,13 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // which: 0 forward, 1 backward-data.  Bits of the "t32" option: 1 forward / 2 backward-data / 4 upsample+conv
 // backward-data of the 4-channel layers, 8 / 16 / 32 the same for the 1-channel layers.
+// The default library holds only what is on by default (bit 2: backward-data of the 4-channel layers); the other forms --
+// measured slower in the page step, DESIGN.md section 5 -- are built with UOCR_BUILD_EXPERIMENTS=1 ./build.sh.
 bool uocr_conv_t32_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d, int which) {
     if (dtype != UOCR_F32 || !ctx->opt_fast || d.n > 65535 || !same5x5(d)) return false;
-    if (d.cin == 4 && (d.cout == 2 || d.cout == 4)) return ctx->opt_t32 & (1 << which);
-    if (d.cin == 1 && d.cout == 1) return ctx->opt_t32 & (8 << which);
+    const int built = ctx->opt_t32 & UOCR_T32_BUILT;
+    if (d.cin == 4 && (d.cout == 2 || d.cout == 4)) return built & (1 << which);
+    if (d.cin == 1 && d.cout == 1) return built & (8 << which);
     return false;
 }
 
@@ -309,9 +312,14 @@ int uocr_conv_fwd_t32(uocr_ctx* ctx, const void* x, const void* w, const void* b
         return launch_t32<G>(ctx, x, w, b, y, nullptr, d.n, d.h, d.w, d.oh, d.ow, d.ph, d.pw, (float)pad_value, use_bias,
                              act, (float)act_alpha, UOCR_ACT_NONE, 0.f);
     };
+#ifdef UOCR_EXPERIMENTS
     if (d.cin == 1) return run(Geo<1, 1, 5, 5, 1, M_FWD>{});
     if (d.cout == 2) return run(Geo<4, 2, 5, 5, 1, M_FWD>{});
     return run(Geo<4, 4, 5, 5, 1, M_FWD>{});
+#else
+    (void)run;
+    UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "conv_t32 forward: library built without UOCR_BUILD_EXPERIMENTS");
+#endif
 }
 
 int uocr_conv_dgrad_t32(uocr_ctx* ctx, const void* dy, const void* w, void* dx, const ConvDims& d,
@@ -322,23 +330,30 @@ int uocr_conv_dgrad_t32(uocr_ctx* ctx, const void* dy, const void* w, void* dx, 
         return launch_t32<G>(ctx, dy, w, nullptr, dx, mask.y, d.n, d.oh, d.ow, d.h, d.w, d.kh - 1 - d.ph,
                              d.kw - 1 - d.pw, 0.f, 0, UOCR_ACT_NONE, 0.f, mact, (float)mask.alpha);
     };
+#ifdef UOCR_EXPERIMENTS
     if (d.cin == 1) return run(Geo<1, 1, 5, 5, 1, M_DGRAD>{});
+#endif
     if (d.cout == 2) return run(Geo<2, 4, 5, 5, 1, M_DGRAD>{});
     return run(Geo<4, 4, 5, 5, 1, M_DGRAD>{});
 }
 
 // backward-data of Upsample2D(2) + conv 5x5 / padding 2 (4 -> 4 or 1 -> 1 channels) on the low-res grid
 bool uocr_upconv_t32_eligible(uocr_ctx* ctx, int dtype, int cin, int cout) {
+    const int built = ctx->opt_t32 & UOCR_T32_BUILT;
     return dtype == UOCR_F32 && ctx->opt_fast &&
-           ((cin == 4 && cout == 4 && (ctx->opt_t32 & 4)) || (cin == 1 && cout == 1 && (ctx->opt_t32 & 32)));
+           ((cin == 4 && cout == 4 && (built & 4)) || (cin == 1 && cout == 1 && (built & 32)));
 }
 
 int uocr_upconv_dgrad_t32(uocr_ctx* ctx, const void* dy, const void* w, void* dx_low, int n, int hl, int wl, int ch,
                           const void* mask_y, int mask_act, double mask_alpha) {
+#ifndef UOCR_EXPERIMENTS
+    UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "upconv_t32: library built without UOCR_BUILD_EXPERIMENTS");
+#else
     const int mact = mask_y ? mask_act : UOCR_ACT_NONE;
     if (ch == 1)
         return launch_t32<Geo<1, 1, 6, 6, 2, M_UPDGRAD, 4>>(ctx, dy, w, nullptr, dx_low, mask_y, n, 2 * hl, 2 * wl, hl, wl,
                                                              2, 2, 0.f, 0, UOCR_ACT_NONE, 0.f, mact, (float)mask_alpha);
     return launch_t32<Geo<4, 4, 6, 6, 2, M_UPDGRAD>>(ctx, dy, w, nullptr, dx_low, mask_y, n, 2 * hl, 2 * wl, hl, wl, 2, 2,
                                                      0.f, 0, UOCR_ACT_NONE, 0.f, mact, (float)mask_alpha);
+#endif
 }

@@ -22,6 +22,10 @@
 // hipcc-flags: -mllvm -amdgpu-mfma-vgpr-form=1
 #include "conv_dims.h"
 
+// Off by default and slower in the page step: built only with UOCR_BUILD_EXPERIMENTS=1 ./build.sh
+// (-DUOCR_EXPERIMENTS); the default library answers "not eligible".
+#ifdef UOCR_EXPERIMENTS
+
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -379,3 +383,10 @@ int uocr_conv_wgrad_t32(uocr_ctx* ctx, const void* x, const void* dy, void* dw, 
     if (d.cout == 4) return launch_s2<1, 4>(ctx, x, dy, dw, db, d, pad_value, use_bias, accumulate);
     return launch_s2<1, 1>(ctx, x, dy, dw, db, d, pad_value, use_bias, accumulate);
 }
+
+#else
+bool uocr_conv_wgrad_t32_eligible(uocr_ctx*, int, const ConvDims&) { return false; }
+int uocr_conv_wgrad_t32(uocr_ctx* ctx, const void*, const void*, void*, void*, const ConvDims&, double, int, int) {
+    UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "conv_t32w: library built without UOCR_BUILD_EXPERIMENTS");
+}
+#endif

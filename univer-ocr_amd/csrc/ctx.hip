@@ -119,7 +119,12 @@ int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "gemm_bm")) ctx->opt_bm = value;
     else if (!strcmp(key, "xcd_remap")) ctx->opt_xcd = value;
     else if (!strcmp(key, "h16")) ctx->opt_h16 = value;
-    else if (!strcmp(key, "t32")) ctx->opt_t32 = value;
+    else if (!strcmp(key, "t32")) {
+        if (value & ~UOCR_T32_BUILT)
+            UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "option t32 = %d asks for kernels this library was built without "
+                      "(UOCR_BUILD_EXPERIMENTS=1 ./build.sh)", value);
+        ctx->opt_t32 = value;
+    }
     else if (!strcmp(key, "pair_band")) ctx->opt_pair_band = value;
     else if (!strcmp(key, "pair_g")) ctx->opt_pair_g = value;
     else if (!strcmp(key, "h3")) ctx->opt_h3 = value;

@@ -32,6 +32,12 @@ struct uocr_ctx {
 };
 
 constexpr int UOCR_SYNC_WORDS = 1 << 18;   // 1 MB
+// bits of the "t32" option whose kernels this library contains (conv_t32.hip, conv_t32w.hip)
+#ifdef UOCR_EXPERIMENTS
+constexpr int UOCR_T32_BUILT = 255;
+#else
+constexpr int UOCR_T32_BUILT = 2;
+#endif
 
 #define UOCR_FAIL(ctx, code, ...)                                   \
     do {                                                            \
