@@ -730,7 +730,7 @@ def main():
                          'frac': None if headline is None else round(headline / peak, 4),
                          'traffic': traffic, 'traffic_source': traffic_source,
                          'solo_launch_us': None if solo_us is None else round(solo_us, 2),
-                         'in_loop_launch_us': round(kernel_us, 2), 'in_loop_achieved': None if in_loop is None else round(in_loop, 2),
+                         'in_loop_launch_us': round(kernel_us, 2) if launches else None, 'in_loop_achieved': None if in_loop is None else round(in_loop, 2),
                          'launches_timed': launches,
                          'algorithmic_flops_per_launch': dominant['flops'],
                          'algorithmic_bytes_per_launch': dominant['bytes']},

@@ -453,8 +453,13 @@ def test_conv_h3_error_compensated_f16_mfma_forward(shape, pad_value, act, f32):
         alpha = 0.1
         ref = np.where(ref >= 0, ref, alpha * ref)
     Xd, wd, bd = CP.copy(X), CP.copy(w), CP.copy(b)
+    from univer_ocr_amd.hip.lib import HipError
     try:
         rt.set_option('h3', 1)
+    except HipError as e:
+        assert 'built without' in str(e)
+        pytest.skip('library built without UOCR_BUILD_EXPERIMENTS (the kernel was measured and not kept: DESIGN.md section 5c)')
+    try:
         for band in (0, 16):
             rt.set_option('pair_band', band)
             y = ops.conv2d_fwd(Xd, wd, bd, (1, 1), (2, 2), pad_value, True, act=act, alpha=alpha)
