@@ -504,6 +504,7 @@ __global__ __launch_bounds__(256) void pair_wave_bwd_h_kernel(const _Float16* __
     const uint32_t keep_l = (sidx > 0 && kq == 0) ? 0xFFFF0000u : 0xFFFFFFFFu;
     const uint32_t keep_r = (!last_strip && kq == 3) ? 0x0000FFFFu : 0xFFFFFFFFu;
     const f16x2 alpha2 = {(_Float16)alpha, (_Float16)alpha};
+    const uint32_t alpha_bits = __builtin_bit_cast(uint32_t, alpha2);
     // the dx columns this lane stores (lane = column of the strip, COLS <= 64): byte offset in the row, or past the row
     const unsigned dx_off = (lane < L::COLS && wc0 + lane >= own_lo && wc0 + lane < own_hi) ? (unsigned)(wc0 + lane) * 2u : 0x7FFFFFFFu;
 
@@ -609,10 +610,12 @@ __global__ __launch_bounds__(256) void pair_wave_bwd_h_kernel(const _Float16* __
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const uint32_t zb = cvt2h(z[g][2 * r], z[g][2 * r + 1]), sb = cvt2h(s[g][2 * r], s[g][2 * r + 1]);
+                // slope = z < 0 ? alpha : 1 on the packed halves (one v_bfi_b32), then two packed products: x * 1 is exact,
+                // so these are the values of the two selects they replace, for one instruction less
                 const uint32_t neg = neg_halves(zb);
-                const uint32_t azb = mul2h(zb, alpha2), asb = mul2h(sb, alpha2);
-                a4[g][r] = (neg & azb) | (~neg & zb);
-                d4[r] = (neg & asb) | (~neg & sb);
+                const f16x2 slope = __builtin_bit_cast(f16x2, (neg & alpha_bits) | (~neg & 0x3C003C00u));
+                a4[g][r] = mul2h(zb, slope);
+                d4[r] = mul2h(sb, slope);
             }
             dn4[g] = d4;
             if constexpr (MODE == 1) {                 // per-position selects on the packed halves
