@@ -407,6 +407,8 @@ def main():
                     help='upload every batch as uint8 from pinned host memory on a copy stream and convert on the '
                          'device (PCIe-inclusive rate; flagged in metric and config, never the headline value)')
     ap.add_argument('--lane-per-net', action='store_true', help='one lane per net instead of the balanced groups')
+    ap.add_argument('--lane-groups', default=None,
+                    help='experiment: nets per lane, e.g. "Monochrome+Char,Paragraph+Line" (default: Monochrome+Paragraph,Line,Char)')
     ap.add_argument('--lane-xcds', default=None,
                     help='EXPERIMENT: CU-partitioned lanes, XCDs per lane group, e.g. "0-2,3-5,6-7" (Monochrome+Paragraph | Line | Char)')
     ap.add_argument('--option', action='append', default=[],
@@ -484,7 +486,9 @@ def main():
                            input_grads=not args.skip_input_grads, graphs=graphs,
                            pipelined=not args.no_pipeline, data_parallel=use_dp,
                            dp_coalesce=args.dp_single_collective, dp_backend=dp_backend,
-                           **({'lane_groups': None} if args.lane_per_net else {}),
+                           **({'lane_groups': None} if args.lane_per_net else
+                              {'lane_groups': tuple(tuple(g.split('+')) for g in args.lane_groups.split(','))}
+                              if args.lane_groups else {}),
                            **({'lane_xcds': parse_xcds(args.lane_xcds)} if args.lane_xcds else {}))
     dp_fallback = None
     trainer, failure = None, None

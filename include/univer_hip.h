@@ -84,8 +84,12 @@ void* uocr_ctx_get_stream(uocr_ctx* ctx);
  * "t32" (bit mask, default 2: which float32 small-channel convolutions use the float32-MFMA Toeplitz
  * kernels: 1 forward / 2 backward-data / 4 upsample+conv backward-data of the 4-channel layers,
  * 8 / 16 / 32 the same for 1-channel layers, 64 / 128 the float32-MFMA weight gradients of the stride-1 /
- * stride-2 5x5 convolutions).  Results do not depend on any of them beyond float32
- * summation order ("h16": beyond the binary16 rounding of the weight operands). */
+ * stride-2 5x5 convolutions -- the default library contains bit 2 only, the others need a library built with
+ * UOCR_BUILD_EXPERIMENTS=1 ./build.sh and are refused with UOCR_ERR_UNSUPPORTED otherwise; likewise "h3" = 1, the
+ * float32 Line output conv forward on error-compensated binary16 MFMAs); the Monochrome pair kernels:
+ * "pair_band" (rows per band, 0 auto), "pair_g" (4 / 2 groups of 16 columns per wave), "pair_pf" (row prefetch form
+ * of the forward kernels, -1 auto).  Results do not depend on any of them beyond float32
+ * summation order ("h16": beyond the binary16 rounding of the weight operands; "h3": 22 significant bits). */
 int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value);
 int uocr_ctx_reserve_workspace(uocr_ctx* ctx, size_t bytes);   /* synchronises; not capturable */
 const char* uocr_last_error(uocr_ctx* ctx);

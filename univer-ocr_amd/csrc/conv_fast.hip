@@ -11,7 +11,6 @@
 //     butterfly across the 64 lanes (NP shuffles instead of 6*NP for a plain all-reduce), LDS
 //     across the 4 waves, one float32 partial per block; a second kernel sums the block partials
 //     in float64 in a fixed order (deterministic, no atomics).
-#include "finish_colsum.h"
 #include "conv_dims.h"
 
 namespace {
@@ -915,29 +914,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast(const TA* __restrict__ x,
     for (int a = tid; a < C::NP; a += 256) out[a] = red[0][a] + red[1][a] + red[2][a] + red[3][a];
 }
 
-// dw / db from the float64 column sums of the block partials (finish_colsum.h).  Output e = (group, accumulator a):
-// the partial matrix of group (kyg, ocg) holds NP accumulators per block, the first NW of them weights
+// block per accumulator index: sums the block partials (float64, fixed order) into dw / db
 template <int KH, int KW, int CIN, int COUT, int KYR, int COB, int NW, int NP>
-struct FastWgradEpilogue {
-    float *dw, *db;
-    int use_bias, accumulate;
-    float unscale;
-    int noutputs;
-    __device__ void store(int e, const double* sums) const {
-        constexpr int OCG = COUT / COB;
-        const int grp = e / NP, a = e % NP;
-        const int kyg = grp / OCG, ocg = grp % OCG;
-        if (a < NW) {
-            const int o = a % COB, t = a / COB;
-            const int c = t % CIN, tap = t / CIN;
-            const int kx = tap % KW, kyl = tap / KW;
-            colsum_out(dw + (((size_t)(kyg * KYR + kyl) * KW + kx) * CIN + c) * COUT + ocg * COB + o, colsum_get(sums, e),
-                       true, unscale, accumulate);
-        } else if (kyg == 0 && a - NW < COB) {             // (columns NW + COB .. NP - 1 are padding)
-            colsum_out(db + ocg * COB + (a - NW), colsum_get(sums, e), use_bias, unscale, accumulate);
-        }
+__global__ __launch_bounds__(256) void conv_wgrad_fast_finish(const float* __restrict__ partial, float* __restrict__ dw,
+                                                              float* __restrict__ db, int nblocks, int use_bias,
+                                                              int accumulate, float unscale) {
+    __shared__ double smem[16];
+    const int a = blockIdx.x, grp = blockIdx.y;
+    constexpr int OCG = COUT / COB;
+    const int kyg = grp / OCG, ocg = grp % OCG;
+    const float* src = partial + (size_t)grp * nblocks * NP + a;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += (double)src[(size_t)i * NP];
+    s = block_reduce_sum(s, smem);
+    if (threadIdx.x != 0) return;
+    float* dst;
+    if (a < NW) {
+        const int o = a % COB, t = a / COB;
+        const int c = t % CIN, tap = t / CIN;
+        const int kx = tap % KW, kyl = tap / KW;
+        dst = dw + (((size_t)(kyg * KYR + kyl) * KW + kx) * CIN + c) * COUT + ocg * COB + o;
+    } else {
+        if (kyg != 0) return;
+        dst = db + ocg * COB + (a - NW);
+        if (!use_bias) s = 0.0;
     }
-};
+    s *= (double)unscale;                                  // UOCR_F16_SCALED(k): 2^-k, else 1
+    *dst = accumulate ? (float)((double)*dst + s) : (float)s;
+}
 
 // ---------------------------------------------------------------------------------------------
 // dw / db of the Line output conv (5x5, 4 -> 2, stride 1, pad 2) from an LDS tile.  conv_wgrad_fast gives
@@ -1027,19 +1031,23 @@ __global__ __launch_bounds__(320) void conv_wgrad_t542(const TA* __restrict__ x,
     if (lane < NACC) partial[(blk * 5 + ky) * NACC + lane] = acc[0];
 }
 
-// outputs a < 200: dw[a] (= tap row a / 40, accumulator a % 40); a = 200, 201: db (from tap row 0's waves); the column
-// sums of the partials [block][tap row][NACC] come from finish_colsum.h
-struct T542Epilogue {
-    float *dw, *db;
-    int use_bias, accumulate;
-    float unscale;
-    int noutputs;
-    __device__ void store(int a, const double* sums) const {
-        using namespace t542;
-        if (a < 200) colsum_out(dw + a, colsum_get(sums, (a / 40) * NACC + a % 40), true, unscale, accumulate);
-        else colsum_out(db + (a - 200), colsum_get(sums, 40 + (a - 200)), use_bias, unscale, accumulate);
-    }
-};
+// block a < 200: dw[a] (= tap row a / 40, accumulator a % 40); a = 200, 201: db (from tap row 0's waves)
+__global__ __launch_bounds__(256) void conv_wgrad_t542_finish(const float* __restrict__ partial, float* __restrict__ dw,
+                                                              float* __restrict__ db, int nblocks, int use_bias,
+                                                              int accumulate, float unscale) {
+    using namespace t542;
+    __shared__ double smem[16];
+    const int a = blockIdx.x;
+    const int ky = a < 200 ? a / 40 : 0, idx = a < 200 ? a % 40 : 40 + (a - 200);
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += (double)partial[((size_t)i * 5 + ky) * NACC + idx];
+    s = block_reduce_sum(s, smem);
+    if (threadIdx.x != 0) return;
+    float* dst = a < 200 ? dw + a : db + (a - 200);
+    if (a >= 200 && !use_bias) s = 0.0;
+    s *= (double)unscale;                                  // UOCR_F16_SCALED(k): 2^-k, else 1
+    *dst = accumulate ? (float)((double)*dst + s) : (float)s;
+}
 
 // ---------------------------------------------------------------------------------------------
 // dw / db of the 5x5 / stride 2 / pad 2 encoder convs (Paragraph down_1/2: 1 -> 1, Line down_1: 1 -> 4,
@@ -1125,21 +1133,24 @@ __global__ __launch_bounds__(320) void conv_wgrad_s2_tiled(const TA* __restrict_
     for (int q = 0; q < C::NP / 64; ++q) out[base + q] = acc[q];
 }
 
-// outputs a < 25 * CIN * COUT: dw[a] (tap row a / NW, accumulator a % NW); then COUT outputs for db; column sums of the
-// partials [block][tap row][NP] from finish_colsum.h
+// block a < 25 * CIN * COUT: dw[a] (tap row a / NW, accumulator a % NW); then COUT blocks for db
 template <int CIN, int COUT>
-struct S2Epilogue {
-    float *dw, *db;
-    int use_bias, accumulate;
-    float unscale;
-    int noutputs;
-    __device__ void store(int a, const double* sums) const {
-        using C = S2Cfg<CIN, COUT>;
-        constexpr int ndw = 5 * C::NW;
-        if (a < ndw) colsum_out(dw + a, colsum_get(sums, (a / C::NW) * C::NP + a % C::NW), true, unscale, accumulate);
-        else colsum_out(db + (a - ndw), colsum_get(sums, C::NW + (a - ndw)), use_bias, unscale, accumulate);
-    }
-};
+__global__ __launch_bounds__(256) void conv_wgrad_s2_finish(const float* __restrict__ partial, float* __restrict__ dw,
+                                                            float* __restrict__ db, int nblocks, int use_bias,
+                                                            int accumulate, float unscale) {
+    using C = S2Cfg<CIN, COUT>;
+    __shared__ double smem[16];
+    const int a = blockIdx.x, ndw = 5 * C::NW;
+    const int ky = a < ndw ? a / C::NW : 0, idx = a < ndw ? a % C::NW : C::NW + (a - ndw);
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += (double)partial[((size_t)i * 5 + ky) * C::NP + idx];
+    s = block_reduce_sum(s, smem);
+    if (threadIdx.x != 0) return;
+    float* dst = a < ndw ? dw + a : db + (a - ndw);
+    if (a >= ndw && !use_bias) s = 0.0;
+    s *= (double)unscale;                                  // UOCR_F16_SCALED(k): 2^-k, else 1
+    *dst = accumulate ? (float)((double)*dst + s) : (float)s;
+}
 
 template <int CIN, int COUT>
 int launch_wgrad_s2(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
@@ -1158,10 +1169,11 @@ int launch_wgrad_s2(uocr_ctx* ctx, int dtype, const void* x, const void* dy, voi
                            (const TA*)dy, partial, d.h, d.w, d.oh, d.ow, (float)pad_value, per_block);
     });
     UOCR_LAUNCH_CHECK(ctx);
-    const ColsumLayout L{partial, nblocks, 5 * C::NP, 5 * C::NP, 0, (size_t)5 * C::NP};
-    return launch_colsum_finish(ctx, L, (size_t)nblocks * 5 * C::NP * sizeof(float), 384,
-                                S2Epilogue<CIN, COUT>{(float*)dw, (float*)db, use_bias, accumulate,
-                                                      (float)uocr_grad_unscale(dtype), 5 * C::NW + COUT});
+    hipLaunchKernelGGL((conv_wgrad_s2_finish<CIN, COUT>), dim3(5 * C::NW + COUT), dim3(256), 0, ctx->stream,
+                       (const float*)partial, (float*)dw, (float*)db, nblocks, use_bias, accumulate,
+                       (float)uocr_grad_unscale(dtype));
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
 }
 
 template <int KH, int KW, int CIN, int COUT, int SH, int SW, int COB, int PY, int DPY, int KYR, int WCOB, int WPY, int FPX,
@@ -1234,12 +1246,11 @@ struct FastConv {
                                partial, dims(d), (float)pad, rows, nbands);
         });
         UOCR_LAUNCH_CHECK(ctx);
-        static_assert(C::NACC <= C::NP, "accumulators per block");
-        const ColsumLayout L{partial, nblocks, ngroups * C::NP, C::NP, (size_t)nblocks * C::NP, (size_t)C::NP};
-        return launch_colsum_finish(ctx, L, bytes, 1024,
-                                    FastWgradEpilogue<KH, KW, CIN, COUT, KYR, WCOB, C::NW, C::NP>{
-                                        (float*)dw, (float*)db, use_bias, accumulate, (float)uocr_grad_unscale(dtype),
-                                        ngroups * C::NP});
+        hipLaunchKernelGGL((conv_wgrad_fast_finish<KH, KW, CIN, COUT, KYR, WCOB, C::NW, C::NP>),
+                           dim3(C::NACC, ngroups), dim3(256), 0, ctx->stream, (const float*)partial, (float*)dw,
+                           (float*)db, nblocks, use_bias, accumulate, (float)uocr_grad_unscale(dtype));
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
     }
 };
 
@@ -1404,10 +1415,10 @@ int uocr_conv_wgrad_fast(uocr_ctx* ctx, int dtype, const void* x, const void* dy
                                partial, d.h, d.w, (float)pad_value, per_block);
         });
         UOCR_LAUNCH_CHECK(ctx);
-        const ColsumLayout L{partial, nblocks, 5 * t542::NACC, 5 * t542::NACC, 0, (size_t)5 * t542::NACC};
-        return launch_colsum_finish(ctx, L, (size_t)nblocks * 5 * t542::NACC * sizeof(float), 256,
-                                    T542Epilogue{(float*)dw, (float*)db, use_bias, accumulate,
-                                                 (float)uocr_grad_unscale(dtype), 202});
+        hipLaunchKernelGGL(conv_wgrad_t542_finish, dim3(202), dim3(256), 0, ctx->stream, (const float*)partial,
+                           (float*)dw, (float*)db, nblocks, use_bias, accumulate, (float)uocr_grad_unscale(dtype));
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
     }
 #define X(KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX)                   \
     if (FastConv<KH, KW, CIN, COUT, SH, SW, COB, PY, DPY, KYR, WCOB, WPY, FPX, DPX>::match(d)) \

@@ -18,7 +18,6 @@
 //     back into the 5x5 kernel by conv_up.hip's finish kernel.
 // Blocks are persistent over a flat tile index; one reduction per block, float64 finish.
 // hipcc-flags: -mllvm -amdgpu-mfma-vgpr-form=1
-#include "finish_colsum.h"
 #include "conv_dims.h"
 
 namespace {
@@ -288,22 +287,20 @@ __global__ __launch_bounds__(256) void wgrad_h16_e11_kernel(const _Float16* __re
     if (tid < NV) partial[(size_t)blockIdx.x * NV + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
-// out[a] (+)= unscale * column sum a of the block partials (finish_colsum.h); a < ndw -> dw, else db
-struct H16WgradEpilogue {
-    float *dw, *db;
-    int ndw, use_bias, accumulate;
-    float unscale;
-    int noutputs;
-    __device__ void store(int a, const double* sums) const {
-        if (a < ndw) colsum_out(dw + a, colsum_get(sums, a), true, unscale, accumulate);
-        else colsum_out(db + (a - ndw), colsum_get(sums, a), use_bias, unscale, accumulate);
-    }
-};
-static int wgrad_h16_finish(uocr_ctx* ctx, const float* partial, int nv, int ndw, float* dw, float* db, int nblocks,
-                            int use_bias, int accumulate, float unscale) {
-    const ColsumLayout L{partial, nblocks, nv, nv, 0, (size_t)nv};
-    return launch_colsum_finish(ctx, L, (size_t)nblocks * nv * sizeof(float), 512,
-                                H16WgradEpilogue{dw, db, ndw, use_bias, accumulate, unscale, nv});
+// block a: out[a] (+)= unscale * sum over blocks of partial[blk][a]; a < ndw -> dw, else db
+__global__ __launch_bounds__(256) void wgrad_h16_finish(const float* __restrict__ partial, int nv, int ndw,
+                                                        float* __restrict__ dw, float* __restrict__ db, int nblocks,
+                                                        int use_bias, int accumulate, float unscale) {
+    __shared__ double smem[16];
+    const int a = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s += (double)partial[(size_t)i * nv + a];
+    s = block_reduce_sum(s, smem);
+    if (threadIdx.x != 0) return;
+    float* dst = a < ndw ? dw + a : db + (a - ndw);
+    if (a >= ndw && !use_bias) s = 0.0;
+    s *= (double)unscale;                                  // UOCR_F16_SCALED(k): 2^-k
+    *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -804,8 +801,11 @@ int uocr_conv_wgrad_h16(uocr_ctx* ctx, int dtype, const void* x, const void* dy,
                        (const _Float16*)x, (const _Float16*)dy, partial, d.h, d.w, tiles_x, tiles_y, (int)ntiles,
                        (float)pad_value);
     UOCR_LAUNCH_CHECK(ctx);
-    return wgrad_h16_finish(ctx, partial, nv, one ? 25 : 200, (float*)dw, (float*)db, grid, use_bias, accumulate,
-                            (float)uocr_grad_unscale(dtype));
+    hipLaunchKernelGGL(wgrad_h16_finish, dim3(nv), dim3(256), 0, ctx->stream, (const float*)partial, nv,
+                       one ? 25 : 200, (float*)dw, (float*)db, grid, use_bias, accumulate,
+                       (float)uocr_grad_unscale(dtype));
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
 }
 
 // partial rows in the layout of conv_up.hip's finish kernels: 4 channels [(m * 4 + ci) * 16 + phase * 4 + co], then
@@ -865,8 +865,10 @@ int launch_s2(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw,
     hipLaunchKernelGGL((wgrad_h16_s2_kernel<CI, CO>), dim3(grid), dim3(256), 0, ctx->stream, (const _Float16*)x,
                        (const _Float16*)dy, partial, d.h, d.w, d.oh, d.ow, tiles_x, tiles_y, (int)ntiles, (float)pad_value);
     UOCR_LAUNCH_CHECK(ctx);
-    return wgrad_h16_finish(ctx, partial, G::NV, 25 * CI * CO, (float*)dw, (float*)db, grid, use_bias, accumulate,
-                            (float)uocr_grad_unscale(dtype));
+    hipLaunchKernelGGL(wgrad_h16_finish, dim3(G::NV), dim3(256), 0, ctx->stream, (const float*)partial, G::NV,
+                       25 * CI * CO, (float*)dw, (float*)db, grid, use_bias, accumulate, (float)uocr_grad_unscale(dtype));
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
 }
 }  // namespace
 

@@ -28,7 +28,6 @@
 
 #include "conv_pair.h"
 #include "conv_pair_strip.h"
-#include "finish_colsum.h"
 #include "uocr_common.h"
 
 namespace {
@@ -566,23 +565,44 @@ __global__ __launch_bounds__(512) void pair_strip_fwd_kernel(const float* __rest
     }
 }
 
-// dw / db from the float64 column sums of the block partials (finish_colsum.h): the columns that are outputs
-// (dw1: 9 x 16, db1 = row 9 of dW1^T, dw2, db2)
-struct PairEpilogue {
-    float *dw1, *db1, *dw2, *db2;
-    int use_b1, use_b2, accumulate;
-    float unscale;
-    int noutputs;
-    __device__ void store(int j, const double* sums) const {
-        float* dst = nullptr;
-        bool live = true;
-        if (j < 144) dst = dw1 + j;                                           // dW1^T[tap][ch] = dw1[tap * 16 + ch]
-        else if (j < 160) { dst = db1 + (j - 144); live = use_b1; }           // row 9: the ones copy
-        else if (j >= 256 && j < 256 + 144) dst = dw2 + (j - 256);
-        else if (j == 512) { dst = db2; live = use_b2; }
-        if (dst) colsum_out(dst, colsum_get(sums, j), live, unscale, accumulate);
+// Sum of the block partials in float64, fixed order.  Block = 32 consecutive partial columns x 32 segments of the
+// blocks (coalesced 128-byte reads, 8 loads in flight per thread), segments added in order; then the columns that
+// are outputs (dw1: 9 x 16, db1 = row 9 of dW1^T, dw2, db2) are stored.
+__global__ __launch_bounds__(1024) void pair_strip_finish(const float* __restrict__ partial, float* __restrict__ dw1,
+                                                        float* __restrict__ db1, float* __restrict__ dw2,
+                                                        float* __restrict__ db2, int nblocks, int use_b1, int use_b2,
+                                                        int accumulate, float unscale) {
+    constexpr int NSEG = 32;
+    __shared__ double seg[NSEG][32];
+    const int o = threadIdx.x & 31, sg = threadIdx.x >> 5, j = blockIdx.x * 32 + o;
+    double s = 0.0;
+    if (j < PAIR_NPART) {
+        const int per = (nblocks + NSEG - 1) / NSEG, b0 = sg * per, b1 = min(nblocks, b0 + per);
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = partial[(size_t)(b + k) * PAIR_NPART + j];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += (double)v[k];
+        }
+        for (; b < b1; ++b) s += (double)partial[(size_t)b * PAIR_NPART + j];
     }
-};
+    seg[sg][o] = s;
+    __syncthreads();
+    if (sg != 0 || j >= PAIR_NPART) return;
+#pragma unroll
+    for (int k = 1; k < NSEG; ++k) s += seg[k][o];
+    float* dst = nullptr;
+    bool live = true;
+    if (j < 144) dst = dw1 + j;                                           // dW1^T[tap][ch] = dw1[tap * 16 + ch]
+    else if (j < 160) { dst = db1 + (j - 144); live = use_b1; }           // row 9: the ones copy
+    else if (j >= 256 && j < 256 + 144) dst = dw2 + (j - 256);
+    else if (j == 512) { dst = db2; live = use_b2; }
+    if (!dst) return;
+    s = live ? s * (double)unscale : 0.0;
+    *dst = accumulate ? (float)((double)*dst + s) : (float)s;
+}
 
 template <int G>
 size_t strip_lds_bytes(int nw, bool dx) {
@@ -684,7 +704,8 @@ int uocr_pair_strip_fwd_f32(uocr_ctx* ctx, const float* x, const float* w1, cons
 
 int uocr_pair_strip_finish(uocr_ctx* ctx, const float* partial, float* dw1, float* db1, float* dw2, float* db2,
                            int nblocks, int use_b1, int use_b2, int accumulate, float unscale) {
-    const ColsumLayout L{partial, nblocks, PAIR_NPART, PAIR_NPART, 0, (size_t)PAIR_NPART};
-    return launch_colsum_finish(ctx, L, (size_t)nblocks * PAIR_NPART * sizeof(float), 32,
-                                PairEpilogue{dw1, db1, dw2, db2, use_b1, use_b2, accumulate, unscale, PAIR_NPART});
+    hipLaunchKernelGGL(pair_strip_finish, dim3((PAIR_NPART + 31) / 32), dim3(1024), 0, ctx->stream, partial, dw1, db1, dw2,
+                       db2, nblocks, use_b1, use_b2, accumulate, unscale);
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
 }

@@ -22,7 +22,6 @@
 // float32 rounding (tests: 1e-5 normalised), not bit for bit.
 // hipcc-flags: -mllvm -amdgpu-mfma-vgpr-form=1
 // (MFMA accumulators in VGPRs: no v_accvgpr copies between the MFMAs and the VALU code that consumes them)
-#include "finish_colsum.h"
 #include "conv_dims.h"
 
 namespace {
@@ -218,20 +217,18 @@ __global__ __launch_bounds__(256) void upconv_wgrad_kernel(const TA* __restrict_
     }
 }
 
-// dw[ky][kx][c][o] (+)= sum over phases of the column sums of dWeff[(m(py,ky), m(px,kx)), c, (phase,o)] (outputs
-// e < 400); e = 400..403: db[o].  The column sums come from finish_colsum.h.
-struct UpconvEpilogue {
-    float *dw, *db;
-    int use_bias, accumulate;
-    float unscale;
-    int noutputs;
-    __device__ void store(int e, const double* sums) const {
-        if (e >= 400) {
-            colsum_out(db + (e - 400), colsum_get(sums, 36 * 16 + (e - 400)), use_bias, unscale, accumulate);
-            return;
-        }
+// block i < 400: dw[ky][kx][c][o] (+)= sum over blocks and phases of dWeff[(m(py,ky), m(px,kx)), c, (phase,o)];
+// blocks 400..403: db[o]
+__global__ __launch_bounds__(256) void upconv_wgrad_finish(const float* __restrict__ partial, float* __restrict__ dw,
+                                                           float* __restrict__ db, int nblocks, int use_bias,
+                                                           int accumulate, float unscale) {
+    __shared__ double smem[16];
+    const int e = blockIdx.x;
+    double s = 0.0;
+    float* dst;
+    if (e < 400) {
         const int o = e & 3, c = (e >> 2) & 3, kk = e >> 4, ky = kk / 5, kx = kk % 5;
-        double s = 0.0;
+        int idx[4];
 #pragma unroll
         for (int phase = 0; phase < 4; ++phase) {
             int my = 0, mx = 0, lo, hi;
@@ -241,11 +238,25 @@ struct UpconvEpilogue {
                 tap_group(phase & 1, mi, lo, hi);
                 if (kx >= lo && kx < hi) mx = mi;
             }
-            s += colsum_get(sums, ((my * 3 + mx) * CH + c) * 16 + phase * 4 + o);
+            idx[phase] = ((my * 3 + mx) * CH + c) * 16 + phase * 4 + o;
         }
-        colsum_out(dw + e, s, true, unscale, accumulate);
+        for (int blk = threadIdx.x; blk < nblocks; blk += blockDim.x) {
+            const float* p = partial + (size_t)blk * (36 * 16 + 4);
+            s += (double)p[idx[0]] + (double)p[idx[1]] + (double)p[idx[2]] + (double)p[idx[3]];
+        }
+        dst = dw + e;
+    } else {
+        const int o = e - 400;
+        for (int blk = threadIdx.x; blk < nblocks; blk += blockDim.x)
+            s += (double)partial[(size_t)blk * (36 * 16 + 4) + 36 * 16 + o];
+        dst = db + o;
     }
-};
+    s = block_reduce_sum(s, smem);
+    if (threadIdx.x != 0) return;
+    if (e >= 400 && !use_bias) s = 0.0;
+    s *= (double)unscale;                                // UOCR_F16_SCALED(k): 2^-k, else 1
+    *dst = accumulate ? (float)((double)*dst + s) : (float)s;
+}
 
 // dx on the vector ALU.  Block = 16 x 32 low-res positions, 2 per thread (rows r and r + 8); dy tile of the
 // (16 + 2) x (32 + 2) source blocks = 36 x 68 high-res pixels in LDS.
@@ -460,19 +471,16 @@ __global__ __launch_bounds__(256) void up1_wgrad_kernel(const TA* __restrict__ x
     if (tid < 37) partial[(size_t)blk * 37 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
-// dw[ky][kx] (+)= sum over phases of the column sums (outputs e < 25), e = 25: db
-struct Up1Epilogue {
-    float *dw, *db;
-    int use_bias, accumulate;
-    float unscale;
-    int noutputs;
-    __device__ void store(int e, const double* sums) const {
-        if (e >= 25) {
-            colsum_out(db, colsum_get(sums, 36), use_bias, unscale, accumulate);
-            return;
-        }
+// block e < 25: dw[ky][kx] (+)= sum over blocks and phases of dWeff[m(phase, k)][phase]; block 25: db
+__global__ __launch_bounds__(256) void up1_wgrad_finish(const float* __restrict__ partial, float* __restrict__ dw,
+                                                        float* __restrict__ db, int nblocks, int use_bias,
+                                                        int accumulate, float unscale) {
+    __shared__ double smem[16];
+    const int e = blockIdx.x;
+    double s = 0.0;
+    if (e < 25) {
         const int ky = e / 5, kx = e % 5;
-        double s = 0.0;
+        int idx[4];
 #pragma unroll
         for (int phase = 0; phase < 4; ++phase) {
             int my = 0, mx = 0, lo, hi;
@@ -482,11 +490,22 @@ struct Up1Epilogue {
                 tap_group(phase & 1, mi, lo, hi);
                 if (kx >= lo && kx < hi) mx = mi;
             }
-            s += colsum_get(sums, (my * 3 + mx) * 4 + phase);
+            idx[phase] = (my * 3 + mx) * 4 + phase;
         }
-        colsum_out(dw + e, s, true, unscale, accumulate);
+        for (int blk = threadIdx.x; blk < nblocks; blk += blockDim.x) {
+            const float* p = partial + (size_t)blk * 37;
+            s += (double)p[idx[0]] + (double)p[idx[1]] + (double)p[idx[2]] + (double)p[idx[3]];
+        }
+    } else {
+        for (int blk = threadIdx.x; blk < nblocks; blk += blockDim.x) s += (double)partial[(size_t)blk * 37 + 36];
     }
-};
+    s = block_reduce_sum(s, smem);
+    if (threadIdx.x != 0) return;
+    float* dst = e < 25 ? dw + e : db;
+    if (e == 25 && !use_bias) s = 0.0;
+    s *= (double)unscale;
+    *dst = accumulate ? (float)((double)*dst + s) : (float)s;
+}
 
 int up_rows_per_block(int strips, int hl, int n, unsigned max_blocks = 2048u) {
     int rows = RH;
@@ -565,20 +584,6 @@ extern "C" int uocr_upconv2x_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, 
     return UOCR_OK;
 }
 
-// float64 column sums of the block partials + the phase sums into dw / db: one launch (finish_colsum.h)
-static int up_finish(uocr_ctx* ctx, const float* partial, int nblocks, int cin, float* dw, float* db, int use_bias,
-                     int accumulate, float unscale) {
-    if (cin == 1) {
-        const ColsumLayout L{partial, nblocks, 37, 37, 0, 37};
-        return launch_colsum_finish(ctx, L, (size_t)nblocks * 37 * sizeof(float), 128,
-                                    Up1Epilogue{dw, db, use_bias, accumulate, unscale, 26});
-    }
-    constexpr int NV = 36 * 16 + 4;
-    const ColsumLayout L{partial, nblocks, NV, NV, 0, NV};
-    return launch_colsum_finish(ctx, L, (size_t)nblocks * NV * sizeof(float), 128,
-                                UpconvEpilogue{dw, db, use_bias, accumulate, unscale, 404});
-}
-
 extern "C" int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_low, const void* dy, void* dw, void* db,
                                         int n, int hl, int wl, int cin, int cout, int kh, int kw, int ph, int pw,
                                         int use_bias, int accumulate) {
@@ -596,8 +601,14 @@ extern "C" int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_
         int nblocks = 0;
         rc = uocr_upconv_wgrad_h16(ctx, x_low, dy, (float*)ctx->workspace, floats, n, hl, wl, cin, &nblocks);
         if (rc != UOCR_OK) return rc;
-        return up_finish(ctx, (const float*)ctx->workspace, nblocks, cin, (float*)dw, (float*)db, use_bias, accumulate,
-                         unscale);
+        if (cin == 1)
+            hipLaunchKernelGGL(up1_wgrad_finish, dim3(26), dim3(256), 0, ctx->stream, (const float*)ctx->workspace,
+                               (float*)dw, (float*)db, nblocks, use_bias, accumulate, unscale);
+        else
+            hipLaunchKernelGGL(upconv_wgrad_finish, dim3(404), dim3(256), 0, ctx->stream, (const float*)ctx->workspace,
+                               (float*)dw, (float*)db, nblocks, use_bias, accumulate, unscale);
+        UOCR_LAUNCH_CHECK(ctx);
+        return UOCR_OK;
     }
     // fewer, longer blocks than the forward: every block ends with a reduction and a partial row for the finish kernel
     const int strips = (wl + RW - 1) / RW, rows = up_rows_per_block(strips, hl, n, 1024u);
@@ -614,5 +625,12 @@ extern "C" int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_
                                (const TA*)x_low, (const TA*)dy, partial, hl, wl, rows);
     });
     UOCR_LAUNCH_CHECK(ctx);
-    return up_finish(ctx, partial, nblocks, cin, (float*)dw, (float*)db, use_bias, accumulate, unscale);
+    if (cin == 1)
+        hipLaunchKernelGGL(up1_wgrad_finish, dim3(26), dim3(256), 0, ctx->stream, (const float*)partial, (float*)dw,
+                           (float*)db, nblocks, use_bias, accumulate, unscale);
+    else
+        hipLaunchKernelGGL(upconv_wgrad_finish, dim3(404), dim3(256), 0, ctx->stream, (const float*)partial, (float*)dw,
+                           (float*)db, nblocks, use_bias, accumulate, unscale);
+    UOCR_LAUNCH_CHECK(ctx);
+    return UOCR_OK;
 }

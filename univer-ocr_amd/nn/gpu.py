@@ -120,12 +120,14 @@ class Runtime:
         """Kernel selection knobs of the C ABI: 'mfma' (0 never / 1 auto / 2 whenever eligible),
         'fast_paths' (0 generic kernels only / 1 shape-specialised).  Applied to every lane."""
         current = self.ctx
+        try:
+            for handle in [h for h, _ in self._lanes] + [s.handle for s in self._sides.values()]:
+                self.ctx = handle
+                self.call('uocr_ctx_set_option', key.encode(), int(value))
+        finally:
+            self.ctx = current
         self._options = getattr(self, '_options', {})
-        self._options[key] = int(value)
-        for handle in [h for h, _ in self._lanes] + [s.handle for s in self._sides.values()]:
-            self.ctx = handle
-            self.call('uocr_ctx_set_option', key.encode(), int(value))
-        self.ctx = current
+        self._options[key] = int(value)              # (replayed on contexts made later: side streams)
 
     # -- side stream of a lane: kernels nobody waits for until the end of the backward pass (weight gradients) --------
     def side(self, *keep):
