@@ -565,16 +565,19 @@ __global__ __launch_bounds__(512) void pair_strip_fwd_kernel(const float* __rest
     }
 }
 
-// Sum of the block partials in float64, fixed order.  Block = 32 consecutive partial columns x 32 segments of the
-// blocks (coalesced 128-byte reads, 8 loads in flight per thread), segments added in order; then the columns that
-// are outputs (dw1: 9 x 16, db1 = row 9 of dW1^T, dw2, db2) are stored.
-__global__ __launch_bounds__(1024) void pair_strip_finish(const float* __restrict__ partial, float* __restrict__ dw1,
-                                                        float* __restrict__ db1, float* __restrict__ dw2,
-                                                        float* __restrict__ db2, int nblocks, int use_b1, int use_b2,
-                                                        int accumulate, float unscale) {
+// Sum of the block partials in float64, fixed order.  Block = FC consecutive partial columns x 32 segments of the
+// blocks (8 loads in flight per thread), segments added in order; then the columns that are outputs (dw1: 9 x 16,
+// db1 = row 9 of dW1^T, dw2, db2) are stored.  FC = 8: 256-thread blocks -- with 32 columns (1024 threads) a block
+// needs sixteen free wave slots on one CU at once, which the other lanes' kernels rarely leave inside the page step:
+// rocprofv3 averaged 23 us there for the 1 000 partials of the 8 x 1024 x 2048 step (4.9 us at 32 x 256 x 512).
+constexpr int FC = 8;
+__global__ __launch_bounds__(FC * 32) void pair_strip_finish(const float* __restrict__ partial, float* __restrict__ dw1,
+                                                          float* __restrict__ db1, float* __restrict__ dw2,
+                                                          float* __restrict__ db2, int nblocks, int use_b1, int use_b2,
+                                                          int accumulate, float unscale) {
     constexpr int NSEG = 32;
-    __shared__ double seg[NSEG][32];
-    const int o = threadIdx.x & 31, sg = threadIdx.x >> 5, j = blockIdx.x * 32 + o;
+    __shared__ double seg[NSEG][FC];
+    const int o = threadIdx.x % FC, sg = threadIdx.x / FC, j = blockIdx.x * FC + o;
     double s = 0.0;
     if (j < PAIR_NPART) {
         const int per = (nblocks + NSEG - 1) / NSEG, b0 = sg * per, b1 = min(nblocks, b0 + per);
@@ -704,7 +707,7 @@ int uocr_pair_strip_fwd_f32(uocr_ctx* ctx, const float* x, const float* w1, cons
 
 int uocr_pair_strip_finish(uocr_ctx* ctx, const float* partial, float* dw1, float* db1, float* dw2, float* db2,
                            int nblocks, int use_b1, int use_b2, int accumulate, float unscale) {
-    hipLaunchKernelGGL(pair_strip_finish, dim3((PAIR_NPART + 31) / 32), dim3(1024), 0, ctx->stream, partial, dw1, db1, dw2,
+    hipLaunchKernelGGL(pair_strip_finish, dim3((PAIR_NPART + FC - 1) / FC), dim3(FC * 32), 0, ctx->stream, partial, dw1, db1, dw2,
                        db2, nblocks, use_b1, use_b2, accumulate, unscale);
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
