@@ -7,14 +7,14 @@ OUT=$R/gpurun_out/quick_$CFG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d "$OUT" --output-format csv -- \
-    python3 "$R/bench.py" --config $CFG --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > "$OUT/bench.json" 2> "$OUT/err.txt"
+    python3 "$R/bench.py" --config $CFG --steps 20 --warmup 5 --steady-steps 0 --no-cpu-baseline --no-secondary > "$OUT/bench.json" 2> "$OUT/err.txt"
 cd "$R"
 python3 - "$OUT" <<'PY'
 import csv, glob, sys
 out = sys.argv[1]
 paths = [p for p in glob.glob(f'{out}/*/*_kernel_stats.csv') if 'pair' in open(p).read()]
 rows = list(csv.DictReader(open(paths[0])))
-steps = 25
+steps = 46
 total = sum(float(r['TotalDurationNs']) for r in rows); calls = sum(int(r['Calls']) for r in rows)
 print(f'kernel time {total/1e6/steps:.3f} ms/step, {calls/steps:.1f} kernels/step')
 for r in rows[:60]:

@@ -5,6 +5,7 @@
 //   SegmentationDice2D / SegmentationJaccard2D ... losses.py:9-42
 //   SigmoidCrossEntropy .......................... losses.py:45-57
 //   SoftmaxCrossEntropy .......................... losses.py:60-73
+#include <algorithm>
 #include <type_traits>
 
 #include "uocr_common.h"
@@ -209,8 +210,7 @@ __global__ __launch_bounds__(256) void seg_partial_vec_kernel(const T* __restric
     double s_pg[C], s_p[C], s_g[C];
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) s_pg[ch] = s_p[ch] = s_g[ch] = 0.0;
-    for (size_t q = v0 + threadIdx.x; q < v1; q += blockDim.x) {
-        const VecOf<T, V> pv = p4[q], gv = g4[q];
+    auto add = [&](const VecOf<T, V>& pv, const VecOf<T, V>& gv) {
         float a_pg[C], a_p[C], a_g[C];
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) a_pg[ch] = a_p[ch] = a_g[ch] = 0.f;
@@ -227,7 +227,22 @@ __global__ __launch_bounds__(256) void seg_partial_vec_kernel(const T* __restric
             s_p[ch] += (double)a_p[ch];
             s_g[ch] += (double)a_g[ch];
         }
+    };
+    // U vectors of each tensor in flight per thread (2 x 16 bytes per trip left the kernel waiting for HBM: 2 blocks of
+    // 256 threads per CU hold 16 KB in flight; the vectors are added in the order of the one-at-a-time loop)
+    constexpr int U = 8;
+    size_t q = v0 + threadIdx.x;
+    for (; q + (U - 1) * blockDim.x < v1; q += U * blockDim.x) {
+        VecOf<T, V> pv[U], gv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pv[u] = p4[q + u * blockDim.x];
+            gv[u] = g4[q + u * blockDim.x];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) add(pv[u], gv[u]);
     }
+    for (; q < v1; q += blockDim.x) add(p4[q], g4[q]);
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) {
         const double t_pg = block_reduce_sum(s_pg[ch], smem);
@@ -242,56 +257,86 @@ __global__ __launch_bounds__(256) void seg_partial_vec_kernel(const T* __restric
     }
 }
 
+// The gradient kernel has its OWN, finer chunking (`nchunks` blocks per image, up to 512: an HBM stream wants many
+// blocks; the sums kernel ends in block reductions and is better off with fewer, `pchunks`): wave 0 adds the
+// pchunks partial sums of the image's channels (lanes over the chunks, then the wave tree: a fixed order).
 template <typename T, int C, int KIND>
 __global__ __launch_bounds__(256) void seg_grad_vec_kernel(const T* __restrict__ pred, const T* __restrict__ gt,
                                                            const double* __restrict__ partial, T* __restrict__ grad,
-                                                           double* __restrict__ loss_out, int hw, int nchunks,
-                                                           int npairs, int out_act, double gscale) {
+                                                           double* __restrict__ loss_out, int hw, int pchunks,
+                                                           int nchunks, int npairs, int out_act, double gscale) {
     constexpr int V = 16 / (int)sizeof(T);
     __shared__ double smem[16];
     __shared__ float coef[C][2];
-    const int chunk = blockIdx.x, b = blockIdx.y;
-    if (chunk == 0 && b == 0) {                          // the loss: sum over all (image, channel) pairs
+    // grid row 0 is the loss row: its block 0 adds up the loss of all (image, channel) pairs -- wave w takes pairs w,
+    // w + 4, ...: lanes over the chunks, then the wave tree -- while the rows behind it stream; the other blocks of the
+    // row leave at once.  (As a prologue of block (0, 0), with one thread per pair walking the chunks, it was the
+    // critical path of the whole launch: 12 of 34 us at 8 x 1024 x 2048.)
+    if (blockIdx.y == 0) {
+        if (blockIdx.x != 0) return;
+        // groups of gs = 16 / 32 / 64 lanes (the smallest that holds the chunks) take one pair each: 256 / gs pairs per
+        // round; butterfly sums inside a group (every lane ends with the total, a fixed tree)
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int gs = pchunks <= 16 ? 16 : pchunks <= 32 ? 32 : 64;
+        const int sub = threadIdx.x % gs, grp = threadIdx.x / gs, ngrp = 256 / gs;
         double loss = 0.0;
-        for (int q = threadIdx.x; q < npairs; q += blockDim.x) {
+        for (int q0 = 0; q0 < npairs; q0 += ngrp) {
+            const int q = q0 + grp;
             double s_pg = 0.0, s_p = 0.0, s_g = 0.0;
-            for (int k = 0; k < nchunks; ++k) {
-                const double* o = partial + ((size_t)q * nchunks + k) * 3;
+            if (q < npairs)
+                for (int k = sub; k < pchunks; k += gs) {
+                    const double* o = partial + ((size_t)q * pchunks + k) * 3;
+                    s_pg += o[0];
+                    s_p += o[1];
+                    s_g += o[2];
+                }
+            for (int off = gs >> 1; off > 0; off >>= 1) {
+                s_pg += __shfl_xor(s_pg, off, 64);
+                s_p += __shfl_xor(s_p, off, 64);
+                s_g += __shfl_xor(s_g, off, 64);
+            }
+            double num, den;
+            seg_num_den<KIND>(s_pg, s_p, s_g, num, den);
+            if (sub == 0 && q < npairs) loss += KIND == UOCR_LOSS_DICE ? 1.0 - 2.0 * num / den : 1.0 - num / den;   // losses.py:22,40
+        }
+        // the group leaders' terms: lanes 0, gs, 2 gs, ... of the wave
+        loss = wave_reduce_sum(loss);
+        if (lane == 0) smem[wv] = loss;
+        __syncthreads();
+        if (threadIdx.x == 0) *loss_out = smem[0] + smem[1] + smem[2] + smem[3];
+        return;
+    }
+    const int chunk = blockIdx.x, b = blockIdx.y - 1;
+    if (!grad) return;
+    if (threadIdx.x < 64) {
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            double s_pg = 0.0, s_p = 0.0, s_g = 0.0;
+            for (int k = threadIdx.x; k < pchunks; k += 64) {
+                const double* o = partial + ((size_t)(b * C + ch) * pchunks + k) * 3;
                 s_pg += o[0];
                 s_p += o[1];
                 s_g += o[2];
             }
-            double num, den;
-            seg_num_den<KIND>(s_pg, s_p, s_g, num, den);
-            loss += KIND == UOCR_LOSS_DICE ? 1.0 - 2.0 * num / den : 1.0 - num / den;   // losses.py:22,40
+            s_pg = wave_reduce_sum(s_pg);
+            s_p = wave_reduce_sum(s_p);
+            s_g = wave_reduce_sum(s_g);
+            if (threadIdx.x == 0) {
+                double num, den, ca, cb;
+                seg_num_den<KIND>(s_pg, s_p, s_g, num, den);
+                if (KIND == UOCR_LOSS_DICE) {
+                    ca = -2.0 / den;
+                    cb = 2.0 * num / (den * den);
+                } else {
+                    ca = -(den + num) / (den * den);
+                    cb = num / (den * den);
+                }
+                // the gradient is linear in the label with these two coefficients (computed in float64, applied in
+                // float32: the label is 0 / 1 and the result is stored in float32 or binary16 anyway)
+                coef[ch][0] = (float)(ca * gscale);
+                coef[ch][1] = (float)(cb * gscale);
+            }
         }
-        loss = block_reduce_sum(loss, smem);
-        if (threadIdx.x == 0) *loss_out = loss;
-        __syncthreads();
-    }
-    if (!grad) return;
-    if (threadIdx.x < C) {                               // nchunks <= 64: a serial sum in chunk order
-        const int ch = threadIdx.x;
-        double s_pg = 0.0, s_p = 0.0, s_g = 0.0;
-        for (int k = 0; k < nchunks; ++k) {
-            const double* o = partial + ((size_t)(b * C + ch) * nchunks + k) * 3;
-            s_pg += o[0];
-            s_p += o[1];
-            s_g += o[2];
-        }
-        double num, den, ca, cb;
-        seg_num_den<KIND>(s_pg, s_p, s_g, num, den);
-        if (KIND == UOCR_LOSS_DICE) {
-            ca = -2.0 / den;
-            cb = 2.0 * num / (den * den);
-        } else {
-            ca = -(den + num) / (den * den);
-            cb = num / (den * den);
-        }
-        // the gradient is linear in the label with these two coefficients (computed in float64, applied in
-        // float32: the label is 0 / 1 and the result is stored in float32 or binary16 anyway)
-        coef[ch][0] = (float)(ca * gscale);
-        coef[ch][1] = (float)(cb * gscale);
     }
     __syncthreads();
     float ca[C], cb[C];
@@ -308,24 +353,46 @@ __global__ __launch_bounds__(256) void seg_grad_vec_kernel(const T* __restrict__
     const VecOf<T, V>* g4 = reinterpret_cast<const VecOf<T, V>*>(gt + base);
     VecOf<T, V>* o4 = reinterpret_cast<VecOf<T, V>*>(grad + base);
     const bool sig = out_act == UOCR_ACT_SIGMOID;
-    for (size_t q = v0 + threadIdx.x; q < v1; q += blockDim.x) {
-        const VecOf<T, V> gv = g4[q];
-        float r[V];
+    // loads of U trips in flight (see seg_partial_vec_kernel); the Sigmoid case is a loop of its own: a per-load
+    // "register or load" choice on a run-time flag makes hipcc branch around every load and wait for each
+    constexpr int U = 4;
+    auto run = [&](auto sigtag) {
+        constexpr bool SIG = decltype(sigtag)::value;
+        auto one = [&](const VecOf<T, V>& gv, const VecOf<T, V>& pv) {
+            float r[V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) r[k] = ca[k % C] * (float)gv.v[k] + cb[k % C];
-        if (sig) {
-            const VecOf<T, V> pv = p4[q];
+            for (int k = 0; k < V; ++k) r[k] = ca[k % C] * (float)gv.v[k] + cb[k % C];
+            if constexpr (SIG) {
 #pragma unroll
-            for (int k = 0; k < V; ++k) {
-                const float pf = (float)pv.v[k];
-                r[k] *= pf * (1.f - pf);
+                for (int k = 0; k < V; ++k) {
+                    const float pf = (float)pv.v[k];
+                    r[k] *= pf * (1.f - pf);
+                }
             }
-        }
-        VecOf<T, V> out;
+            VecOf<T, V> out;
 #pragma unroll
-        for (int k = 0; k < V; ++k) out.v[k] = grad_store<T>(r[k]);
-        o4[q] = out;
-    }
+            for (int k = 0; k < V; ++k) out.v[k] = grad_store<T>(r[k]);
+            return out;
+        };
+        size_t q = v0 + threadIdx.x;
+        for (; q + (U - 1) * blockDim.x < v1; q += U * blockDim.x) {
+            VecOf<T, V> gv[U], pv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                gv[u] = g4[q + u * blockDim.x];
+                if constexpr (SIG) pv[u] = p4[q + u * blockDim.x];
+                else pv[u] = gv[u];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) o4[q + u * blockDim.x] = one(gv[u], pv[u]);
+        }
+        for (; q < v1; q += blockDim.x) {
+            const VecOf<T, V> gv = g4[q];
+            o4[q] = one(gv, SIG ? p4[q] : gv);
+        }
+    };
+    if (sig) run(std::true_type{});
+    else run(std::false_type{});
 }
 
 // SoftmaxCrossEntropy (losses.py:60-73).  A row of the Char net has 162 classes: one wave per row leaves 2/3 of
@@ -424,25 +491,28 @@ int uocr_seg_loss(uocr_ctx* ctx, int dtype, int kind, const void* pred, const vo
     const auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     const int elem = UOCR_DTYPE_BASE(dtype) == UOCR_F16 ? 2 : UOCR_DTYPE_BASE(dtype) == UOCR_F32 ? 4 : 8;
     const bool vec = elem <= 4 && (c == 1 || c == 2 || c == 4) && ((size_t)hw * c * elem) % 16 == 0 && al16(pred) &&
-                     al16(gt) && (!grad || al16(grad)) && n <= 65535;
+                     al16(gt) && (!grad || al16(grad)) && n < 65535;
     if (vec) {
-        // channel-interleaved 16-byte kernels; the partial layout and the order of the final sums are those of
-        // the generic kernels (only the order of additions inside a chunk differs)
-        const dim3 grid(nchunks, n);
+        // channel-interleaved 16-byte kernels.  The sums kernel keeps the chunking of the generic kernels (<= 64 chunks
+        // of >= 8192 pixels); the gradient kernel streams in chunks of 1024 vectors (256 threads x 4 in flight), at most
+        // 512 per image
+        const size_t nvec = (size_t)hw * c * elem / 16;
+        const int gchunks = (int)std::min<size_t>(512, std::max<size_t>(1, (nvec + 1023) / 1024));
+        // (more than 64 chunks for the sums kernel: 128 / 256 measured the same at 8 x 1024 x 2048, tools/dev/dice_sweep.py)
         auto run = [&](auto tag, auto ctag) {
             using T = decltype(tag);
             constexpr int C = decltype(ctag)::value;
-            hipLaunchKernelGGL((seg_partial_vec_kernel<T, C>), grid, dim3(256), 0, ctx->stream, (const T*)pred,
+            hipLaunchKernelGGL((seg_partial_vec_kernel<T, C>), dim3(nchunks, n), dim3(256), 0, ctx->stream, (const T*)pred,
                                (const T*)gt, partial, hw, nchunks);
-            const dim3 ggrid = grad ? grid : dim3(1, 1);
+            const dim3 ggrid = grad ? dim3(gchunks, n + 1) : dim3(1, 1);       // row 0: the loss
             if (kind == UOCR_LOSS_DICE)
                 hipLaunchKernelGGL((seg_grad_vec_kernel<T, C, UOCR_LOSS_DICE>), ggrid, dim3(256), 0, ctx->stream,
                                    (const T*)pred, (const T*)gt, (const double*)partial, (T*)grad, loss_out, hw, nchunks,
-                                   npairs, out_act, gscale);
+                                   gchunks, npairs, out_act, gscale);
             else
                 hipLaunchKernelGGL((seg_grad_vec_kernel<T, C, UOCR_LOSS_JACCARD>), ggrid, dim3(256), 0, ctx->stream,
                                    (const T*)pred, (const T*)gt, (const double*)partial, (T*)grad, loss_out, hw, nchunks,
-                                   npairs, out_act, gscale);
+                                   gchunks, npairs, out_act, gscale);
         };
         auto by_c = [&](auto tag) {
             if (c == 1) run(tag, std::integral_constant<int, 1>{});
