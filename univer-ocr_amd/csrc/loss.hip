@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void seg_partial_vec_kernel(const T* __restric
     };
     // U vectors of each tensor in flight per thread (2 x 16 bytes per trip left the kernel waiting for HBM: 2 blocks of
     // 256 threads per CU hold 16 KB in flight; the vectors are added in the order of the one-at-a-time loop)
-    constexpr int U = 8;
+    constexpr int U = 4;
     size_t q = v0 + threadIdx.x;
     for (; q + (U - 1) * blockDim.x < v1; q += U * blockDim.x) {
         VecOf<T, V> pv[U], gv[U];
