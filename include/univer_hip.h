@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define UOCR_ABI_VERSION 3
+#define UOCR_ABI_VERSION 4
 
 typedef struct uocr_ctx uocr_ctx;
 
@@ -119,6 +119,16 @@ int uocr_graph_begin_capture(uocr_ctx* ctx);
 int uocr_graph_end_capture(uocr_ctx* ctx, void** out_graph_exec);
 int uocr_graph_launch(uocr_ctx* ctx, void* graph_exec);
 int uocr_graph_destroy(void* graph_exec);
+/* Deferred weight gradients.  The reference computes dW of a layer right where it computes dX (convolutional.py:101-145,
+ * layers.py:341-347); nothing reads dW before the backward pass ends (models.py:226-254).  Between begin and flush the
+ * weight-gradient GEMMs of uocr_conv2d_bwd_weight / uocr_dense_bwd(_act) that are small enough to leave the chip
+ * mostly idle on their own (the Char net's, my_model/model.py:250-304) are only recorded -- the call returns at once --
+ * and flush runs all of them as ONE grid and one reduction; every other call is unaffected.  Operands named in
+ * recorded calls must stay valid and unchanged until the flush.  keep_open != 0: flush what is recorded and keep
+ * recording (a gradient bucket must be complete now).  Same sums as the separate launches up to float32 summation
+ * order (the depth splits are chosen for the group). */
+int uocr_wgrad_defer_begin(uocr_ctx* ctx);
+int uocr_wgrad_defer_flush(uocr_ctx* ctx, int keep_open);
 /* name, CU count, HBM bytes of the ctx's device (train.py:70-90 prints the numba equivalents) */
 int uocr_device_info(uocr_ctx* ctx, char* name_out, size_t name_cap, int* cu_count, size_t* hbm_bytes);
 

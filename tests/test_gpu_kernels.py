@@ -472,6 +472,69 @@ def test_conv_h3_error_compensated_f16_mfma_forward(shape, pad_value, act, f32):
         rt.set_option('pair_band', 0)
 
 
+def test_deferred_weight_gradients_run_as_one_group(f32):
+    """uocr_wgrad_defer_begin / _flush (Runtime.defer_wgrad): the weight gradients of three convolutions (one of them the
+    windows + dense layer of the Char net) and two dense layers are recorded and run as ONE grid + one reduction; dw / db
+    against the oracle and against the separate launches (2e-5: the depth splits differ), accumulating into non-zero
+    buffers; dx of the dense layers is NOT deferred; a flush in the middle (keep_open) and a second group on the same ctx."""
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    rt = CP.runtime()
+    rng = np.random.default_rng(77)
+    convs = [((4, 14, 64, 64), (5, 3), 64, (2, 1), (0, 1)), ((4, 5, 64, 64), (5, 3), 64, (2, 1), (0, 1)),
+             ((3, 9, 20, 32), (3, 3), 48, (1, 1), (1, 1))]
+    dense = [(256, 1024, 128), (256, 128, 162)]
+    jobs = []
+    for xs, ks, cout, st, pd in convs:
+        X = rng.standard_normal(xs)
+        w = rng.standard_normal((*ks, xs[3], cout)) * 0.1
+        y = O.conv2d_fwd(X, w, np.zeros(cout), st, pd, 0.0, True)
+        g = rng.standard_normal(y.shape)
+        _, ref_dw, ref_db = O.conv2d_bwd(X, w, g, st, pd, 0.0, True)
+        jobs.append(('conv', CP.copy(X), CP.copy(g), w.shape, cout, st, pd, ref_dw, ref_db))
+    for m, n_in, n_out in dense:
+        X = rng.standard_normal((m, n_in))
+        w = rng.standard_normal((n_in + 1, n_out)) * 0.1
+        g = rng.standard_normal((m, n_out))
+        ref_dw = np.concatenate([X, np.ones((m, 1))], axis=1).T @ g
+        ref_dx = g @ w[:-1].T
+        jobs.append(('dense', CP.copy(X), CP.copy(g), CP.copy(w), ref_dw, ref_dx))
+
+    def run(deferred, flush_after=None):
+        outs = []
+        scope = rt.defer_wgrad() if deferred else None
+        if scope:
+            scope.__enter__()
+        try:
+            for i, job in enumerate(jobs):
+                if job[0] == 'conv':
+                    _, Xd, gd, wshape, cout, st, pd, _, _ = job
+                    dw, db = CP.full(wshape, 0.5), CP.full((cout,), 0.25)
+                    ops.conv2d_bwd_weight(Xd, gd, dw, db, st, pd, 0.0, True, accumulate=True)
+                    outs.append((dw, db))
+                else:
+                    _, Xd, gd, wd, _, _ = job
+                    dw = CP.full(wd.shape, 0.5)
+                    dx = ops.dense_bwd(Xd, wd, gd, dw, accumulate=True)
+                    outs.append((dw, dx))
+                if deferred and flush_after == i:
+                    rt.flush_deferred()
+        finally:
+            if scope:
+                scope.__exit__(None, None, None)
+        return [(CP.asnumpy(a).astype(np.float64), CP.asnumpy(b).astype(np.float64)) for a, b in outs]
+
+    plain = run(False)
+    for flush_after in (None, 1, None):
+        got = run(True, flush_after)
+        for job, (a, b), (pa, pb) in zip(jobs, got, plain):
+            if job[0] == 'conv':
+                assert rel_linf(a, job[7] + 0.5) <= 2e-5 and rel_linf(b, job[8] + 0.25) <= 2e-5
+            else:
+                assert rel_linf(a, job[4] + 0.5) <= 2e-5 and rel_linf(b, job[5]) <= 1e-5
+            assert rel_linf(a, pa) <= 2e-5 and rel_linf(b, pb) <= 2e-5
+
+
 def test_cross_entropy_single_launch_sums(f32):
     """SoftmaxCrossEntropy / SigmoidCrossEntropy add their per-block partials in the last block to arrive (one launch
     each): value against the oracle over many blocks, repeated calls (counter back at zero), odd row counts."""

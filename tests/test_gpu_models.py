@@ -283,7 +283,8 @@ def test_weight_gradients_on_side_streams_change_nothing(graphs):
     CP.lazy_losses = True
     try:
         for side in ((), ('all',)):
-            trainer = PageTrainer(2, 32, 64, 16, optimizer='adam', lr=0.001, seed=3, graphs=graphs, side_wgrad=side)
+            trainer = PageTrainer(2, 32, 64, 16, optimizer='adam', lr=0.001, seed=3, graphs=graphs, side_wgrad=side,
+                                  group_wgrad=())
             assert all(m.side_wgrad == bool(side) for m in trainer.models.values())
             history = []
             for i in range(6):
@@ -301,6 +302,49 @@ def test_weight_gradients_on_side_streams_change_nothing(graphs):
     assert results[0][0] == results[1][0]
     for name, w in results[0][1].items():
         assert np.array_equal(np.asarray(w), np.asarray(results[1][1][name])), name
+
+
+@pytest.mark.parametrize('graphs', [False, True], ids=['eager', 'graphs'])
+def test_grouped_weight_gradients_train_like_separate_launches(graphs):
+    """PageTrainer(group_wgrad=('Char',)) -- the Char net's five weight-gradient GEMMs as one launch at the end of the
+    backward pass (Runtime.defer_wgrad) -- against separate launches: same losses and weights to float32 summation order
+    (the depth splits differ) over four steps, the other nets bit-identical."""
+    from univer_ocr_amd.my_model.synthetic import make_page_batch
+    from univer_ocr_amd.my_model.trainer import PageTrainer
+    from univer_ocr_amd.nn import CP
+    CP.use_gpu(0)
+    CP.set_dtype('float32')
+    batches = [make_page_batch(4, 32, 64, 64, seed=s) for s in (7, 8)]
+    results = []
+    lazy = CP.lazy_losses
+    CP.lazy_losses = True
+    try:
+        for group in ((), ('Char',)):
+            trainer = PageTrainer(4, 32, 64, 64, optimizer='sgd', lr=0.01, seed=3, graphs=graphs, group_wgrad=group)
+            assert trainer.models['Char'].group_wgrad == bool(group)
+            history = []
+            for i in range(4):
+                losses = trainer.step(trainer.make_context(batches[i % 2]))
+                history.append({n: [float(v) for v in l['output_losses']] + [float(l['regularization_loss'])]
+                                for n, l in losses.items()})
+            results.append((history, {n: m.get_weights() for n, m in trainer.models.items()}))
+    finally:
+        CP.lazy_losses = lazy
+    (h0, w0), (h1, w1) = results
+    for a, b in zip(h0, h1):
+        for name in a:
+            if name == 'Char':
+                assert np.allclose(a[name], b[name], rtol=1e-5, atol=1e-7), (a[name], b[name])
+            else:
+                assert a[name] == b[name]
+    for name in w0:
+        for layer, params in w0[name].items():
+            for key, w in params.items():
+                a, b = np.asarray(w, np.float64), np.asarray(w1[name][layer][key], np.float64)
+                if name == 'Char':
+                    assert np.allclose(a, b, rtol=1e-4, atol=1e-6), (layer, key)
+                else:
+                    assert np.array_equal(a, b), (layer, key)
 
 
 def test_graph_replay_matches_eager_steps():

@@ -37,7 +37,7 @@ def dev(a):
 
 def test_library_loaded_is_in_tree():
     from univer_ocr_amd.hip import get_lib, lib_path
-    assert get_lib().uocr_abi_version() == 3
+    assert get_lib().uocr_abi_version() == 4
     assert lib_path().endswith('univer-ocr_amd/libuniver_hip.so')
 
 

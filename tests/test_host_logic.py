@@ -26,7 +26,7 @@ def test_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/univer_hip.h but not exported'
     assert sorted(hiplib.ABI_SYMBOLS) == declared, 'ctypes prototypes out of sync with the header'
-    assert lib.uocr_abi_version() == 3
+    assert lib.uocr_abi_version() == 4
 
 
 @pytest.mark.parametrize('net_name', ['Monochrome', 'Paragraph', 'Line', 'Char'])

@@ -3,6 +3,7 @@
 // CP.asnumpy = D2H, cupy.zeros = malloc + memset, cuda.synchronize() = stream sync.
 #include <cstdlib>
 
+#include "gemm.h"
 #include "uocr_common.h"
 
 extern "C" {
@@ -21,6 +22,7 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->workspace = nullptr;
     ctx->workspace_bytes = 0;
     ctx->sync = nullptr;
+    ctx->gemm_defer = nullptr;
     ctx->owns_stream = true;
     ctx->opt_mfma = 1;
     ctx->opt_fast = 1;
@@ -34,6 +36,7 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->opt_xcd = 1;
     ctx->opt_pair_band = 0;
     ctx->opt_pair_g = 4;
+    ctx->opt_group_blocks = 0;
     ctx->opt_h3 = 0;
 #ifdef UOCR_EXPERIMENTS
     if (const char* e = getenv("UOCR_H3")) ctx->opt_h3 = atoi(e);            // development override (tools/dev/h3_ab.sh)
@@ -94,6 +97,7 @@ int uocr_ctx_destroy(uocr_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->workspace) hipFree(ctx->workspace);
     if (ctx->sync) hipFree(ctx->sync);
+    uocr_gemm_defer_free(ctx);
     if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return UOCR_OK;
@@ -129,6 +133,7 @@ int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value) {
     }
     else if (!strcmp(key, "pair_band")) ctx->opt_pair_band = value;
     else if (!strcmp(key, "pair_g")) ctx->opt_pair_g = value;
+    else if (!strcmp(key, "group_blocks")) ctx->opt_group_blocks = value;
     else if (!strcmp(key, "h3")) {
 #ifndef UOCR_EXPERIMENTS
         if (value) UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "option h3: this library was built without conv_h3 "

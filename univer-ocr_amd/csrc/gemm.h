@@ -24,3 +24,5 @@ bool uocr_gemm_mfma_eligible(uocr_ctx* ctx, int dtype, const GemmArgs& g);
 int uocr_gemm_mfma(uocr_ctx* ctx, const GemmArgs& g);
 // dispatcher: MFMA path when eligible, else generic
 int uocr_gemm(uocr_ctx* ctx, int dtype, const GemmArgs& g);
+// deferred weight-gradient group of a ctx (gemm_mfma.hip): freed with the ctx
+void uocr_gemm_defer_free(uocr_ctx* ctx);

@@ -416,10 +416,32 @@ struct AConvWgrad {
 // ---------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------
+// LDS of one block: the A tile (double buffered), then the B tile
+template <int BM>
+constexpr int gemm_a_floats() { return 2 * BM * LDA; }
+template <typename BLoader>
+constexpr int gemm_b_floats() { return 2 * (BLoader::DEPTH_CONTIG ? BN * LDA : BD * BN); }
+
+// Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Blocks that share
+// operand rows (the M tiles of one depth slab in dw; neighbouring pixel tiles, which share halo rows, in a
+// conv forward) should share an L2: XCD c takes the c-th contiguous eighth of the logical block ids.
+__device__ __forceinline__ void gemm_block_coords(int lin, int gx, int gy, int gz, int xcd_remap, int& bx, int& by, int& bz) {
+    if (xcd_remap) {
+        const int total = gx * gy * gz;
+        const int c = lin & 7, q = total >> 3, r = total & 7;
+        lin = c * q + min(c, r) + (lin >> 3);
+    }
+    bx = lin % gx;
+    const int rest = lin / gx;
+    by = rest % gy;
+    bz = rest / gy;
+}
+
+// one block's share of C = A . B: output tile (bx, by), depth slice bz; As / Bs: this block's LDS
 template <int BM, typename ALoader, typename BLoader>
-__global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BLoader B, Epilogue ep, int M, int N,
-                                                        int ntiles, int tiles_per_split, float* slabs,
-                                                        int xcd_remap) {
+__device__ __forceinline__ void gemm_tile(const ALoader& A, const BLoader& B, const Epilogue& ep, int M, int N, int ntiles,
+                                          int tiles_per_split, float* slabs, int bx, int by, int bz, float* As,
+                                          float* Bs) {
     constexpr int WM = BM / 32;            // waves along M: 4 or 2
     constexpr int WN = 4 / WM;             // waves along N: 1 or 2
     constexpr int NB = (BN / WN) / 32;     // 32x32 blocks per wave along N: 2 or 1
@@ -428,25 +450,10 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BLoader B, Ep
     constexpr int AM_ROWS = 256 / AM_GROUPS;   // depth rows covered per pass: 8 or 16
     constexpr int AM_PASSES = BD / AM_ROWS;    // 4 or 2
     constexpr int A_REGS = ALoader::DEPTH_CONTIG ? A_PASSES : AM_PASSES;
-
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BLoader::DEPTH_CONTIG ? BN * LDA : BD * BN];
+    constexpr int ASZ = BM * LDA;                                             // floats per buffer
+    constexpr int BSZ = BLoader::DEPTH_CONTIG ? BN * LDA : BD * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2.  Blocks that share
-    // operand rows (the M tiles of one depth slab in dw; neighbouring pixel tiles, which share halo rows, in a
-    // conv forward) should share an L2: XCD c takes the c-th contiguous eighth of the logical block ids.
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (xcd_remap) {
-        const int total = gridDim.x * gridDim.y * gridDim.z;
-        const int lin = bx + gridDim.x * (by + gridDim.y * bz);
-        const int c = lin & 7, q = total >> 3, r = total & 7;
-        const int logical = c * q + min(c, r) + (lin >> 3);
-        bx = logical % gridDim.x;
-        const int rest = logical / gridDim.x;
-        by = rest % gridDim.y;
-        bz = rest / gridDim.y;
-    }
     const int m0 = bx * BM, n0 = by * BN;
     const int t_begin = bz * tiles_per_split;
     const int t_end = min(ntiles, t_begin + tiles_per_split);
@@ -531,7 +538,7 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BLoader B, Ep
         }
     };
     auto store_tile = [&](int buf) {
-        float* as = As[buf];
+        float* as = As + buf * ASZ;
 #pragma unroll
         for (int s = 0; s < A_REGS; ++s) areg[s] = ld_resolve(areg[s], acode[s], A.fill());
 #pragma unroll
@@ -550,10 +557,10 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BLoader B, Ep
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) Bs[buf][(b_r + 32 * s) * LDA + b_kq * 4 + q] = breg[s].v[q];
+                for (int q = 0; q < 4; ++q) Bs[buf * BSZ + (b_r + 32 * s) * LDA + b_kq * 4 + q] = breg[s].v[q];
         } else {
-            *reinterpret_cast<F4*>(&Bs[buf][b_kr * BN + b_nq * 4]) = breg[0];
-            *reinterpret_cast<F4*>(&Bs[buf][(b_kr + 16) * BN + b_nq * 4]) = breg[1];
+            *reinterpret_cast<F4*>(&Bs[buf * BSZ + b_kr * BN + b_nq * 4]) = breg[0];
+            *reinterpret_cast<F4*>(&Bs[buf * BSZ + (b_kr + 16) * BN + b_nq * 4]) = breg[1];
         }
     };
 
@@ -597,12 +604,12 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BLoader B, Ep
             // the MFMAs, section 5a of DESIGN.md)
             // (indices into the __shared__ arrays, not pointers: a pointer through the asm loses its address space and
             // the reads become flat loads)
-            int ia = buf * (BM * LDA) + (ALoader::DEPTH_CONTIG ? fi * LDA + fk : fk * BM + fi);
-            int ib = buf * (BLoader::DEPTH_CONTIG ? BN * LDA : BD * BN) + (BLoader::DEPTH_CONTIG ? fj * LDA + fk : fk * BN + fj);
+            int ia = buf * ASZ + (ALoader::DEPTH_CONTIG ? fi * LDA + fk : fk * BM + fi);
+            int ib = buf * BSZ + (BLoader::DEPTH_CONTIG ? fj * LDA + fk : fk * BN + fj);
             asm volatile("" : "+v"(ia), "+v"(ib));
-            auto frag_a = [&](int k) { return (&As[0][0])[ia + (ALoader::DEPTH_CONTIG ? k : k * BM)]; };
+            auto frag_a = [&](int k) { return As[ia + (ALoader::DEPTH_CONTIG ? k : k * BM)]; };
             auto frag_b = [&](int k, int nb) {
-                return (&Bs[0][0])[ib + (BLoader::DEPTH_CONTIG ? nb * 32 * LDA + k : k * BN + nb * 32)];
+                return Bs[ib + (BLoader::DEPTH_CONTIG ? nb * 32 * LDA + k : k * BN + nb * 32)];
             };
             float a = frag_a(0), b[NB];
 #pragma unroll
@@ -642,6 +649,18 @@ __global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BLoader B, Ep
             }
         }
     }
+}
+
+template <int BM, typename ALoader, typename BLoader>
+__global__ __launch_bounds__(256) void mfma_gemm_kernel(ALoader A, BLoader B, Epilogue ep, int M, int N,
+                                                        int ntiles, int tiles_per_split, float* slabs,
+                                                        int xcd_remap) {
+    __shared__ __attribute__((aligned(16))) float As[gemm_a_floats<BM>()];
+    __shared__ __attribute__((aligned(16))) float Bs[gemm_b_floats<BLoader>()];
+    int bx, by, bz;
+    gemm_block_coords(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), gridDim.x, gridDim.y, gridDim.z,
+                      xcd_remap, bx, by, bz);
+    gemm_tile<BM, ALoader, BLoader>(A, B, ep, M, N, ntiles, tiles_per_split, slabs, bx, by, bz, As, Bs);
 }
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nsplit, int M, int N,
@@ -732,6 +751,175 @@ int launch_mfma(uocr_ctx* ctx, const ALoader& A, const BLoader& B, const Epilogu
     return UOCR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deferred weight-gradient GEMMs: ONE launch for all of them (uocr_wgrad_defer_begin / _flush)
+//
+// The weight gradients of a backward pass do not depend on each other and nothing reads them before the pass ends; the
+// Char net's five (conv_2, conv_3, the windows + dense_1 layer as a conv; dense_2, dense_3) are GEMMs of 15-130 output
+// tiles each, run one after the other: five launches of a few hundred latency-bound blocks + five reduce launches, 125
+// of the net's 440 us.  Between begin and flush the eligible weight-gradient GEMMs are only RECORDED; flush splits
+// their depths so that all of them together fill the chip and runs them as one grid (block -> problem by a prefix
+// table, two loader types) followed by one reduce launch.  Same tiles, same slab order per problem: the sums are those
+// of the separate launches with the same split.
+// ---------------------------------------------------------------------------------------------
+constexpr int GROUP_MAX = 8, GROUP_MAX_TYPE = 4;
+
+struct GroupShape {
+    int M, N, ntiles, tps, gx, gy, gz, first_block;
+    float* slabs;
+    Epilogue ep;
+};
+struct GroupArgs {
+    int count, xcd_remap;
+    int type[GROUP_MAX];            // 0: AConvWgrad, 1: AColMajor
+    int index[GROUP_MAX];           // into conv_a / col_a
+    GroupShape shape[GROUP_MAX];
+    BRowMajor b[GROUP_MAX];
+    AConvWgrad conv_a[GROUP_MAX_TYPE];
+    AColMajor col_a[GROUP_MAX_TYPE];
+};
+
+__global__ __launch_bounds__(256) void mfma_gemm_group_kernel(GroupArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[gemm_a_floats<64>()];
+    __shared__ __attribute__((aligned(16))) float Bs[gemm_b_floats<BRowMajor>()];
+    int p = 0;
+    while (p + 1 < g.count && (int)blockIdx.x >= g.shape[p + 1].first_block) ++p;     // (block-uniform)
+    const GroupShape& sh = g.shape[p];
+    int bx, by, bz;
+    gemm_block_coords((int)blockIdx.x - sh.first_block, sh.gx, sh.gy, sh.gz, g.xcd_remap, bx, by, bz);
+    if (g.type[p] == 0)
+        gemm_tile<64, AConvWgrad, BRowMajor>(g.conv_a[g.index[p]], g.b[p], sh.ep, sh.M, sh.N, sh.ntiles, sh.tps, sh.slabs, bx,
+                                             by, bz, As, Bs);
+    else
+        gemm_tile<64, AColMajor, BRowMajor>(g.col_a[g.index[p]], g.b[p], sh.ep, sh.M, sh.N, sh.ntiles, sh.tps, sh.slabs, bx,
+                                            by, bz, As, Bs);
+}
+
+struct GroupReduceArgs {
+    int count;
+    long first[GROUP_MAX + 1];      // element offsets of the problems that were split
+    const float* slabs[GROUP_MAX];
+    int nsplit[GROUP_MAX], N[GROUP_MAX];
+    Epilogue ep[GROUP_MAX];
+};
+
+__global__ __launch_bounds__(256) void slab_reduce_group_kernel(GroupReduceArgs a) {
+    const long total = a.first[a.count];
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+        int p = 0;
+        while (p + 1 < a.count && g >= a.first[p + 1]) ++p;
+        const long idx = g - a.first[p], size = a.first[p + 1] - a.first[p];
+        const float* slabs = a.slabs[p];
+        const int nsplit = a.nsplit[p];
+        float v = 0.f;                                  // eight slabs' loads in flight, added in slab order (slab_reduce_kernel)
+        int z = 0;
+        for (; z + 8 <= nsplit; z += 8) {
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = slabs[(long)(z + k) * size + idx];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += t[k];
+        }
+        for (; z < nsplit; ++z) v += slabs[(long)z * size + idx];
+        epilogue_store(a.ep[p], (int)(idx / a.N[p]), (int)(idx % a.N[p]), v);
+    }
+}
+
+// what is recorded between begin and flush
+struct GemmDefer {
+    bool on = false;
+    int count = 0, nconv = 0, ncol = 0;
+    GroupArgs args{};
+    int depth[GROUP_MAX]{};
+};
+
+inline GemmDefer* defer_of(uocr_ctx* ctx) { return (GemmDefer*)ctx->gemm_defer; }
+
+// true: recorded (the caller returns UOCR_OK without launching)
+template <typename ALoader>
+bool defer_record(uocr_ctx* ctx, const ALoader& A, const BRowMajor& B, const Epilogue& ep, int M, int N, int depth) {
+    GemmDefer* d = defer_of(ctx);
+    if (!d || !d->on || d->count >= GROUP_MAX) return false;
+    constexpr bool conv = std::is_same<ALoader, AConvWgrad>::value;
+    if ((conv ? d->nconv : d->ncol) >= GROUP_MAX_TYPE) return false;
+    // only the small problems (64-row tiles, few of them) gain from sharing a launch
+    const long tiles = (long)((M + 63) / 64) * ((N + BN - 1) / BN);
+    if (tiles >= 2L * ctx->cu_count || (size_t)M * N * sizeof(float) * 2 > ws_half(ctx)) return false;
+    const int p = d->count++;
+    GroupArgs& g = d->args;
+    g.type[p] = conv ? 0 : 1;
+    if constexpr (conv) {
+        g.index[p] = d->nconv;
+        g.conv_a[d->nconv++] = A;
+    } else {
+        g.index[p] = d->ncol;
+        g.col_a[d->ncol++] = A;
+    }
+    g.b[p] = B;
+    g.shape[p].M = M;
+    g.shape[p].N = N;
+    g.shape[p].ep = ep;
+    d->depth[p] = depth;
+    return true;
+}
+
+int defer_flush(uocr_ctx* ctx) {
+    GemmDefer* d = defer_of(ctx);
+    if (!d || d->count == 0) return UOCR_OK;
+    GroupArgs& g = d->args;
+    g.count = d->count;
+    g.xcd_remap = ctx->opt_xcd;
+    // depth splits: the problems share ~4 resident blocks per CU in proportion to their work (tile-iterations)
+    double work[GROUP_MAX], total_work = 0.0;
+    for (int p = 0; p < g.count; ++p) {
+        GroupShape& sh = g.shape[p];
+        sh.gx = (sh.M + 63) / 64;
+        sh.gy = (sh.N + BN - 1) / BN;
+        sh.ntiles = (d->depth[p] + BD - 1) / BD;
+        work[p] = (double)sh.gx * sh.gy * sh.ntiles;
+        total_work += work[p];
+    }
+    const double target = ctx->opt_split <= 0 ? 0.0 : ctx->opt_group_blocks > 0 ? (double)ctx->opt_group_blocks : 4.0 * ctx->cu_count;
+    size_t slab_floats = 0;
+    int nblocks = 0;
+    GroupReduceArgs r{};
+    for (int p = 0; p < g.count; ++p) {
+        GroupShape& sh = g.shape[p];
+        const int tiles = sh.gx * sh.gy;
+        int nsplit = (int)(target * work[p] / total_work / tiles + 0.5);
+        const int cap = std::max(std::min(32, sh.ntiles / 2), std::min(256, sh.ntiles / 32));
+        nsplit = std::max(1, std::min(nsplit, cap));
+        const size_t per = (size_t)sh.M * sh.N;
+        while (nsplit > 1 && (slab_floats + (size_t)nsplit * per) * sizeof(float) > ws_half(ctx)) --nsplit;
+        if (nsplit < ctx->opt_split_min) nsplit = 1;
+        sh.tps = (sh.ntiles + nsplit - 1) / nsplit;
+        nsplit = (sh.ntiles + sh.tps - 1) / sh.tps;
+        sh.gz = nsplit;
+        sh.first_block = nblocks;
+        nblocks += tiles * nsplit;
+        sh.slabs = nullptr;
+        if (nsplit > 1) {
+            sh.slabs = ws_slabs(ctx) + slab_floats;
+            slab_floats += (size_t)nsplit * per;
+            const int q = r.count++;
+            r.first[q + 1] = r.first[q] + (long)per;
+            r.slabs[q] = sh.slabs;
+            r.nsplit[q] = nsplit;
+            r.N[q] = sh.N;
+            r.ep[q] = sh.ep;
+        }
+    }
+    hipLaunchKernelGGL(mfma_gemm_group_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, g);
+    UOCR_LAUNCH_CHECK(ctx);
+    if (r.count > 0) {
+        hipLaunchKernelGGL(slab_reduce_group_kernel, dim3(uocr_blocks_for((size_t)r.first[r.count], 256, 2048)), dim3(256),
+                           0, ctx->stream, r);
+        UOCR_LAUNCH_CHECK(ctx);
+    }
+    d->count = d->nconv = d->ncol = 0;
+    return UOCR_OK;
+}
+
 inline Epilogue plain_epilogue(float* c, long ldc, int accumulate) {
     return Epilogue{c, ldc, nullptr, UOCR_ACT_NONE, 0.f, accumulate, -1, nullptr, nullptr, UOCR_ACT_NONE, 0.f};
 }
@@ -790,6 +978,8 @@ int uocr_gemm_mfma(uocr_ctx* ctx, const GemmArgs& g) {
     const int stored_rows = g.a_ones_row ? g.m - 1 : g.m;
     AColMajor A{(const float*)g.a, g.a_cs, stored_rows, g.a_ones_row, g.depth,
                 (g.a_cs % 4 == 0 && stored_rows % 4 == 0 && aligned16(g.a)) ? 1 : 0};
+    // [x, 1]^T . dy, a dense layer's weight gradient: recorded when a deferred group is open (and B lies in place)
+    if (g.b_cs == 1 && g.a_ones_row && defer_record(ctx, A, B, ep, g.m, g.n, g.depth)) return UOCR_OK;
     return launch_mfma(ctx, A, B, ep, g.m, g.n, g.depth, true);
 }
 
@@ -847,8 +1037,34 @@ int uocr_conv_wgrad_mfma(uocr_ctx* ctx, const void* x, const void* dy, void* dw,
     BRowMajor B{(const float*)dy, d.cout, P, d.cout, aligned16(dy) ? 1 : 0};
     Epilogue ep{(float*)dw, d.cout, nullptr, UOCR_ACT_NONE, 0.f, accumulate, use_bias ? K : -1, (float*)db,
                 nullptr,    UOCR_ACT_NONE, 0.f};
-    int rc = launch_mfma(ctx, A, B, ep, M, d.cout, P, true);
-    if (rc) return rc;
+    if (!defer_record(ctx, A, B, ep, M, d.cout, P)) {
+        int rc = launch_mfma(ctx, A, B, ep, M, d.cout, P, true);
+        if (rc) return rc;
+    }
     if (!use_bias && !accumulate) UOCR_HIP(ctx, hipMemsetAsync(db, 0, (size_t)d.cout * sizeof(float), ctx->stream));
     return UOCR_OK;
+}
+
+void uocr_gemm_defer_free(uocr_ctx* ctx) {
+    delete (GemmDefer*)ctx->gemm_defer;
+    ctx->gemm_defer = nullptr;
+}
+
+extern "C" int uocr_wgrad_defer_begin(uocr_ctx* ctx) {
+    UOCR_CHECK_CTX(ctx);
+    if (!ctx->gemm_defer) ctx->gemm_defer = new GemmDefer();
+    GemmDefer* d = (GemmDefer*)ctx->gemm_defer;
+    if (d->on) UOCR_FAIL(ctx, UOCR_ERR_ARG, "uocr_wgrad_defer_begin: a deferred group is already open");
+    d->on = true;
+    d->count = d->nconv = d->ncol = 0;
+    return UOCR_OK;
+}
+
+extern "C" int uocr_wgrad_defer_flush(uocr_ctx* ctx, int keep_open) {
+    UOCR_CHECK_CTX(ctx);
+    GemmDefer* d = (GemmDefer*)ctx->gemm_defer;
+    if (!d || !d->on) UOCR_FAIL(ctx, UOCR_ERR_ARG, "uocr_wgrad_defer_flush: no deferred group is open");
+    const int rc = defer_flush(ctx);
+    d->on = keep_open != 0 && rc == UOCR_OK;
+    return rc;
 }

@@ -13,6 +13,7 @@ struct uocr_ctx {
     bool owns_stream;
     void* workspace;
     size_t workspace_bytes;
+    void* gemm_defer;    // recorded weight-gradient GEMMs of an open deferred group (gemm_mfma.hip), or null
     unsigned* sync;      // UOCR_SYNC_WORDS arrival counters of the single-launch reductions (loss.hip): zero between launches
     int cu_count;
     int opt_mfma;        // 0 = never, 1 = auto (default), 2 = whenever eligible (tests)
@@ -27,6 +28,7 @@ struct uocr_ctx {
     int opt_pair_band;   // rows per band of the strip kernels (0 = about one block per CU)
     int opt_pair_pf;     // row prefetch of the pair forward kernels (-1 auto / 0 / 1 / 2, see conv_pair_strip.hip)
     int opt_h3;          // 1 = the float32 Line output conv forward on error-compensated binary16 MFMAs (conv_h3.hip; experiment)
+    int opt_group_blocks; // blocks of a deferred weight-gradient group (0 = four per CU)
     int opt_pair_g;      // groups of 16 columns per wave of the strip kernels: 4 (8 waves per block) or 2 (16 waves)
     char err[512];
 };

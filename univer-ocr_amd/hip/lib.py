@@ -68,6 +68,8 @@ _PROTOS = {
     'uocr_graph_end_capture': [_ctx, C.POINTER(_vp)],
     'uocr_graph_launch': [_ctx, _vp],
     'uocr_graph_destroy': [_vp],
+    'uocr_wgrad_defer_begin': [_ctx],
+    'uocr_wgrad_defer_flush': [_ctx, _i],
     'uocr_device_info': [_ctx, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_sz)],
     'uocr_conv2d_fwd': [_ctx, _i, _vp, _vp, _vp, _vp] + [_i] * 13 + [_d, _i, _i, _d],
     'uocr_conv2d_bwd_data': [_ctx, _i, _vp, _vp, _vp] + [_i] * 13 + [_vp, _i, _d],

@@ -43,7 +43,8 @@ class PageTrainer:
                  dp_coalesce=False, dp_backend=None,
                  init='kaiming_normal', fuse=True, lanes=True, input_grads=True, graphs=False, eager_nets=(), pipelined=False,
                  snapshot_losses=True,
-                 lane_groups=(('Monochrome', 'Paragraph'), ('Line',), ('Char',)), lane_xcds=None, side_wgrad=None):
+                 lane_groups=(('Monochrome', 'Paragraph'), ('Line',), ('Char',)), lane_xcds=None, side_wgrad=None,
+                 group_wgrad=None):
         np.random.seed(seed)                        # kaiming_uniform draws from the NumPy global RNG
         self.batch = batch
         self.optimizer = make_optimizer(optimizer, lr)
@@ -67,6 +68,12 @@ class PageTrainer:
             side_wgrad = tuple(n for n in os.environ.get('UOCR_SIDE_WGRAD', '').split(',') if n)
         for name, model in self.models.items():
             model.side_wgrad = CP.has_device() and (name in side_wgrad or 'all' in side_wgrad)
+        # group_wgrad: nets whose small weight-gradient GEMMs run as ONE launch at the end of the backward pass
+        # (Runtime.defer_wgrad / uocr_wgrad_defer_*): the Char net's five
+        if group_wgrad is None:
+            group_wgrad = tuple(n for n in os.environ.get('UOCR_GROUP_WGRAD', 'Char').split(',') if n)
+        for name, model in self.models.items():
+            model.group_wgrad = CP.has_device() and (name in group_wgrad or 'all' in group_wgrad)
         # one stream (lane) per net: the nets are independent until the optimizer step
         self.lanes = None
         if lanes and CP.has_device() and len(self.models) > 1:
@@ -286,6 +293,7 @@ class PageTrainer:
 
                     def cut(_model, node, cap=cap, parts=parts, split=split):
                         if node == split:
+                            rt.flush_deferred()           # (recorded weight gradients of the tail: into THIS graph)
                             cap[0].__exit__(None, None, None)
                             parts.append(cap[0].graph)
                             cap[0] = rt.capture(pool)

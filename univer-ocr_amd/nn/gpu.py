@@ -60,6 +60,7 @@ class Runtime:
         self.call('uocr_ctx_set_stream', C.c_void_p(self.stream.cuda_stream))
         self._lanes = [(self.ctx, self.stream)]      # lane 0 = the main stream
         self._sides = {}                             # lane ctx -> its side stream (weight gradients), made on demand
+        self._deferred = {}                          # lane ctx -> arrays held for its open deferred weight-gradient group
         self.side_on = False                         # Model.backward turns it on for models with side_wgrad
 
     # -- lanes: extra (context, stream) pairs so independent models run concurrently ---------------
@@ -128,6 +129,26 @@ class Runtime:
             self.ctx = current
         self._options = getattr(self, '_options', {})
         self._options[key] = int(value)              # (replayed on contexts made later: side streams)
+
+    # -- deferred weight gradients (uocr_wgrad_defer_begin / _flush): one launch for the small GEMMs of a backward pass --
+    def defer_wgrad(self):
+        """`with rt.defer_wgrad():` -- the weight-gradient GEMMs issued inside on the current lane that are too small
+        to fill the chip are recorded by the library and run as ONE grid (+ one reduction) at the end of the block, or
+        earlier at `flush_deferred()`.  The arrays they read are held until then (`keep`)."""
+        return _DeferScope(self)
+
+    def keep(self, *arrays):
+        """Hold `arrays` until the deferred weight gradients of the current lane have been flushed (no-op otherwise)."""
+        held = self._deferred.get(self.ctx.value)
+        if held is not None:
+            held.extend(arrays)
+
+    def flush_deferred(self):
+        """Run what has been recorded on the current lane now and keep recording (a gradient bucket is due)."""
+        held = self._deferred.get(self.ctx.value)
+        if held is not None:
+            self.call('uocr_wgrad_defer_flush', 1)
+            held.clear()
 
     # -- side stream of a lane: kernels nobody waits for until the end of the backward pass (weight gradients) --------
     def side(self, *keep):
@@ -274,6 +295,29 @@ class LossArena:
         out = CP.empty((self.used,), np.float64)
         CP.runtime().call('uocr_d2d', out.ptr, self.array.ptr, 8 * self.used)
         return out
+
+
+class _DeferScope:
+    def __init__(self, rt):
+        self.rt = rt
+
+    def __enter__(self):
+        self.key = self.rt.ctx.value
+        if self.key in self.rt._deferred:
+            raise HipError('defer_wgrad: a deferred group is already open on this lane')
+        self.rt.call('uocr_wgrad_defer_begin')
+        self.rt._deferred[self.key] = []
+
+    def __exit__(self, exc_type, exc, tb):
+        held = self.rt._deferred.pop(self.key)
+        try:
+            self.rt.call('uocr_wgrad_defer_flush', 0)
+        except HipError:
+            if exc_type is None:
+                raise
+        finally:
+            held.clear()
+        return False
 
 
 class _Side:

@@ -113,6 +113,7 @@ class Model(BaseModel):
         self._pending_losses = None
         self.bucket_hook = None
         self.side_wgrad = False          # weight-gradient kernels on the lane's side stream (Runtime.side)
+        self.group_wgrad = False         # small weight-gradient GEMMs of a backward pass as one launch (Runtime.defer_wgrad)
         self._receptive_fields = {}
         self.layers, self.relations = None, None
         self.unravel_model()
@@ -258,6 +259,9 @@ class Model(BaseModel):
 
     @track_method('backward')
     def backward(self, grads):
+        if self.group_wgrad and CP.has_device():
+            with CP.runtime().defer_wgrad():
+                return self._backward_pass(grads)
         rt = CP.runtime() if self.side_wgrad and CP.has_device() else None
         if rt is None:
             return self._backward_pass(grads)

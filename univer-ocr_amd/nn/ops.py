@@ -107,6 +107,7 @@ def conv2d_bwd_weight(x, dy, dw, db, stride, padding, pad_value=0.0, bias=True, 
     with _rt().side(x, dy):               # nothing on the lane reads dw before the end of the backward pass
         _rt().call('uocr_conv2d_bwd_weight', code, x.ptr, dy.ptr, dw.ptr, db.ptr, *dims, float(pad_value),
                    int(bool(bias)), int(bool(accumulate)))
+    _rt().keep(x, dy)                     # (read at the flush if the call was deferred: Runtime.defer_wgrad)
 
 
 def conv_pair_fwd(x, w1, b1, w2, b2, pad_value1=0.0, bias1=True, bias2=True, alpha=0.01, act2=hiplib.ACT_NONE):
@@ -259,6 +260,7 @@ def dense_bwd(x, w, dy, dw, accumulate=True, need_dx=True, x_act=None, x_alpha=0
         return dx
     rt.call('uocr_dense_bwd_act', code, x.ptr, w.ptr, dy.ptr, dx.ptr if need_dx else None, dw.ptr, m, n_in,
             n_out, int(bool(accumulate)), ACT_CODES[x_act], float(x_alpha))
+    rt.keep(x, dy)
     return dx
 
 
@@ -298,6 +300,7 @@ def windows_dense_bwd(x, w, dy, dw, width, accumulate=True, x_act=None, act=None
     with _rt().side(x, dy):
         _rt().call('uocr_conv2d_bwd_weight', code, x.ptr, dy.ptr, dw.ptr, dw.ptr + bias_off, *dims, 0.0, 1,
                    int(bool(accumulate)))
+    _rt().keep(x, dy)
     dx = _like_grad(CP.empty(x.shape, dy.dtype), dy)
     _rt().call('uocr_conv2d_bwd_data', code, dy.ptr, w.ptr, dx.ptr, *dims, None if x_act is None else x_act.ptr,
                ACT_CODES[act if x_act is not None else None], float(alpha))

@@ -300,6 +300,9 @@ class DataParallel:
         found = self._split.get(id(model))
         if found is None or node != found[0]:
             return
+        if getattr(model, 'group_wgrad', False):
+            from .nn.gpu import CP
+            CP.runtime().flush_deferred()             # the tail's weight gradients are still only recorded
         if getattr(model, 'side_wgrad', False):
             from .nn.gpu import CP
             CP.runtime().join_side()                  # weight gradients of the tail still on the lane's side stream
