@@ -58,6 +58,7 @@ __host__ __device__ __forceinline__ void tap_group(int phase, int mi, int& lo, i
     }
 }
 
+constexpr int UP_NOUT = 404;      // a block's partial row of the 4-channel weight gradient: dw (5 x 5 x 4 x 4), db (4)
 // weff[(m*4 + c)*16 + phase*4 + o], m = my*3 + mx, phase = py*2 + px
 __global__ __launch_bounds__(256) void upconv_weff_kernel(const float* __restrict__ w, float* __restrict__ weff) {
     for (int i = threadIdx.x; i < NWEFF; i += blockDim.x) {
@@ -203,18 +204,62 @@ __global__ __launch_bounds__(256) void upconv_wgrad_kernel(const TA* __restrict_
         for (int v = 0; v < 4; ++v) red[wv][16 * j + 4 * kq + v][n] = acc[j][v];
     reddb[wv][lane] = dbacc;
     __syncthreads();
+    // The block's partial row: the 400 entries of dw (each the sum of its four phase entries of dWeff) and db -- the
+    // phase sums are taken HERE, so that the finish kernel is a plain, coalesced column sum of a 404-column matrix
+    // (it used to gather four scattered entries of a 580-column row per output and block: 10-13 us inside the step)
     const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    float* out = partial + (size_t)blk * (36 * 16 + 4);
-    for (int i = tid; i < 36 * 16; i += 256) {
-        const int K = i >> 4, col = i & 15;
-        out[i] = red[0][K][col] + red[1][K][col] + red[2][K][col] + red[3][K][col];
+    float* out = partial + (size_t)blk * UP_NOUT;
+    for (int e = tid; e < 400; e += 256) {
+        const int o = e & 3, c = (e >> 2) & 3, kk = e >> 4, ky = kk / 5, kx = kk % 5;
+        float s = 0.f;
+#pragma unroll
+        for (int phase = 0; phase < 4; ++phase) {
+            // source offset index of tap k for output parity p (tap_group in closed form): (k + p) >> 1
+            const int my = (ky + (phase >> 1)) >> 1, mx = (kx + (phase & 1)) >> 1;
+            const int K = (my * 3 + mx) * CH + c, col = phase * 4 + o;
+            s += red[0][K][col] + red[1][K][col] + red[2][K][col] + red[3][K][col];
+        }
+        out[e] = s;
     }
     if (tid < 4) {                                       // db[o]: lanes with (n & 3) == o
         float s = 0.f;
         for (int w = 0; w < 4; ++w)
             for (int l = tid; l < 64; l += 4) s += reddb[w][l];
-        out[36 * 16 + tid] = s;
+        out[400 + tid] = s;
     }
+}
+
+// out[a] (+)= unscale * (float64 column sum a of the block partials [nblocks][ncols]), a < ndw -> dw, else db.  Block = 8
+// columns x 32 segments of the rows (pair_strip_finish's shape: 256 threads are schedulable inside the page step, eight
+// loads in flight per thread, 32-byte coalesced segments), segments added in order.
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, int nblocks, int ncols,
+                                                            int ndw, float* __restrict__ dw, float* __restrict__ db,
+                                                            int use_bias, int accumulate, float unscale) {
+    constexpr int FC = 8, NSEG = 32;
+    __shared__ double seg[NSEG][FC];
+    const int o = threadIdx.x % FC, sg = threadIdx.x / FC, j = blockIdx.x * FC + o;
+    double s = 0.0;
+    if (j < ncols) {
+        const int per = (nblocks + NSEG - 1) / NSEG, b0 = sg * per, b1 = min(nblocks, b0 + per);
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = partial[(size_t)(b + k) * ncols + j];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += (double)v[k];
+        }
+        for (; b < b1; ++b) s += (double)partial[(size_t)b * ncols + j];
+    }
+    seg[sg][o] = s;
+    __syncthreads();
+    if (sg != 0 || j >= ncols) return;
+#pragma unroll
+    for (int k = 1; k < NSEG; ++k) s += seg[k][o];
+    float* dst = j < ndw ? dw + j : db + (j - ndw);
+    if (j >= ndw && !use_bias) s = 0.0;
+    s *= (double)unscale;                                // UOCR_F16_SCALED(k): 2^-k, else 1
+    *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
 
 // block i < 400: dw[ky][kx][c][o] (+)= sum over blocks and phases of dWeff[(m(py,ky), m(px,kx)), c, (phase,o)];
@@ -615,7 +660,7 @@ extern "C" int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_
     const int bands = (hl + rows - 1) / rows, nblocks = strips * bands * n;
     rc = uocr_need_workspace(ctx, (size_t)nblocks * (36 * 16 + 4) * sizeof(float));
     if (rc != UOCR_OK) return rc;
-    float* partial = (float*)ctx->workspace;
+    float* partial = (float*)ctx->workspace;                  // rows of 37 (1 channel) / UP_NOUT (4 channels) floats
     UOCR_DISPATCH_TA(ctx, dtype, {
         if (cin == 1)
             hipLaunchKernelGGL((up1_wgrad_kernel<TA>), dim3(strips, bands, n), dim3(256), 0, ctx->stream,
@@ -629,8 +674,8 @@ extern "C" int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_
         hipLaunchKernelGGL(up1_wgrad_finish, dim3(26), dim3(256), 0, ctx->stream, (const float*)partial, (float*)dw,
                            (float*)db, nblocks, use_bias, accumulate, unscale);
     else
-        hipLaunchKernelGGL(upconv_wgrad_finish, dim3(404), dim3(256), 0, ctx->stream, (const float*)partial, (float*)dw,
-                           (float*)db, nblocks, use_bias, accumulate, unscale);
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3((UP_NOUT + 7) / 8), dim3(256), 0, ctx->stream, (const float*)partial,
+                           nblocks, UP_NOUT, 400, (float*)dw, (float*)db, use_bias, accumulate, unscale);
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
 }
