@@ -535,6 +535,72 @@ def test_deferred_weight_gradients_run_as_one_group(f32):
             assert rel_linf(a, pa) <= 2e-5 and rel_linf(b, pb) <= 2e-5
 
 
+def test_deferred_finish_kernels_run_as_one_launch(f32):
+    """Runtime.defer_wgrad: the finish kernels of the direct weight-gradient producers (the 5x5 convs of the Paragraph /
+    Line nets in their four layouts, upsample + conv, the Monochrome pair block) are recorded and run as ONE launch at the
+    flush, their block partials kept in a region of their own meanwhile; dw / db equal those of the separate finish kernels
+    (float64 column sums in a different order: 1e-6) and the oracle's (2e-5), accumulating into non-zero buffers."""
+    from univer_ocr_amd.nn import ops
+    CP = f32
+    rt = CP.runtime()
+    rng = np.random.default_rng(99)
+    convs = [((2, 40, 72, 1), 1, (2, 2)), ((2, 40, 72, 4), 2, (1, 1)), ((2, 40, 72, 1), 4, (2, 2)), ((2, 40, 72, 4), 4, (2, 2))]
+    jobs = []
+    for xs, cout, st in convs:
+        X = rng.standard_normal(xs)
+        w = rng.standard_normal((5, 5, xs[3], cout)) * 0.2
+        y = O.conv2d_fwd(X, w, np.zeros(cout), st, 2, 0.0, True)
+        g = rng.standard_normal(y.shape)
+        _, ref_dw, ref_db = O.conv2d_bwd(X, w, g, st, 2, 0.0, True)
+        jobs.append(('conv', CP.copy(X), CP.copy(g), w.shape, cout, st, ref_dw, ref_db))
+    xl = rng.standard_normal((2, 20, 36, 4))
+    wu = rng.standard_normal((5, 5, 4, 4)) * 0.2
+    gu = rng.standard_normal((2, 40, 72, 4))
+    _, ref_dwu, ref_dbu = O.conv2d_bwd(O.upsample2d_fwd(xl, (2, 2)), wu, gu, 1, 2, 0.0, True)
+    jobs.append(('up', CP.copy(xl), CP.copy(gu), wu.shape, ref_dwu, ref_dbu))
+    Xp = rng.standard_normal((2, 24, 64, 1))
+    w1, b1 = rng.standard_normal((3, 3, 1, 16)) * 0.4, rng.standard_normal(16) * 0.3
+    w2, b2 = rng.standard_normal((3, 3, 16, 1)) * 0.2, rng.standard_normal(1)
+    gp = rng.standard_normal((2, 24, 64, 1))
+    pd = [CP.copy(a) for a in (Xp, w1, b1, w2, b2, gp)]
+    yp = ops.conv_pair_fwd(pd[0], pd[1], pd[2], pd[3], pd[4], alpha=0.01)
+
+    def run(deferred):
+        outs = []
+        scope = rt.defer_wgrad() if deferred else None
+        if scope:
+            scope.__enter__()
+        try:
+            for job in jobs:
+                if job[0] == 'conv':
+                    _, Xd, gd, wshape, cout, st, _, _ = job
+                    dw, db = CP.full(wshape, 0.5), CP.full((cout,), 0.25)
+                    ops.conv2d_bwd_weight(Xd, gd, dw, db, st, (2, 2), 0.0, True, accumulate=True)
+                else:
+                    _, xd, gd, wshape, _, _ = job
+                    dw, db = CP.full(wshape, 0.5), CP.full((4,), 0.25)
+                    ops.upconv2x_bwd_weight(xd, gd, dw, db, (2, 2), True, accumulate=True)
+                outs += [dw, db]
+            grads = [CP.full(a.shape, 0.5) for a in (w1, b1, w2, b2)]
+            ops.conv_pair_bwd(pd[0], yp, pd[5], pd[1], pd[2], pd[3], *grads, alpha=0.01, need_dx=False, accumulate=True)
+            outs += grads
+        finally:
+            if scope:
+                scope.__exit__(None, None, None)
+        return [CP.asnumpy(a).astype(np.float64) for a in outs]
+
+    plain = run(False)
+    for _ in range(2):
+        got = run(True)
+        for a, b in zip(got, plain):
+            assert rel_linf(a, b) <= 1e-6
+        k = 0
+        for job in jobs:
+            ref_dw, ref_db = job[-2], job[-1]
+            assert rel_linf(got[k], ref_dw + 0.5) <= 2e-5 and rel_linf(got[k + 1], ref_db + 0.25) <= 2e-5
+            k += 2
+
+
 def test_cross_entropy_single_launch_sums(f32):
     """SoftmaxCrossEntropy / SigmoidCrossEntropy add their per-block partials in the last block to arrive (one launch
     each): value against the oracle over many blocks, repeated calls (counter back at zero), odd row counts."""

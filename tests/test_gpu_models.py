@@ -305,10 +305,11 @@ def test_weight_gradients_on_side_streams_change_nothing(graphs):
 
 
 @pytest.mark.parametrize('graphs', [False, True], ids=['eager', 'graphs'])
-def test_grouped_weight_gradients_train_like_separate_launches(graphs):
-    """PageTrainer(group_wgrad=('Char',)) -- the Char net's five weight-gradient GEMMs as one launch at the end of the
-    backward pass (Runtime.defer_wgrad) -- against separate launches: same losses and weights to float32 summation order
-    (the depth splits differ) over four steps, the other nets bit-identical."""
+@pytest.mark.parametrize('grouped', [('Char',), ('all',)], ids=['char', 'all'])
+def test_grouped_weight_gradients_train_like_separate_launches(graphs, grouped):
+    """PageTrainer(group_wgrad=...): the backward pass inside Runtime.defer_wgrad -- the Char net's five weight-gradient
+    GEMMs as one launch, and with 'all' every net's finish kernels as one launch per net -- against separate launches:
+    same losses and weights to float32 / float64 summation order over four steps; ungrouped nets bit-identical."""
     from univer_ocr_amd.my_model.synthetic import make_page_batch
     from univer_ocr_amd.my_model.trainer import PageTrainer
     from univer_ocr_amd.nn import CP
@@ -319,7 +320,7 @@ def test_grouped_weight_gradients_train_like_separate_launches(graphs):
     lazy = CP.lazy_losses
     CP.lazy_losses = True
     try:
-        for group in ((), ('Char',)):
+        for group in ((), grouped):
             trainer = PageTrainer(4, 32, 64, 64, optimizer='sgd', lr=0.01, seed=3, graphs=graphs, group_wgrad=group)
             assert trainer.models['Char'].group_wgrad == bool(group)
             history = []
@@ -333,7 +334,7 @@ def test_grouped_weight_gradients_train_like_separate_launches(graphs):
     (h0, w0), (h1, w1) = results
     for a, b in zip(h0, h1):
         for name in a:
-            if name == 'Char':
+            if name == 'Char' or 'all' in grouped:
                 assert np.allclose(a[name], b[name], rtol=1e-5, atol=1e-7), (a[name], b[name])
             else:
                 assert a[name] == b[name]
@@ -341,7 +342,7 @@ def test_grouped_weight_gradients_train_like_separate_launches(graphs):
         for layer, params in w0[name].items():
             for key, w in params.items():
                 a, b = np.asarray(w, np.float64), np.asarray(w1[name][layer][key], np.float64)
-                if name == 'Char':
+                if name == 'Char' or 'all' in grouped:
                     assert np.allclose(a, b, rtol=1e-4, atol=1e-6), (layer, key)
                 else:
                     assert np.array_equal(a, b), (layer, key)

@@ -11,6 +11,7 @@
 //     butterfly across the 64 lanes (NP shuffles instead of 6*NP for a plain all-reduce), LDS
 //     across the 4 waves, one float32 partial per block; a second kernel sums the block partials
 //     in float64 in a fixed order (deterministic, no atomics).
+#include "finish_group.h"
 #include "conv_dims.h"
 
 namespace {
@@ -1161,14 +1162,25 @@ int launch_wgrad_s2(uocr_ctx* ctx, int dtype, const void* x, const void* dy, voi
     while (per_block < tiles_y && (size_t)tiles_x * ((tiles_y + per_block - 1) / per_block) * d.n > 1024) ++per_block;
     const dim3 grid(tiles_x, (tiles_y + per_block - 1) / per_block, d.n);
     const int nblocks = (int)(grid.x * grid.y * grid.z);
-    int rc = uocr_need_workspace(ctx, (size_t)nblocks * 5 * C::NP * sizeof(float));
+    int rc = UOCR_OK;
+    float* partial = uocr_partial_buffer(ctx, (size_t)nblocks * 5 * C::NP * sizeof(float), &rc);
     if (rc) return rc;
-    float* partial = (float*)ctx->workspace;
     UOCR_DISPATCH_TA(ctx, dtype, {
         hipLaunchKernelGGL((conv_wgrad_s2_tiled<CIN, COUT, TA>), grid, dim3(320), 0, ctx->stream, (const TA*)x,
                            (const TA*)dy, partial, d.h, d.w, d.oh, d.ow, (float)pad_value, per_block);
     });
     UOCR_LAUNCH_CHECK(ctx);
+    FinishDesc fd{};                                     // recorded when a deferred group is open (finish_group.h)
+    fd.kind = FIN_TAPROWS;
+    fd.partial = partial;
+    fd.nblocks = nblocks;
+    fd.ncols = fd.group_cols = 5 * C::NP;
+    fd.row_stride = (size_t)5 * C::NP;
+    fd.dw = (float*)dw, fd.db = (float*)db;
+    fd.use_bias = use_bias, fd.accumulate = accumulate;
+    fd.unscale = (float)uocr_grad_unscale(dtype);
+    fd.p[0] = C::NP, fd.p[1] = C::NW, fd.p[2] = COUT;
+    if (uocr_finish_defer(ctx, fd)) return UOCR_OK;
     hipLaunchKernelGGL((conv_wgrad_s2_finish<CIN, COUT>), dim3(5 * C::NW + COUT), dim3(256), 0, ctx->stream,
                        (const float*)partial, (float*)dw, (float*)db, nblocks, use_bias, accumulate,
                        (float)uocr_grad_unscale(dtype));
@@ -1237,15 +1249,28 @@ struct FastConv {
         const int nbands = (d.oh + rows - 1) / rows;
         const int nblocks = nbands * d.n, ngroups = C::KYG * C::OCG;
         const size_t bytes = (size_t)nblocks * ngroups * C::NP * sizeof(float);
-        int rc = uocr_need_workspace(ctx, bytes);
+        int rc = UOCR_OK;
+        float* partial = uocr_partial_buffer(ctx, bytes, &rc);
         if (rc) return rc;
-        float* partial = (float*)ctx->workspace;
         UOCR_DISPATCH_TA(ctx, dtype, {
             hipLaunchKernelGGL((conv_wgrad_fast<KH, KW, CIN, COUT, SH, SW, KYR, WCOB, WPY, (CIN >= 4), TA>),
                                dim3(nblocks, ngroups), dim3(64, 4), 0, ctx->stream, (const TA*)x, (const TA*)dy,
                                partial, dims(d), (float)pad, rows, nbands);
         });
         UOCR_LAUNCH_CHECK(ctx);
+        FinishDesc fd{};                                 // recorded when a deferred group is open (finish_group.h)
+        fd.kind = FIN_FAST;
+        fd.partial = partial;
+        fd.nblocks = nblocks;
+        fd.ncols = ngroups * C::NP;
+        fd.group_cols = C::NP;
+        fd.group_stride = (size_t)nblocks * C::NP;
+        fd.row_stride = C::NP;
+        fd.dw = (float*)dw, fd.db = (float*)db;
+        fd.use_bias = use_bias, fd.accumulate = accumulate;
+        fd.unscale = (float)uocr_grad_unscale(dtype);
+        fd.p[0] = C::NP, fd.p[1] = C::NW, fd.p[2] = KW, fd.p[3] = CIN, fd.p[4] = COUT, fd.p[5] = KYR, fd.p[6] = WCOB;
+        if (uocr_finish_defer(ctx, fd)) return UOCR_OK;
         hipLaunchKernelGGL((conv_wgrad_fast_finish<KH, KW, CIN, COUT, KYR, WCOB, C::NW, C::NP>),
                            dim3(C::NACC, ngroups), dim3(256), 0, ctx->stream, (const float*)partial, (float*)dw,
                            (float*)db, nblocks, use_bias, accumulate, (float)uocr_grad_unscale(dtype));
@@ -1407,14 +1432,25 @@ int uocr_conv_wgrad_fast(uocr_ctx* ctx, int dtype, const void* x, const void* dy
         while (per_block < tiles_y && (size_t)tiles_x * ((tiles_y + per_block - 1) / per_block) * d.n > 1024) ++per_block;
         const dim3 grid(tiles_x, (tiles_y + per_block - 1) / per_block, d.n);
         const int nblocks = (int)(grid.x * grid.y * grid.z);
-        int rc = uocr_need_workspace(ctx, (size_t)nblocks * 5 * t542::NACC * sizeof(float));
+        int rc = UOCR_OK;
+        float* partial = uocr_partial_buffer(ctx, (size_t)nblocks * 5 * t542::NACC * sizeof(float), &rc);
         if (rc) return rc;
-        float* partial = (float*)ctx->workspace;
         UOCR_DISPATCH_TA(ctx, dtype, {
             hipLaunchKernelGGL((conv_wgrad_t542<TA>), grid, dim3(320), 0, ctx->stream, (const TA*)x, (const TA*)dy,
                                partial, d.h, d.w, (float)pad_value, per_block);
         });
         UOCR_LAUNCH_CHECK(ctx);
+        FinishDesc fd{};                                 // recorded when a deferred group is open (finish_group.h)
+        fd.kind = FIN_TAPROWS;
+        fd.partial = partial;
+        fd.nblocks = nblocks;
+        fd.ncols = fd.group_cols = 5 * t542::NACC;
+        fd.row_stride = (size_t)5 * t542::NACC;
+        fd.dw = (float*)dw, fd.db = (float*)db;
+        fd.use_bias = use_bias, fd.accumulate = accumulate;
+        fd.unscale = (float)uocr_grad_unscale(dtype);
+        fd.p[0] = t542::NACC, fd.p[1] = 40, fd.p[2] = 2;
+        if (uocr_finish_defer(ctx, fd)) return UOCR_OK;
         hipLaunchKernelGGL(conv_wgrad_t542_finish, dim3(202), dim3(256), 0, ctx->stream, (const float*)partial,
                            (float*)dw, (float*)db, nblocks, use_bias, accumulate, (float)uocr_grad_unscale(dtype));
         UOCR_LAUNCH_CHECK(ctx);

@@ -28,6 +28,7 @@
 
 #include "conv_pair.h"
 #include "conv_pair_strip.h"
+#include "finish_group.h"
 #include "uocr_common.h"
 
 namespace {
@@ -633,9 +634,9 @@ int strip_bwd_launch(uocr_ctx* ctx, const float* x, const float* y, const float*
     bands = (h + band_h - 1) / band_h;
     const size_t nblocks = (size_t)nbx * bands * n;
     UOCR_REQUIRE(ctx, bands <= 65535 && n <= 65535);
-    int rc = uocr_need_workspace(ctx, nblocks * PAIR_NPART * sizeof(float));
+    int rc = UOCR_OK;
+    float* partial = uocr_partial_buffer(ctx, nblocks * PAIR_NPART * sizeof(float), &rc);
     if (rc != UOCR_OK) return rc;
-    float* partial = (float*)ctx->workspace;
     const size_t lds = strip_lds_bytes<G>(nw, dx != nullptr);
     auto launch = [&](auto kernel) -> int {
         static bool attr_set = false;      // (per instantiation) allow more than 64 KB of dynamic LDS
@@ -707,6 +708,16 @@ int uocr_pair_strip_fwd_f32(uocr_ctx* ctx, const float* x, const float* w1, cons
 
 int uocr_pair_strip_finish(uocr_ctx* ctx, const float* partial, float* dw1, float* db1, float* dw2, float* db2,
                            int nblocks, int use_b1, int use_b2, int accumulate, float unscale) {
+    FinishDesc fd{};                                     // recorded when a deferred group is open (finish_group.h)
+    fd.kind = FIN_PAIR;
+    fd.partial = partial;
+    fd.nblocks = nblocks;
+    fd.ncols = fd.group_cols = PAIR_NPART;
+    fd.row_stride = PAIR_NPART;
+    fd.dw = dw1, fd.db = db1, fd.dw2 = dw2, fd.db2 = db2;
+    fd.use_bias = use_b1, fd.use_bias2 = use_b2, fd.accumulate = accumulate;
+    fd.unscale = unscale;
+    if (uocr_finish_defer(ctx, fd)) return UOCR_OK;
     hipLaunchKernelGGL(pair_strip_finish, dim3((PAIR_NPART + FC - 1) / FC), dim3(FC * 32), 0, ctx->stream, partial, dw1, db1, dw2,
                        db2, nblocks, use_b1, use_b2, accumulate, unscale);
     UOCR_LAUNCH_CHECK(ctx);

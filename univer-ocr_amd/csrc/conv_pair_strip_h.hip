@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <type_traits>
 
+#include "finish_group.h"
 #include "conv_pair.h"
 #include "conv_pair_strip.h"
 #include "uocr_common.h"
@@ -996,9 +997,9 @@ int wave_bwd_launch(uocr_ctx* ctx, const void* x, const void* y, const void* dy,
                                 sizeof(float) * nw * PAIR_NPART);
     const size_t nblocks = (size_t)blocks_x * bands * n;
     UOCR_REQUIRE(ctx, bands <= 65535 && n <= 65535);
-    int rc = uocr_need_workspace(ctx, nblocks * PAIR_NPART * sizeof(float));
+    int rc = UOCR_OK;
+    float* partial = uocr_partial_buffer(ctx, nblocks * PAIR_NPART * sizeof(float), &rc);
     if (rc != UOCR_OK) return rc;
-    float* partial = (float*)ctx->workspace;
     auto run = [&](auto dxtag, auto sigtag) -> int {
         constexpr bool D = decltype(dxtag)::value, S = decltype(sigtag)::value;
         static bool attr_set = false;
@@ -1045,9 +1046,9 @@ int uocr_pair_strip_bwd_f16(uocr_ctx* ctx, const void* x, const void* y, const v
     bands = (h + band_h - 1) / band_h;
     const size_t nblocks = (size_t)bands * n;
     UOCR_REQUIRE(ctx, bands <= 65535 && n <= 65535);
-    int rc = uocr_need_workspace(ctx, nblocks * PAIR_NPART * sizeof(float));
+    int rc = UOCR_OK;
+    float* partial = uocr_partial_buffer(ctx, nblocks * PAIR_NPART * sizeof(float), &rc);
     if (rc != UOCR_OK) return rc;
-    float* partial = (float*)ctx->workspace;
     const size_t ring = dx ? sizeof(float) * NSLOT * NPLANE * (bwc + 16) : 0;
     const size_t lds = std::max(sizeof(float) * ((nw * L::WAVE + 1) / 2) + ring, sizeof(float) * nw * PAIR_NPART);
     auto launch = [&](auto kernel) -> int {

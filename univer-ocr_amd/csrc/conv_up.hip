@@ -22,6 +22,7 @@
 // float32 rounding (tests: 1e-5 normalised), not bit for bit.
 // hipcc-flags: -mllvm -amdgpu-mfma-vgpr-form=1
 // (MFMA accumulators in VGPRs: no v_accvgpr copies between the MFMAs and the VALU code that consumes them)
+#include "finish_group.h"
 #include "conv_dims.h"
 
 namespace {
@@ -658,9 +659,8 @@ extern "C" int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_
     // fewer, longer blocks than the forward: every block ends with a reduction and a partial row for the finish kernel
     const int strips = (wl + RW - 1) / RW, rows = up_rows_per_block(strips, hl, n, 1024u);
     const int bands = (hl + rows - 1) / rows, nblocks = strips * bands * n;
-    rc = uocr_need_workspace(ctx, (size_t)nblocks * (36 * 16 + 4) * sizeof(float));
-    if (rc != UOCR_OK) return rc;
-    float* partial = (float*)ctx->workspace;                  // rows of 37 (1 channel) / UP_NOUT (4 channels) floats
+    float* partial = uocr_partial_buffer(ctx, (size_t)nblocks * (36 * 16 + 4) * sizeof(float), &rc);   // rows of 37 (1 channel) /
+    if (rc != UOCR_OK) return rc;                                                                     // UP_NOUT (4 channels) floats
     UOCR_DISPATCH_TA(ctx, dtype, {
         if (cin == 1)
             hipLaunchKernelGGL((up1_wgrad_kernel<TA>), dim3(strips, bands, n), dim3(256), 0, ctx->stream,
@@ -673,9 +673,21 @@ extern "C" int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_
     if (cin == 1)
         hipLaunchKernelGGL(up1_wgrad_finish, dim3(26), dim3(256), 0, ctx->stream, (const float*)partial, (float*)dw,
                            (float*)db, nblocks, use_bias, accumulate, unscale);
-    else
+    else {
+        FinishDesc fd{};                                 // recorded when a deferred group is open (finish_group.h)
+        fd.kind = FIN_COLS;
+        fd.partial = partial;
+        fd.nblocks = nblocks;
+        fd.ncols = fd.group_cols = UP_NOUT;
+        fd.row_stride = UP_NOUT;
+        fd.dw = (float*)dw, fd.db = (float*)db;
+        fd.use_bias = use_bias, fd.accumulate = accumulate;
+        fd.unscale = unscale;
+        fd.p[0] = 400;
+        if (uocr_finish_defer(ctx, fd)) return UOCR_OK;
         hipLaunchKernelGGL(colsum_finish_kernel, dim3((UP_NOUT + 7) / 8), dim3(256), 0, ctx->stream, (const float*)partial,
                            nblocks, UP_NOUT, 400, (float*)dw, (float*)db, use_bias, accumulate, unscale);
+    }
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
 }

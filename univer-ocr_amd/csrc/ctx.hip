@@ -3,6 +3,7 @@
 // CP.asnumpy = D2H, cupy.zeros = malloc + memset, cuda.synchronize() = stream sync.
 #include <cstdlib>
 
+#include "finish_group.h"
 #include "gemm.h"
 #include "uocr_common.h"
 
@@ -23,6 +24,7 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->workspace_bytes = 0;
     ctx->sync = nullptr;
     ctx->gemm_defer = nullptr;
+    ctx->finish_defer = nullptr;
     ctx->owns_stream = true;
     ctx->opt_mfma = 1;
     ctx->opt_fast = 1;
@@ -98,6 +100,7 @@ int uocr_ctx_destroy(uocr_ctx* ctx) {
     if (ctx->workspace) hipFree(ctx->workspace);
     if (ctx->sync) hipFree(ctx->sync);
     uocr_gemm_defer_free(ctx);
+    uocr_finish_defer_free(ctx);
     if (ctx->owns_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return UOCR_OK;

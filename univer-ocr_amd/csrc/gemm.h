@@ -26,3 +26,5 @@ int uocr_gemm_mfma(uocr_ctx* ctx, const GemmArgs& g);
 int uocr_gemm(uocr_ctx* ctx, int dtype, const GemmArgs& g);
 // deferred weight-gradient group of a ctx (gemm_mfma.hip): freed with the ctx
 void uocr_gemm_defer_free(uocr_ctx* ctx);
+int uocr_gemm_defer_begin(uocr_ctx* ctx);
+int uocr_gemm_defer_flush(uocr_ctx* ctx, int keep_open);

@@ -1050,20 +1050,17 @@ void uocr_gemm_defer_free(uocr_ctx* ctx) {
     ctx->gemm_defer = nullptr;
 }
 
-extern "C" int uocr_wgrad_defer_begin(uocr_ctx* ctx) {
-    UOCR_CHECK_CTX(ctx);
+int uocr_gemm_defer_begin(uocr_ctx* ctx) {
     if (!ctx->gemm_defer) ctx->gemm_defer = new GemmDefer();
     GemmDefer* d = (GemmDefer*)ctx->gemm_defer;
-    if (d->on) UOCR_FAIL(ctx, UOCR_ERR_ARG, "uocr_wgrad_defer_begin: a deferred group is already open");
     d->on = true;
     d->count = d->nconv = d->ncol = 0;
     return UOCR_OK;
 }
 
-extern "C" int uocr_wgrad_defer_flush(uocr_ctx* ctx, int keep_open) {
-    UOCR_CHECK_CTX(ctx);
+int uocr_gemm_defer_flush(uocr_ctx* ctx, int keep_open) {
     GemmDefer* d = (GemmDefer*)ctx->gemm_defer;
-    if (!d || !d->on) UOCR_FAIL(ctx, UOCR_ERR_ARG, "uocr_wgrad_defer_flush: no deferred group is open");
+    if (!d || !d->on) return UOCR_OK;
     const int rc = defer_flush(ctx);
     d->on = keep_open != 0 && rc == UOCR_OK;
     return rc;

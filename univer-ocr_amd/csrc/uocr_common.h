@@ -14,6 +14,7 @@ struct uocr_ctx {
     void* workspace;
     size_t workspace_bytes;
     void* gemm_defer;    // recorded weight-gradient GEMMs of an open deferred group (gemm_mfma.hip), or null
+    void* finish_defer;  // recorded finish kernels + their partial region (finish_group.hip), or null
     unsigned* sync;      // UOCR_SYNC_WORDS arrival counters of the single-launch reductions (loss.hip): zero between launches
     int cu_count;
     int opt_mfma;        // 0 = never, 1 = auto (default), 2 = whenever eligible (tests)

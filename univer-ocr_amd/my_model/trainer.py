@@ -68,10 +68,11 @@ class PageTrainer:
             side_wgrad = tuple(n for n in os.environ.get('UOCR_SIDE_WGRAD', '').split(',') if n)
         for name, model in self.models.items():
             model.side_wgrad = CP.has_device() and (name in side_wgrad or 'all' in side_wgrad)
-        # group_wgrad: nets whose small weight-gradient GEMMs run as ONE launch at the end of the backward pass
-        # (Runtime.defer_wgrad / uocr_wgrad_defer_*): the Char net's five
+        # group_wgrad: nets whose backward pass runs inside Runtime.defer_wgrad (uocr_wgrad_defer_*): the finish kernels of
+        # the weight-gradient producers (five per step in the Paragraph and Line nets) become ONE launch at the end of the
+        # pass, and so do the small weight-gradient GEMMs (the Char net's five).  Default: every net
         if group_wgrad is None:
-            group_wgrad = tuple(n for n in os.environ.get('UOCR_GROUP_WGRAD', 'Char').split(',') if n)
+            group_wgrad = tuple(n for n in os.environ.get('UOCR_GROUP_WGRAD', 'all').split(',') if n)
         for name, model in self.models.items():
             model.group_wgrad = CP.has_device() and (name in group_wgrad or 'all' in group_wgrad)
         # one stream (lane) per net: the nets are independent until the optimizer step
