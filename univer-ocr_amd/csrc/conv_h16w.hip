@@ -18,6 +18,8 @@
 //     back into the 5x5 kernel by conv_up.hip's finish kernel.
 // Blocks are persistent over a flat tile index; one reduction per block, float64 finish.
 // hipcc-flags: -mllvm -amdgpu-mfma-vgpr-form=1
+#include "finish_group.h"
+#include "up_phase.h"
 #include "conv_dims.h"
 
 namespace {
@@ -303,6 +305,22 @@ __global__ __launch_bounds__(256) void wgrad_h16_finish(const float* __restrict_
     *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
 
+// the same finish as a record of an open deferred group (finish_group.h); false: launch wgrad_h16_finish
+static bool h16_finish_deferred(uocr_ctx* ctx, const float* partial, int nv, int ndw, float* dw, float* db, int nblocks,
+                                int use_bias, int accumulate, float unscale) {
+    FinishDesc fd{};
+    fd.kind = FIN_COLS;
+    fd.partial = partial;
+    fd.nblocks = nblocks;
+    fd.ncols = fd.group_cols = nv;
+    fd.row_stride = nv;
+    fd.dw = dw, fd.db = db;
+    fd.use_bias = use_bias, fd.accumulate = accumulate;
+    fd.unscale = unscale;
+    fd.p[0] = ndw;
+    return uocr_finish_defer(ctx, fd);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // (2) upsample2x + 5x5 4 -> 4 on the low-res grid
 // ------------------------------------------------------------------------------------------------------------
@@ -447,15 +465,16 @@ __global__ __launch_bounds__(256) void wgrad_h16_up_kernel(const _Float16* __res
     dbv += __shfl_xor(dbv, 8, 64);
     if (kq == 3 && n < 4) red[wv][36 * 16 + n] = dbv;
     __syncthreads();
-    for (int i = tid; i < NV; i += 256)
-        partial[(size_t)blockIdx.x * NV + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    // the block's partial row: dw and db themselves (phase entries added here: up_phase.h)
+    up4_write_row(partial + (size_t)blockIdx.x * UP4_NOUT, [&](int i) { return red[0][i] + red[1][i] + red[2][i] + red[3][i]; },
+                  tid, 256);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // (2b) upsample2x + 5x5 1 -> 1 (the Paragraph decoder blocks): dWeff[(my, mx)][phase] = sum_pos xl[pos + m - 1] *
 // dy[2 pos + phase].  One xl pair-word plane; dy as four PHASE planes (row parity from the row, column parity
 // de-interleaved while staging); per source row my one MFMA with M = mx (3 rows + the ones row), N = phase.
-// Partial rows in the layout of conv_up.hip's up1_wgrad_finish: [m * 4 + phase] (36), then db.
+// Partial rows as conv_up.hip's 1-channel producer writes them: dw (5 x 5) and db (up_phase.h).
 // ------------------------------------------------------------------------------------------------------------
 namespace up1 {
 constexpr int BR = 16, BC = 64;                  // low-res positions per tile
@@ -566,7 +585,8 @@ __global__ __launch_bounds__(256) void wgrad_h16_up1_kernel(const _Float16* __re
         if (n == 0) red[wv][36] = dbv;
     }
     __syncthreads();
-    if (tid < NV) partial[(size_t)blockIdx.x * NV + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    up1_write_row(partial + (size_t)blockIdx.x * UP1_NOUT, [&](int i) { return red[0][i] + red[1][i] + red[2][i] + red[3][i]; },
+                  tid);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -794,13 +814,16 @@ int uocr_conv_wgrad_h16(uocr_ctx* ctx, int dtype, const void* x, const void* dy,
     const long cap = (long)ctx->cu_count * (one ? resident_blocks(ctx, wgrad_h16_e11_kernel, &cache11)
                                                 : resident_blocks(ctx, wgrad_h16_e42_kernel, &cache42));
     const int grid = (int)(ntiles < cap ? ntiles : cap);
-    int rc = uocr_need_workspace(ctx, (size_t)grid * nv * sizeof(float));
+    int rc = UOCR_OK;
+    float* partial = uocr_partial_buffer(ctx, (size_t)grid * nv * sizeof(float), &rc);
     if (rc != UOCR_OK) return rc;
-    float* partial = (float*)ctx->workspace;
     hipLaunchKernelGGL(one ? wgrad_h16_e11_kernel : wgrad_h16_e42_kernel, dim3(grid), dim3(256), 0, ctx->stream,
                        (const _Float16*)x, (const _Float16*)dy, partial, d.h, d.w, tiles_x, tiles_y, (int)ntiles,
                        (float)pad_value);
     UOCR_LAUNCH_CHECK(ctx);
+    if (h16_finish_deferred(ctx, partial, nv, one ? 25 : 200, (float*)dw, (float*)db, grid, use_bias, accumulate,
+                            (float)uocr_grad_unscale(dtype)))
+        return UOCR_OK;
     hipLaunchKernelGGL(wgrad_h16_finish, dim3(nv), dim3(256), 0, ctx->stream, (const float*)partial, nv,
                        one ? 25 : 200, (float*)dw, (float*)db, grid, use_bias, accumulate,
                        (float)uocr_grad_unscale(dtype));
@@ -808,8 +831,7 @@ int uocr_conv_wgrad_h16(uocr_ctx* ctx, int dtype, const void* x, const void* dy,
     return UOCR_OK;
 }
 
-// partial rows in the layout of conv_up.hip's finish kernels: 4 channels [(m * 4 + ci) * 16 + phase * 4 + co], then
-// db[4] (upconv_wgrad_finish); 1 channel [m * 4 + phase], then db (up1_wgrad_finish)
+// partial rows as conv_up.hip's producers write them: dw and db themselves (up_phase.h: UP4_NOUT / UP1_NOUT floats)
 int uocr_upconv_wgrad_h16(uocr_ctx* ctx, const void* x_low, const void* dy, float* partial, size_t partial_floats,
                           int n, int hl, int wl, int ch, int* nblocks) {
     if (ch == 1) {
@@ -819,7 +841,7 @@ int uocr_upconv_wgrad_h16(uocr_ctx* ctx, const void* x_low, const void* dy, floa
         UOCR_REQUIRE(ctx, ntiles < (1l << 31) && (long)hl * wl * 4 < (1l << 31));
         const long cap = (long)ctx->cu_count * resident_blocks(ctx, wgrad_h16_up1_kernel, &cache1);
         const int grid = (int)(ntiles < cap ? ntiles : cap);
-        UOCR_REQUIRE(ctx, (size_t)grid * up1::NV <= partial_floats);
+        UOCR_REQUIRE(ctx, (size_t)grid * UP1_NOUT <= partial_floats);
         hipLaunchKernelGGL(wgrad_h16_up1_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const _Float16*)x_low,
                            (const _Float16*)dy, partial, hl, wl, tiles_x, tiles_y, (int)ntiles);
         UOCR_LAUNCH_CHECK(ctx);
@@ -832,7 +854,7 @@ int uocr_upconv_wgrad_h16(uocr_ctx* ctx, const void* x_low, const void* dy, floa
     UOCR_REQUIRE(ctx, ntiles < (1l << 31) && (long)hl * wl * 16 < (1l << 31));
     const long cap = (long)ctx->cu_count * resident_blocks(ctx, wgrad_h16_up_kernel, &cache);
     const int grid = (int)(ntiles < cap ? ntiles : cap);
-    UOCR_REQUIRE(ctx, (size_t)grid * up::NV <= partial_floats);
+    UOCR_REQUIRE(ctx, (size_t)grid * UP4_NOUT <= partial_floats);
     hipLaunchKernelGGL(wgrad_h16_up_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const _Float16*)x_low,
                        (const _Float16*)dy, partial, hl, wl, tiles_x, tiles_y, (int)ntiles);
     UOCR_LAUNCH_CHECK(ctx);
@@ -859,12 +881,15 @@ int launch_s2(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw,
     UOCR_REQUIRE(ctx, ntiles < (1l << 31));
     const long cap = (long)ctx->cu_count * resident_blocks(ctx, wgrad_h16_s2_kernel<CI, CO>, &cache);
     const int grid = (int)(ntiles < cap ? ntiles : cap);
-    int rc = uocr_need_workspace(ctx, (size_t)grid * G::NV * sizeof(float));
+    int rc = UOCR_OK;
+    float* partial = uocr_partial_buffer(ctx, (size_t)grid * G::NV * sizeof(float), &rc);
     if (rc != UOCR_OK) return rc;
-    float* partial = (float*)ctx->workspace;
     hipLaunchKernelGGL((wgrad_h16_s2_kernel<CI, CO>), dim3(grid), dim3(256), 0, ctx->stream, (const _Float16*)x,
                        (const _Float16*)dy, partial, d.h, d.w, d.oh, d.ow, tiles_x, tiles_y, (int)ntiles, (float)pad_value);
     UOCR_LAUNCH_CHECK(ctx);
+    if (h16_finish_deferred(ctx, partial, G::NV, 25 * CI * CO, (float*)dw, (float*)db, grid, use_bias, accumulate,
+                            (float)uocr_grad_unscale(dtype)))
+        return UOCR_OK;
     hipLaunchKernelGGL(wgrad_h16_finish, dim3(G::NV), dim3(256), 0, ctx->stream, (const float*)partial, G::NV,
                        25 * CI * CO, (float*)dw, (float*)db, grid, use_bias, accumulate, (float)uocr_grad_unscale(dtype));
     UOCR_LAUNCH_CHECK(ctx);

@@ -22,6 +22,7 @@
 // float32 rounding (tests: 1e-5 normalised), not bit for bit.
 // hipcc-flags: -mllvm -amdgpu-mfma-vgpr-form=1
 // (MFMA accumulators in VGPRs: no v_accvgpr copies between the MFMAs and the VALU code that consumes them)
+#include "up_phase.h"
 #include "finish_group.h"
 #include "conv_dims.h"
 
@@ -59,7 +60,6 @@ __host__ __device__ __forceinline__ void tap_group(int phase, int mi, int& lo, i
     }
 }
 
-constexpr int UP_NOUT = 404;      // a block's partial row of the 4-channel weight gradient: dw (5 x 5 x 4 x 4), db (4)
 // weff[(m*4 + c)*16 + phase*4 + o], m = my*3 + mx, phase = py*2 + px
 __global__ __launch_bounds__(256) void upconv_weff_kernel(const float* __restrict__ w, float* __restrict__ weff) {
     for (int i = threadIdx.x; i < NWEFF; i += blockDim.x) {
@@ -205,29 +205,22 @@ __global__ __launch_bounds__(256) void upconv_wgrad_kernel(const TA* __restrict_
         for (int v = 0; v < 4; ++v) red[wv][16 * j + 4 * kq + v][n] = acc[j][v];
     reddb[wv][lane] = dbacc;
     __syncthreads();
-    // The block's partial row: the 400 entries of dw (each the sum of its four phase entries of dWeff) and db -- the
-    // phase sums are taken HERE, so that the finish kernel is a plain, coalesced column sum of a 404-column matrix
-    // (it used to gather four scattered entries of a 580-column row per output and block: 10-13 us inside the step)
-    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    float* out = partial + (size_t)blk * UP_NOUT;
-    for (int e = tid; e < 400; e += 256) {
-        const int o = e & 3, c = (e >> 2) & 3, kk = e >> 4, ky = kk / 5, kx = kk % 5;
-        float s = 0.f;
-#pragma unroll
-        for (int phase = 0; phase < 4; ++phase) {
-            // source offset index of tap k for output parity p (tap_group in closed form): (k + p) >> 1
-            const int my = (ky + (phase >> 1)) >> 1, mx = (kx + (phase & 1)) >> 1;
-            const int K = (my * 3 + mx) * CH + c, col = phase * 4 + o;
-            s += red[0][K][col] + red[1][K][col] + red[2][K][col] + red[3][K][col];
-        }
-        out[e] = s;
-    }
+    // The block's partial row: dw and db themselves (the four phase entries of dWeff added HERE, up_phase.h), so that the
+    // finish is a plain, coalesced column sum of a 404-column matrix (it used to gather four scattered entries of a
+    // 580-column row per output and block: 10-13 us inside the step)
     if (tid < 4) {                                       // db[o]: lanes with (n & 3) == o
         float s = 0.f;
         for (int w = 0; w < 4; ++w)
             for (int l = tid; l < 64; l += 4) s += reddb[w][l];
-        out[400 + tid] = s;
+        reddb[0][tid] = s;                               // (read back below as entry 576 + o)
     }
+    __syncthreads();
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    up4_write_row(partial + (size_t)blk * UP4_NOUT, [&](int i) {
+        if (i >= 576) return reddb[0][i - 576];
+        const int K = i >> 4, col = i & 15;
+        return red[0][K][col] + red[1][K][col] + red[2][K][col] + red[3][K][col];
+    }, tid, 256);
 }
 
 // out[a] (+)= unscale * (float64 column sum a of the block partials [nblocks][ncols]), a < ndw -> dw, else db.  Block = 8
@@ -259,47 +252,6 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
     for (int k = 1; k < NSEG; ++k) s += seg[k][o];
     float* dst = j < ndw ? dw + j : db + (j - ndw);
     if (j >= ndw && !use_bias) s = 0.0;
-    s *= (double)unscale;                                // UOCR_F16_SCALED(k): 2^-k, else 1
-    *dst = accumulate ? (float)((double)*dst + s) : (float)s;
-}
-
-// block i < 400: dw[ky][kx][c][o] (+)= sum over blocks and phases of dWeff[(m(py,ky), m(px,kx)), c, (phase,o)];
-// blocks 400..403: db[o]
-__global__ __launch_bounds__(256) void upconv_wgrad_finish(const float* __restrict__ partial, float* __restrict__ dw,
-                                                           float* __restrict__ db, int nblocks, int use_bias,
-                                                           int accumulate, float unscale) {
-    __shared__ double smem[16];
-    const int e = blockIdx.x;
-    double s = 0.0;
-    float* dst;
-    if (e < 400) {
-        const int o = e & 3, c = (e >> 2) & 3, kk = e >> 4, ky = kk / 5, kx = kk % 5;
-        int idx[4];
-#pragma unroll
-        for (int phase = 0; phase < 4; ++phase) {
-            int my = 0, mx = 0, lo, hi;
-            for (int mi = 0; mi < 3; ++mi) {
-                tap_group(phase >> 1, mi, lo, hi);
-                if (ky >= lo && ky < hi) my = mi;
-                tap_group(phase & 1, mi, lo, hi);
-                if (kx >= lo && kx < hi) mx = mi;
-            }
-            idx[phase] = ((my * 3 + mx) * CH + c) * 16 + phase * 4 + o;
-        }
-        for (int blk = threadIdx.x; blk < nblocks; blk += blockDim.x) {
-            const float* p = partial + (size_t)blk * (36 * 16 + 4);
-            s += (double)p[idx[0]] + (double)p[idx[1]] + (double)p[idx[2]] + (double)p[idx[3]];
-        }
-        dst = dw + e;
-    } else {
-        const int o = e - 400;
-        for (int blk = threadIdx.x; blk < nblocks; blk += blockDim.x)
-            s += (double)partial[(size_t)blk * (36 * 16 + 4) + 36 * 16 + o];
-        dst = db + o;
-    }
-    s = block_reduce_sum(s, smem);
-    if (threadIdx.x != 0) return;
-    if (e >= 400 && !use_bias) s = 0.0;
     s *= (double)unscale;                                // UOCR_F16_SCALED(k): 2^-k, else 1
     *dst = accumulate ? (float)((double)*dst + s) : (float)s;
 }
@@ -514,44 +466,9 @@ __global__ __launch_bounds__(256) void up1_wgrad_kernel(const TA* __restrict__ x
     if (lane == 0) red[wv][36] = dbacc;
     __syncthreads();
     const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (tid < 37) partial[(size_t)blk * 37 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    up1_write_row(partial + (size_t)blk * UP1_NOUT, [&](int i) { return red[0][i] + red[1][i] + red[2][i] + red[3][i]; }, tid);
 }
 
-// block e < 25: dw[ky][kx] (+)= sum over blocks and phases of dWeff[m(phase, k)][phase]; block 25: db
-__global__ __launch_bounds__(256) void up1_wgrad_finish(const float* __restrict__ partial, float* __restrict__ dw,
-                                                        float* __restrict__ db, int nblocks, int use_bias,
-                                                        int accumulate, float unscale) {
-    __shared__ double smem[16];
-    const int e = blockIdx.x;
-    double s = 0.0;
-    if (e < 25) {
-        const int ky = e / 5, kx = e % 5;
-        int idx[4];
-#pragma unroll
-        for (int phase = 0; phase < 4; ++phase) {
-            int my = 0, mx = 0, lo, hi;
-            for (int mi = 0; mi < 3; ++mi) {
-                tap_group(phase >> 1, mi, lo, hi);
-                if (ky >= lo && ky < hi) my = mi;
-                tap_group(phase & 1, mi, lo, hi);
-                if (kx >= lo && kx < hi) mx = mi;
-            }
-            idx[phase] = (my * 3 + mx) * 4 + phase;
-        }
-        for (int blk = threadIdx.x; blk < nblocks; blk += blockDim.x) {
-            const float* p = partial + (size_t)blk * 37;
-            s += (double)p[idx[0]] + (double)p[idx[1]] + (double)p[idx[2]] + (double)p[idx[3]];
-        }
-    } else {
-        for (int blk = threadIdx.x; blk < nblocks; blk += blockDim.x) s += (double)partial[(size_t)blk * 37 + 36];
-    }
-    s = block_reduce_sum(s, smem);
-    if (threadIdx.x != 0) return;
-    float* dst = e < 25 ? dw + e : db;
-    if (e == 25 && !use_bias) s = 0.0;
-    s *= (double)unscale;
-    *dst = accumulate ? (float)((double)*dst + s) : (float)s;
-}
 
 int up_rows_per_block(int strips, int hl, int n, unsigned max_blocks = 2048u) {
     int rows = RH;
@@ -638,29 +555,42 @@ extern "C" int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_
     int rc = check_up(ctx, dtype, n, hl, wl, cin, cout, kh, kw, ph, pw);
     if (rc != UOCR_OK) return rc;
     const float unscale = (float)uocr_grad_unscale(dtype);
-    if (UOCR_DTYPE_BASE(dtype) == UOCR_F16 && ctx->opt_fast && ctx->opt_h16 && uocr_aligned_act(x_low, dtype) &&
-        uocr_aligned_act(dy, dtype)) {
-        // binary16 MFMAs over channel / phase planes (conv_h16w.hip), same partial layouts, same finish kernels
-        const size_t floats = (size_t)ctx->cu_count * 8 * (36 * 16 + 4);
-        rc = uocr_need_workspace(ctx, floats * sizeof(float));
-        if (rc != UOCR_OK) return rc;
-        int nblocks = 0;
-        rc = uocr_upconv_wgrad_h16(ctx, x_low, dy, (float*)ctx->workspace, floats, n, hl, wl, cin, &nblocks);
-        if (rc != UOCR_OK) return rc;
-        if (cin == 1)
-            hipLaunchKernelGGL(up1_wgrad_finish, dim3(26), dim3(256), 0, ctx->stream, (const float*)ctx->workspace,
-                               (float*)dw, (float*)db, nblocks, use_bias, accumulate, unscale);
-        else
-            hipLaunchKernelGGL(upconv_wgrad_finish, dim3(404), dim3(256), 0, ctx->stream, (const float*)ctx->workspace,
-                               (float*)dw, (float*)db, nblocks, use_bias, accumulate, unscale);
+    const int ncols = cin == 1 ? UP1_NOUT : UP4_NOUT, ndw = ncols - cin;
+    // the block partials are rows of dw and db themselves (up_phase.h); their float64 column sums: recorded when a deferred
+    // group is open (finish_group.h), else one coalesced launch
+    auto finish = [&](const float* partial, int nblocks) -> int {
+        FinishDesc fd{};
+        fd.kind = FIN_COLS;
+        fd.partial = partial;
+        fd.nblocks = nblocks;
+        fd.ncols = fd.group_cols = ncols;
+        fd.row_stride = ncols;
+        fd.dw = (float*)dw, fd.db = (float*)db;
+        fd.use_bias = use_bias, fd.accumulate = accumulate;
+        fd.unscale = unscale;
+        fd.p[0] = ndw;
+        if (uocr_finish_defer(ctx, fd)) return UOCR_OK;
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3((ncols + 7) / 8), dim3(256), 0, ctx->stream, partial, nblocks, ncols,
+                           ndw, (float*)dw, (float*)db, use_bias, accumulate, unscale);
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
+    };
+    if (UOCR_DTYPE_BASE(dtype) == UOCR_F16 && ctx->opt_fast && ctx->opt_h16 && uocr_aligned_act(x_low, dtype) &&
+        uocr_aligned_act(dy, dtype)) {
+        // binary16 MFMAs over channel / phase planes (conv_h16w.hip), same partial rows
+        const size_t floats = (size_t)ctx->cu_count * 8 * ncols;
+        float* partial = uocr_partial_buffer(ctx, floats * sizeof(float), &rc);
+        if (rc != UOCR_OK) return rc;
+        int nblocks = 0;
+        rc = uocr_upconv_wgrad_h16(ctx, x_low, dy, partial, floats, n, hl, wl, cin, &nblocks);
+        if (rc != UOCR_OK) return rc;
+        return finish(partial, nblocks);
     }
     // fewer, longer blocks than the forward: every block ends with a reduction and a partial row for the finish kernel
     const int strips = (wl + RW - 1) / RW, rows = up_rows_per_block(strips, hl, n, 1024u);
     const int bands = (hl + rows - 1) / rows, nblocks = strips * bands * n;
-    float* partial = uocr_partial_buffer(ctx, (size_t)nblocks * (36 * 16 + 4) * sizeof(float), &rc);   // rows of 37 (1 channel) /
-    if (rc != UOCR_OK) return rc;                                                                     // UP_NOUT (4 channels) floats
+    float* partial = uocr_partial_buffer(ctx, (size_t)nblocks * ncols * sizeof(float), &rc);
+    if (rc != UOCR_OK) return rc;
     UOCR_DISPATCH_TA(ctx, dtype, {
         if (cin == 1)
             hipLaunchKernelGGL((up1_wgrad_kernel<TA>), dim3(strips, bands, n), dim3(256), 0, ctx->stream,
@@ -670,24 +600,5 @@ extern "C" int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_
                                (const TA*)x_low, (const TA*)dy, partial, hl, wl, rows);
     });
     UOCR_LAUNCH_CHECK(ctx);
-    if (cin == 1)
-        hipLaunchKernelGGL(up1_wgrad_finish, dim3(26), dim3(256), 0, ctx->stream, (const float*)partial, (float*)dw,
-                           (float*)db, nblocks, use_bias, accumulate, unscale);
-    else {
-        FinishDesc fd{};                                 // recorded when a deferred group is open (finish_group.h)
-        fd.kind = FIN_COLS;
-        fd.partial = partial;
-        fd.nblocks = nblocks;
-        fd.ncols = fd.group_cols = UP_NOUT;
-        fd.row_stride = UP_NOUT;
-        fd.dw = (float*)dw, fd.db = (float*)db;
-        fd.use_bias = use_bias, fd.accumulate = accumulate;
-        fd.unscale = unscale;
-        fd.p[0] = 400;
-        if (uocr_finish_defer(ctx, fd)) return UOCR_OK;
-        hipLaunchKernelGGL(colsum_finish_kernel, dim3((UP_NOUT + 7) / 8), dim3(256), 0, ctx->stream, (const float*)partial,
-                           nblocks, UP_NOUT, 400, (float*)dw, (float*)db, use_bias, accumulate, unscale);
-    }
-    UOCR_LAUNCH_CHECK(ctx);
-    return UOCR_OK;
+    return finish(partial, nblocks);
 }
