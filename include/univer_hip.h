@@ -119,6 +119,14 @@ int uocr_graph_begin_capture(uocr_ctx* ctx);
 int uocr_graph_end_capture(uocr_ctx* ctx, void** out_graph_exec);
 int uocr_graph_launch(uocr_ctx* ctx, void* graph_exec);
 int uocr_graph_destroy(void* graph_exec);
+/* Per-step snapshots of a net's losses without a launch of their own.  The reference reads every loss on the host right
+ * after the kernel that made it (losses.py:25, models.py:246-254); here losses stay in device slots that the next step
+ * overwrites.  With a snapshot configured, the fused optimizer entry points (uocr_momentum_step_fused /
+ * uocr_adam_step_fused: the last kernel of a train step) end by copying slots[0..count) into row (n % ring_len) of
+ * ring[ring_len][count], n = the number of such calls since `counter` (one device word, zeroed by the caller) was set
+ * up -- a device-side count, so a replayed HIP graph advances it by itself.  slots == NULL switches it off. */
+int uocr_ctx_set_loss_snapshot(uocr_ctx* ctx, const double* slots, int count, double* ring, int ring_len,
+                               unsigned* counter);
 /* Deferred weight gradients.  The reference computes dW of a layer right where it computes dX (convolutional.py:101-145,
  * layers.py:341-347); nothing reads dW before the backward pass ends (models.py:226-254).  Between begin and flush the
  * weight-gradient GEMMs of uocr_conv2d_bwd_weight / uocr_dense_bwd(_act) that are small enough to leave the chip

@@ -24,6 +24,11 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->workspace_bytes = 0;
     ctx->sync = nullptr;
     ctx->gemm_defer = nullptr;
+    ctx->snap_src = nullptr;
+    ctx->snap_count = 0;
+    ctx->snap_ring = nullptr;
+    ctx->snap_ring_len = 0;
+    ctx->snap_counter = nullptr;
     ctx->finish_defer = nullptr;
     ctx->owns_stream = true;
     ctx->opt_mfma = 1;

@@ -337,12 +337,29 @@ __device__ __forceinline__ void opt_fused_one(T& wi, T& gi, T& vi, T& ai, long l
 // VEC = 4: every thread moves 4 consecutive parameters per trip as one vector per array (the arrays are
 // 4-element aligned: the launcher checks); VEC = 1 is the fallback for unaligned views.  The regulariser
 // ranges are tested once per vector, element by element only where a range is touched.
+// uocr_ctx_set_loss_snapshot: the thread that ends the step's last kernel (the one that stores the regularisation loss)
+// copies the net's loss slots into the next row of a ring -- the per-step snapshot of the losses without a copy launch
+// of its own (a launch costs its lane 8-10 us inside the page step).  The row index is a device counter: a replayed
+// HIP graph advances it by itself.
+struct LossSnapshot {
+    const double* src;       // null: off
+    int count;
+    double* ring;            // [ring_len][count]
+    int ring_len;
+    unsigned* counter;
+};
+__device__ __forceinline__ void loss_snapshot(const LossSnapshot& s) {
+    if (!s.src) return;
+    const unsigned k = atomicAdd(s.counter, 1u) % (unsigned)s.ring_len;
+    for (int i = 0; i < s.count; ++i) s.ring[(size_t)k * s.count + i] = s.src[i];
+}
+
 template <typename T, int OPT, int VEC>
 __global__ __launch_bounds__(256) void opt_fused_kernel(T* __restrict__ w, T* __restrict__ g, T* __restrict__ s1,
                                                         T* __restrict__ s2, size_t n, T p0, T p1, T p2, T p3,
                                                         RegRanges rr, double* partial /* [grid][4] */,
                                                         double* __restrict__ loss_out, unsigned* counter,
-                                                        int zero_grad, const double* __restrict__ hyper) {
+                                                        int zero_grad, const double* __restrict__ hyper, LossSnapshot snap) {
     if (hyper) {      // hyper-parameters from device memory: a captured HIP graph follows lr / beta changes
         p0 = (T)hyper[0];
         p1 = (T)hyper[1];
@@ -387,7 +404,10 @@ __global__ __launch_bounds__(256) void opt_fused_kernel(T* __restrict__ w, T* __
         s1[i] = vi;
         if constexpr (OPT == 1) s2[i] = ai;
     }
-    if (rr.n == 0) return;
+    if (rr.n == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) loss_snapshot(snap);
+        return;
+    }
     // one block reduction for all ranges: waves through shuffles, the four waves through LDS (fixed order)
     const int lane = threadIdx.x & 63, wv_id = threadIdx.x >> 6;
 #pragma unroll
@@ -401,6 +421,7 @@ __global__ __launch_bounds__(256) void opt_fused_kernel(T* __restrict__ w, T* __
             double total = 0.0;
             for (int r = 0; r < rr.n; ++r) total += rr.strength[r] * (smem[0][r] + smem[1][r] + smem[2][r] + smem[3][r]);
             *loss_out = total;
+            loss_snapshot(snap);
         }
         return;
     }
@@ -425,6 +446,7 @@ __global__ __launch_bounds__(256) void opt_fused_kernel(T* __restrict__ w, T* __
     if (threadIdx.x == 0) {
         *loss_out = total;
         sync_clear(counter);
+        loss_snapshot(snap);
     }
 }
 
@@ -697,10 +719,11 @@ static int launch_opt_fused(uocr_ctx* ctx, int dtype, int opt, void* w, void* g,
     int rc = uocr_need_workspace(ctx, (size_t)grid * 4 * sizeof(double));
     if (rc) return rc;
     double* partial = (double*)ctx->workspace;
+    const LossSnapshot snap{ctx->snap_src, ctx->snap_count, ctx->snap_ring, ctx->snap_ring_len, ctx->snap_counter};
     UOCR_DISPATCH(ctx, dtype, {
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, ctx->stream, (T*)w, (T*)g, (T*)s1, (T*)s2, count, (T)p0,
-                               (T)p1, (T)p2, (T)p3, rr, partial, reg_loss_out, ctx->sync + 3, zero_grad, hyper_dev);
+                               (T)p1, (T)p2, (T)p3, rr, partial, reg_loss_out, ctx->sync + 3, zero_grad, hyper_dev, snap);
         };
         if (opt == 0 && vec) launch(opt_fused_kernel<T, 0, 4>);
         else if (opt == 0) launch(opt_fused_kernel<T, 0, 1>);
@@ -726,6 +749,18 @@ int uocr_adam_step_fused(uocr_ctx* ctx, int dtype, void* w, void* g, void* v, vo
     UOCR_CHECK_CTX(ctx);
     return launch_opt_fused(ctx, dtype, 1, w, g, v, a, count, lr, beta1, beta2, eps, nranges, lo, hi, kind, strength,
                             reg_loss_out, zero_grad, hyper_dev);
+}
+
+int uocr_ctx_set_loss_snapshot(uocr_ctx* ctx, const double* slots, int count, double* ring, int ring_len,
+                               unsigned* counter) {
+    UOCR_CHECK_CTX(ctx);
+    UOCR_REQUIRE(ctx, !slots || (count > 0 && ring && ring_len > 0 && counter));
+    ctx->snap_src = slots;
+    ctx->snap_count = count;
+    ctx->snap_ring = ring;
+    ctx->snap_ring_len = ring_len;
+    ctx->snap_counter = counter;
+    return UOCR_OK;
 }
 
 int uocr_rmsprop_step(uocr_ctx* ctx, int dtype, void* w, const void* g, void* a, size_t count, double lr,

@@ -13,6 +13,11 @@ struct uocr_ctx {
     bool owns_stream;
     void* workspace;
     size_t workspace_bytes;
+    const double* snap_src;   // uocr_ctx_set_loss_snapshot: loss slots the fused optimizer kernels copy into ...
+    int snap_count;
+    double* snap_ring;        // ... row (counter++ % snap_ring_len) of this ring, or snap_src == null
+    int snap_ring_len;
+    unsigned* snap_counter;
     void* gemm_defer;    // recorded weight-gradient GEMMs of an open deferred group (gemm_mfma.hip), or null
     void* finish_defer;  // recorded finish kernels + their partial region (finish_group.hip), or null
     unsigned* sync;      // UOCR_SYNC_WORDS arrival counters of the single-launch reductions (loss.hip): zero between launches

@@ -68,6 +68,7 @@ _PROTOS = {
     'uocr_graph_end_capture': [_ctx, C.POINTER(_vp)],
     'uocr_graph_launch': [_ctx, _vp],
     'uocr_graph_destroy': [_vp],
+    'uocr_ctx_set_loss_snapshot': [_ctx, _vp, _i, _vp, _i, _vp],
     'uocr_wgrad_defer_begin': [_ctx],
     'uocr_wgrad_defer_flush': [_ctx, _i],
     'uocr_device_info': [_ctx, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_sz)],

@@ -104,7 +104,7 @@ class PageTrainer:
         # first GPU call (bench.py sets it; ROCm's default 4 makes two nets share a queue)
         self.pipelined = bool(pipelined) and self.lanes is not None
         # graphs: the captured step writes its losses into static slots that the NEXT replay overwrites; with
-        # snapshot_losses every step() copies them (one 8-byte-per-loss copy per net, on the net's lane) so that the
+        # snapshot_losses the step's last kernel copies them into the next row of a ring of 64 (LossArena) so that the
         # scalars it returns keep the value of THEIR step however late they are read
         self.snapshot_losses = bool(snapshot_losses)
         self._lane_done = {}
@@ -287,8 +287,13 @@ class PageTrainer:
             parts = []
             try:
                 with rt.lane(self.lanes[comp.name]):
+                    # the loss slots and their snapshot ring live as long as the graphs: allocated BEFORE the first capture
+                    # (what is allocated in the pool between or during captures may be handed out again to a later capture)
+                    ring = self.snapshot_losses and model.has_fused_tail()
                     with torch.cuda.use_mem_pool(pool):
                         arena = CP.loss_arena = LossArena(16)
+                        if ring:
+                            arena.arm()
                     cap = [rt.capture(pool)]
                     cap[0].__enter__()
 
@@ -310,7 +315,12 @@ class PageTrainer:
                     begin = GraphSequence(parts)
                     pending = model._pending_losses
                     with rt.capture(pool) as finish:
-                        losses = model.train_finish()
+                        if ring:                              # the optimizer tail itself snapshots the loss slots
+                            rt.set_loss_snapshot(arena)
+                        try:
+                            losses = model.train_finish()
+                        finally:
+                            rt.set_loss_snapshot(None)
             finally:
                 CP.loss_arena = None
             slots = pending + [losses['regularization_loss']]
@@ -402,8 +412,9 @@ class PageTrainer:
                     if model.grad_sync is not None and model.defer_grad_sync:
                         model.grad_sync.__self__.wait(model)
                     entry['finish'].replay()
-                    if self.snapshot_losses:                  # one 8-byte-per-loss copy on the lane, no kernel
-                        snap = entry['arena'].snapshot()
+                    if self.snapshot_losses:                  # the row of the ring the replayed optimizer tail wrote to,
+                        arena = entry['arena']                # or (no fused tail) one 8-byte-per-loss copy on the lane
+                        snap = arena.next_row() if arena.ring is not None else arena.snapshot()
                 done = self._event(comp.name).record()
             if entry is None:
                 self._finish_lane(comp.name, done, context['losses'][comp.name])

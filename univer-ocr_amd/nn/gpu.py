@@ -130,6 +130,15 @@ class Runtime:
         self._options = getattr(self, '_options', {})
         self._options[key] = int(value)              # (replayed on contexts made later: side streams)
 
+    def set_loss_snapshot(self, arena):
+        """From now on the fused optimizer tails launched on the CURRENT lane end by copying `arena`'s slots into the next
+        row of its ring (LossArena.arm); None switches it off."""
+        if arena is None:
+            self.call('uocr_ctx_set_loss_snapshot', None, 0, None, 0, None)
+        else:
+            self.call('uocr_ctx_set_loss_snapshot', arena.array.ptr, arena.array.shape[0], arena.ring.ptr, arena.ring_len,
+                      arena.counter.ptr)
+
     # -- deferred weight gradients (uocr_wgrad_defer_begin / _flush): one launch for the small GEMMs of a backward pass --
     def defer_wgrad(self):
         """`with rt.defer_wgrad():` -- the weight-gradient GEMMs issued inside on the current lane that are too small
@@ -273,12 +282,18 @@ class _Capture:
 
 
 class LossArena:
-    """Consecutive float64 loss slots in ONE device array: the loss kernels of a captured step write side by side,
-    so one uocr_d2d snapshots all of them (no packing kernel)."""
+    """Consecutive float64 loss slots in ONE device array: the loss kernels of a captured step write side by side.
+    Per-step snapshots: `arm()` gives the arena a ring of `ring_len` rows; with Runtime.set_loss_snapshot(arena) in force
+    the step's last kernel (the fused optimizer tail) copies the slots into the next row by itself
+    (uocr_ctx_set_loss_snapshot), and `next_row()` names that row on the host -- no copy launch.  A row is overwritten
+    `ring_len` steps later."""
 
-    def __init__(self, capacity=16):
+    def __init__(self, capacity=16, ring_len=64):
         self.array = CP.empty((capacity,), np.float64)
         self.used = 0
+        self.ring_len = ring_len
+        self.ring = self.counter = None
+        self.rows = 0                                # optimizer tails launched since arm() (the device counts the same)
 
     def take(self):
         if self.used >= self.array.shape[0]:
@@ -291,10 +306,25 @@ class LossArena:
         return (tensor.data_ptr() - self.array.ptr) // 8
 
     def snapshot(self):
-        """a copy of the used slots, made on the current ctx's stream"""
+        """a copy of the used slots, made on the current ctx's stream (one uocr_d2d)"""
         out = CP.empty((self.used,), np.float64)
         CP.runtime().call('uocr_d2d', out.ptr, self.array.ptr, 8 * self.used)
         return out
+
+    def arm(self):
+        """allocate the ring and its device counter (not inside a graph capture: the counter is zeroed once)"""
+        capacity = self.array.shape[0]
+        self.ring = CP.empty((self.ring_len * capacity,), np.float64)
+        self.counter = CP.zeros((1,), np.int32)
+        self.rows = 0
+        return self
+
+    def next_row(self):
+        """the ring row the optimizer tail that was just launched writes: a view, valid for ring_len further steps"""
+        capacity = self.array.shape[0]
+        k = self.rows % self.ring_len
+        self.rows += 1
+        return DeviceArray(self.ring.t[k * capacity:(k + 1) * capacity])
 
 
 class _DeferScope:

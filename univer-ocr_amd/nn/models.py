@@ -596,6 +596,13 @@ class Model(BaseModel):
         """The three calls that end a train step (models.py:252-254: regularize via compute_loss_and_gradients,
         update_grads, clear_grads) as ONE kernel over the flat pack when the whole model is trained by one
         Momentum or Adam optimizer and has at most 4 L1/L2 ranges; None = not applicable, run them one by one."""
+        plan = self._fused_tail_plan()
+        if plan is None:
+            return None
+        optimizer, pack, ranges = plan
+        return optimizer.update_pack_fused(pack, ranges)
+
+    def _fused_tail_plan(self):
         from .optimizers import Adam, Momentum
         pack = self._pack
         if pack is None or not self.trainable or not all(layer.trainable for layer in self.layers.values()):
@@ -606,7 +613,11 @@ class Model(BaseModel):
         ranges = self._regularizer_ranges()
         if len(ranges) > 4 or any(key[0] not in ('l1', 'l2') for key, _, _ in ranges):
             return None
-        return optimizer.update_pack_fused(pack, ranges)
+        return optimizer, pack, ranges
+
+    def has_fused_tail(self):
+        """True when train_finish ends in ONE fused kernel (which can also snapshot the loss slots: LossArena)."""
+        return self._fused_tail_plan() is not None
 
     def test(self, X, y):
         predicted = self.forward(make_list_if_not(X))
