@@ -71,8 +71,12 @@ class PageTrainer:
         # group_wgrad: nets whose backward pass runs inside Runtime.defer_wgrad (uocr_wgrad_defer_*): the finish kernels of
         # the weight-gradient producers (five per step in the Paragraph and Line nets) become ONE launch at the end of the
         # pass, and so do the small weight-gradient GEMMs (the Char net's five).  Default: every net
+        # (under data parallelism only the Char net: in the one-rank RCCL rehearsal the page nets' late finish launches cost
+        # more than they save -- 0.865 ms/step with 'Char', 0.880 with 'all', 0.905 with none; without it 0.835 / 0.822 / 0.852)
+        if data_parallel is None:
+            data_parallel = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if group_wgrad is None:
-            group_wgrad = tuple(n for n in os.environ.get('UOCR_GROUP_WGRAD', 'all').split(',') if n)
+            group_wgrad = tuple(n for n in os.environ.get('UOCR_GROUP_WGRAD', 'Char' if data_parallel else 'all').split(',') if n)
         for name, model in self.models.items():
             model.group_wgrad = CP.has_device() and (name in group_wgrad or 'all' in group_wgrad)
         # one stream (lane) per net: the nets are independent until the optimizer step
