@@ -189,12 +189,14 @@ int uocr_conv_pair_bwd(uocr_ctx* ctx, int dtype, const void* x, const void* y, c
  * (float32; results equal the two-layer path to rounding, not bit for bit).  Arguments as uocr_conv2d_*,
  * with hl, wl the LOW-RES size; bwd_data returns the gradient w.r.t. x_low (= upsample backward of the conv's
  * dx).  UOCR_ERR_UNSUPPORTED for any other shape or dtype: the caller then runs the two layers. */
+/* weff (may be NULL): 576 floats owned by the caller.  The float32 4-channel forward writes the per-phase 3 x 3 weights
+ * there; handed to bwd_data of the same layer while w is unchanged (the same train step), it saves that call a launch. */
 int uocr_upconv2x_fwd(uocr_ctx* ctx, int dtype, const void* x_low, const void* w, const void* b, void* y,
                       int n, int hl, int wl, int cin, int cout, int kh, int kw, int ph, int pw,
-                      int use_bias, int act, double act_alpha);
+                      int use_bias, int act, double act_alpha, void* weff);
 int uocr_upconv2x_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, const void* w, void* dx_low,
                            int n, int hl, int wl, int cin, int cout, int kh, int kw, int ph, int pw,
-                           const void* x_act, int act, double act_alpha);
+                           const void* x_act, int act, double act_alpha, const void* weff);
 int uocr_upconv2x_bwd_weight(uocr_ctx* ctx, int dtype, const void* x_low, const void* dy, void* dw, void* db,
                              int n, int hl, int wl, int cin, int cout, int kh, int kw, int ph, int pw,
                              int use_bias, int accumulate);

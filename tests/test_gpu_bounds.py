@@ -77,11 +77,11 @@ def test_upconv_stays_inside_its_buffers(shape, ch, rt):
     w, b = CP.copy(rng.standard_normal((5, 5, ch, ch)) * 0.1), CP.copy(rng.standard_normal(ch))
     dims = (n, hl, wl, ch, ch, 5, 5, 2, 2)
     y = Guarded(CP, n * 4 * hl * wl * ch)
-    runtime.call('uocr_upconv2x_fwd', hiplib.F32, xl.ptr, w.ptr, b.ptr, y.ptr, *dims, 1, hiplib.ACT_LEAKY, 0.01)
+    runtime.call('uocr_upconv2x_fwd', hiplib.F32, xl.ptr, w.ptr, b.ptr, y.ptr, *dims, 1, hiplib.ACT_LEAKY, 0.01, None)
     y.check('upconv fwd y')
     g = CP.copy(rng.standard_normal((n, 2 * hl, 2 * wl, ch)))
     dx = Guarded(CP, n * hl * wl * ch)
-    runtime.call('uocr_upconv2x_bwd_data', hiplib.F32, g.ptr, w.ptr, dx.ptr, *dims, xl.ptr, hiplib.ACT_LEAKY, 0.01)
+    runtime.call('uocr_upconv2x_bwd_data', hiplib.F32, g.ptr, w.ptr, dx.ptr, *dims, xl.ptr, hiplib.ACT_LEAKY, 0.01, None)
     dx.check('upconv dx')
     dw, db = Guarded(CP, 25 * ch * ch), Guarded(CP, ch)
     runtime.call('uocr_upconv2x_bwd_weight', hiplib.F32, xl.ptr, g.ptr, dw.ptr, db.ptr, *dims, 1, 0)

@@ -384,6 +384,14 @@ def test_upconv2x_kernels_against_oracle(shape, ch, bias, act, f32):
     gd = CP.copy(gz)
     dx = ops.upconv2x_bwd_data(gd, wd, xl.shape, (2, 2))
     check(dx, ref_dx, 1e-5, 'dx')
+    if ch == 4:
+        # the per-phase weights written by the forward kernel and handed back: the same bits as computed in the call
+        weff = CP.full((576,), np.nan)
+        y2 = ops.upconv2x_fwd(xd, wd, bd, (2, 2), bias, act, alpha, weff=weff)
+        assert np.array_equal(CP.asnumpy(y2), CP.asnumpy(y))
+        assert np.isfinite(CP.asnumpy(weff)).all()
+        dx2 = ops.upconv2x_bwd_data(gd, wd, xl.shape, (2, 2), weff=weff)
+        assert np.array_equal(CP.asnumpy(dx2), CP.asnumpy(dx))
     # epilogue: dx *= LeakyReLU'(x_act) with x_act = the low-res input seen as an activation output
     dxm = ops.upconv2x_bwd_data(gd, wd, xl.shape, (2, 2), x_act=xd, act='leaky', alpha=alpha)
     check(dxm, ref_dx * ((xl >= 0) + alpha * (xl < 0)), 1e-5, 'dx with mask')

@@ -96,9 +96,24 @@ template <typename TA>
 __global__ __launch_bounds__(256) void upconv_fwd_kernel(const TA* __restrict__ xl, const float* __restrict__ w,
                                                          const float* __restrict__ bias, TA* __restrict__ y,
                                                          int hl, int wl, int rows_per_block, int use_bias, int act,
-                                                         float alpha) {
+                                                         float alpha, float* __restrict__ weff_out) {
     __shared__ float xs[CH * XPLANE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
+    // the per-phase 3 x 3 weights the backward-data kernel of this layer wants (upconv_weff_kernel's table), written by
+    // block 0 while it is here anyway: the caller hands the buffer back to uocr_upconv2x_bwd_data, which then needs no
+    // launch of its own for them (a launch costs the lane 8-10 us inside the page step)
+    if (weff_out && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        for (int i = tid; i < NWEFF; i += 256) {
+            const int o = i & 3, phase = (i >> 2) & 3, c = (i >> 4) & 3, m = i >> 6;
+            int ylo, yhi, xlo, xhi;
+            tap_group(phase >> 1, m / 3, ylo, yhi);
+            tap_group(phase & 1, m % 3, xlo, xhi);
+            float s = 0.f;
+            for (int ky = ylo; ky < yhi; ++ky)
+                for (int kx = xlo; kx < xhi; ++kx) s += w[((ky * 5 + kx) * CH + c) * CH + o];
+            weff_out[i] = s;
+        }
+    }
     const int rx = blockIdx.x * RW;
     const int row_begin = blockIdx.y * rows_per_block, row_end = min(hl, row_begin + rows_per_block);
     const TA* xb = xl + (size_t)blockIdx.z * hl * wl * CH;
@@ -491,7 +506,7 @@ int check_up(uocr_ctx* ctx, int dtype, int n, int hl, int wl, int cin, int cout,
 
 extern "C" int uocr_upconv2x_fwd(uocr_ctx* ctx, int dtype, const void* x_low, const void* w, const void* b, void* y,
                                  int n, int hl, int wl, int cin, int cout, int kh, int kw, int ph, int pw,
-                                 int use_bias, int act, double act_alpha) {
+                                 int use_bias, int act, double act_alpha, void* weff) {
     UOCR_CHECK_CTX(ctx);
     UOCR_REQUIRE(ctx, x_low && w && b && y);
     int rc = check_up(ctx, dtype, n, hl, wl, cin, cout, kh, kw, ph, pw);
@@ -507,7 +522,7 @@ extern "C" int uocr_upconv2x_fwd(uocr_ctx* ctx, int dtype, const void* x_low, co
         else
             hipLaunchKernelGGL((upconv_fwd_kernel<TA>), dim3(strips, (hl + rows - 1) / rows, n), dim3(256), 0,
                                ctx->stream, (const TA*)x_low, (const float*)w, (const float*)b, (TA*)y, hl, wl, rows,
-                               use_bias, act, (float)act_alpha);
+                               use_bias, act, (float)act_alpha, (float*)weff);
     });
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;
@@ -515,7 +530,7 @@ extern "C" int uocr_upconv2x_fwd(uocr_ctx* ctx, int dtype, const void* x_low, co
 
 extern "C" int uocr_upconv2x_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, const void* w, void* dx_low, int n,
                                       int hl, int wl, int cin, int cout, int kh, int kw, int ph, int pw,
-                                      const void* x_act, int act, double act_alpha) {
+                                      const void* x_act, int act, double act_alpha, const void* weff_in) {
     UOCR_CHECK_CTX(ctx);
     UOCR_REQUIRE(ctx, dy && w && dx_low);
     UOCR_REQUIRE(ctx, act == UOCR_ACT_NONE || x_act != nullptr);
@@ -527,12 +542,12 @@ extern "C" int uocr_upconv2x_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, 
     if (uocr_upconv_t32_eligible(ctx, dtype, cin, cout) && (reinterpret_cast<uintptr_t>(dy) & 15u) == 0 &&
         (reinterpret_cast<uintptr_t>(dx_low) & 15u) == 0 && (act == UOCR_ACT_NONE || (reinterpret_cast<uintptr_t>(x_act) & 15u) == 0))
         return uocr_upconv_dgrad_t32(ctx, dy, w, dx_low, n, hl, wl, cin, act == UOCR_ACT_NONE ? nullptr : x_act, act, act_alpha);
-    float* weff = nullptr;
-    if (cin != 1) {
+    const float* weff = (const float*)weff_in;             // from this layer's forward call with the same w, or null
+    if (cin != 1 && !weff) {
         rc = uocr_need_workspace(ctx, NWEFF * sizeof(float));
         if (rc != UOCR_OK) return rc;
-        weff = (float*)ctx->workspace;
-        hipLaunchKernelGGL(upconv_weff_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)w, weff);
+        hipLaunchKernelGGL(upconv_weff_kernel, dim3(1), dim3(256), 0, ctx->stream, (const float*)w, (float*)ctx->workspace);
+        weff = (const float*)ctx->workspace;
     }
     const dim3 grid((wl + RW - 1) / RW, (hl + RH - 1) / RH, n);
     UOCR_DISPATCH_TA(ctx, dtype, {
@@ -541,7 +556,7 @@ extern "C" int uocr_upconv2x_bwd_data(uocr_ctx* ctx, int dtype, const void* dy, 
                                (TA*)dx_low, hl, wl, (const TA*)x_act, act, (float)act_alpha);
         else
             hipLaunchKernelGGL((upconv_dgrad_kernel<TA>), grid, dim3(256), 0, ctx->stream, (const TA*)dy,
-                               (const float*)weff, (TA*)dx_low, hl, wl, (const TA*)x_act, act, (float)act_alpha);
+                               weff, (TA*)dx_low, hl, wl, (const TA*)x_act, act, (float)act_alpha);
     });
     UOCR_LAUNCH_CHECK(ctx);
     return UOCR_OK;

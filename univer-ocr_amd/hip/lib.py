@@ -77,8 +77,8 @@ _PROTOS = {
     'uocr_conv2d_bwd_weight': [_ctx, _i, _vp, _vp, _vp, _vp] + [_i] * 13 + [_d, _i, _i],
     'uocr_conv_pair_fwd': [_ctx, _i] + [_vp] * 6 + [_i] * 4 + [_d, _i, _i, _d, _i],
     'uocr_conv_pair_bwd': [_ctx, _i] + [_vp] * 11 + [_i] * 4 + [_d, _i, _i, _d, _i, _i],
-    'uocr_upconv2x_fwd': [_ctx, _i, _vp, _vp, _vp, _vp] + [_i] * 9 + [_i, _i, _d],
-    'uocr_upconv2x_bwd_data': [_ctx, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp, _i, _d],
+    'uocr_upconv2x_fwd': [_ctx, _i, _vp, _vp, _vp, _vp] + [_i] * 9 + [_i, _i, _d, _vp],
+    'uocr_upconv2x_bwd_data': [_ctx, _i, _vp, _vp, _vp] + [_i] * 9 + [_vp, _i, _d, _vp],
     'uocr_upconv2x_bwd_weight': [_ctx, _i, _vp, _vp, _vp, _vp] + [_i] * 9 + [_i, _i],
     'uocr_maxpool2d_fwd': [_ctx, _i, _vp, _vp, _vp] + [_i] * 12,
     'uocr_maxpool2d_bwd': [_ctx, _i, _vp, _vp, _vp] + [_i] * 12,

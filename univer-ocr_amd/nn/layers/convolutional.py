@@ -5,7 +5,10 @@ The reference has a NumPy path (Python loop over output pixels, :62-145) and a n
 semantics follow the NumPy path: the `bias` flag is honoured in forward and in db (the numba path
 always adds the bias, :168-169), `padding_value` fills the border and contributes to dw.
 """
+import numpy as np
+
 from .. import ops
+from ..gpu import CP
 from ..help_func import make_list_if_not, tuplize
 from ..progress_tracker import track_method
 from .layers import BaseLayer, BaseLayerGPU, Param
@@ -106,9 +109,15 @@ class Convolutional2D(BaseLayerGPU):
         x_low = ops.as_device(x_low)
         assert x_low.shape[3] == self.in_channels
         self._mem[0] = x_low
+        # float32, 4 channels: the forward kernel leaves the per-phase weights for this step's backward_up
+        self._weff = None
+        if self.in_channels == 4 and x_low.dtype == np.float32:
+            if getattr(self, '_weff_buf', None) is None:
+                self._weff_buf = CP.empty((576,), np.float32)
+            self._weff = self._weff_buf
         y = ops.upconv2x_fwd(x_low, self.w.value, self.b.value, self.padding, self.bias,
                              None if activation is None else activation.kind,
-                             0.0 if activation is None else activation.alpha)
+                             0.0 if activation is None else activation.alpha, weff=self._weff)
         self._fused_out = y if activation is not None else None
         return y
 
@@ -121,11 +130,13 @@ class Convolutional2D(BaseLayerGPU):
             grad = ops.act_bwd_from_output(activation.kind, self._fused_out, grad, activation.alpha)
         x_low = self._mem[0]
         ops.upconv2x_bwd_weight(x_low, grad, self.w.grad, self.b.grad, self.padding, self.bias, accumulate=True)
+        weff = getattr(self, '_weff', None)               # written by forward_up of this step (same weights)
+        self._weff = None
         if input_activation is None:
-            dx = ops.upconv2x_bwd_data(grad, self.w.value, x_low.shape, self.padding)
+            dx = ops.upconv2x_bwd_data(grad, self.w.value, x_low.shape, self.padding, weff=weff)
         else:
             dx = ops.upconv2x_bwd_data(grad, self.w.value, x_low.shape, self.padding, x_act=x_low,
-                                       act=input_activation.kind, alpha=input_activation.alpha)
+                                       act=input_activation.kind, alpha=input_activation.alpha, weff=weff)
         self._fused_out = None
         self.clear_memory()
         return dx

@@ -138,22 +138,24 @@ def _up_dims(x_low_shape, w_shape, padding):
     return n, hl, wl, cin, cout, kh, kw, padding[0], padding[1]
 
 
-def upconv2x_fwd(x_low, w, b, padding, bias=True, act=None, alpha=0.0):
-    """Upsample2D(2) + conv (stride 1) on the low-res tensor (float32 5x5 4->4 only, see univer_hip.h)."""
+def upconv2x_fwd(x_low, w, b, padding, bias=True, act=None, alpha=0.0, weff=None):
+    """Upsample2D(2) + conv (stride 1) on the low-res tensor (float32 5x5 4->4 only, see univer_hip.h).
+    `weff`: a float32 array of 576 that receives the per-phase weights for upconv2x_bwd_data of the same step."""
     dims = _up_dims(x_low.shape, w.shape, padding)
     code = _same_dtype(x_low, w, b)
     y = CP.empty((dims[0], 2 * dims[1], 2 * dims[2], dims[4]), x_low.dtype)
     _rt().call('uocr_upconv2x_fwd', code, x_low.ptr, w.ptr, b.ptr, y.ptr, *dims, int(bool(bias)), ACT_CODES[act],
-               float(alpha))
+               float(alpha), None if weff is None else weff.ptr)
     return y
 
 
-def upconv2x_bwd_data(dy, w, x_low_shape, padding, x_act=None, act=None, alpha=0.0):
+def upconv2x_bwd_data(dy, w, x_low_shape, padding, x_act=None, act=None, alpha=0.0, weff=None):
+    """`weff`: what upconv2x_fwd of this layer wrote in the same step (w unchanged since), or None."""
     dims = _up_dims(x_low_shape, w.shape, padding)
     code = _same_dtype(dy, w, grad=dy)
     dx = _like_grad(CP.empty(x_low_shape, dy.dtype), dy)
     _rt().call('uocr_upconv2x_bwd_data', code, dy.ptr, w.ptr, dx.ptr, *dims, None if x_act is None else x_act.ptr,
-               ACT_CODES[act if x_act is not None else None], float(alpha))
+               ACT_CODES[act if x_act is not None else None], float(alpha), None if weff is None else weff.ptr)
     return dx
 
 
