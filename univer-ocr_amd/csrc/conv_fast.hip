@@ -311,12 +311,13 @@ __global__ __launch_bounds__(256) void conv_dgrad_c64s2(const float* __restrict_
                                                         const float* __restrict__ mask_y, int mask_act,
                                                         float mask_alpha) {
     constexpr int KH = 5, KW = 3, CO = 64;
-    const size_t pix = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    // grid = (16-pixel groups of a row, rows, images): the pixel's coordinates without an integer division (three 64-bit
+    // ones per thread used to come before the first load)
     const int q = threadIdx.x & 15;                        // channels 4q .. 4q + 3
-    const size_t total = (size_t)n * h * wd;
-    const bool live = pix < total;
-    const size_t p = live ? pix : total - 1;
-    const int x = (int)(p % wd), y = (int)((p / wd) % h), b = (int)(p / ((size_t)wd * h));
+    const int b = blockIdx.z, y = blockIdx.y;
+    const bool live = (int)(blockIdx.x * 16 + (threadIdx.x >> 4)) < wd;
+    const int x = live ? blockIdx.x * 16 + (threadIdx.x >> 4) : wd - 1;
+    const size_t pix = ((size_t)b * h + y) * wd + x;
     const float* gb = dy + (size_t)b * oh * ow * CO + 4 * q;
     float acc = 0.f;
 #pragma unroll
@@ -1368,8 +1369,8 @@ int uocr_conv_dgrad_fast(uocr_ctx* ctx, int dtype, const void* dy, const void* w
         return UOCR_OK;
     }
     if (f32 && d.kh == 5 && d.kw == 3 && d.sh == 2 && d.sw == 1 && d.ph == 0 && d.pw == 1 && d.cin == 1 && d.cout == 64) {
-        const size_t pixels = (size_t)d.n * d.h * d.w;
-        hipLaunchKernelGGL(conv_dgrad_c64s2, dim3((unsigned)((pixels + 15) / 16)), dim3(256), 0, ctx->stream,
+        UOCR_REQUIRE(ctx, d.h <= 65535 && d.n <= 65535);
+        hipLaunchKernelGGL(conv_dgrad_c64s2, dim3((unsigned)((d.w + 15) / 16), d.h, d.n), dim3(256), 0, ctx->stream,
                            (const float*)dy, (const float*)w, (float*)dx, d.n, d.h, d.w, d.oh, d.ow,
                            (const float*)mask.y, mask.act, (float)mask.alpha);
         UOCR_LAUNCH_CHECK(ctx);

@@ -251,6 +251,12 @@ struct AConvFwd {
     ConvDims d;
     float pad;
     int m;             // n*oh*ow
+    // (every integer division of the loaders is a multiply-high by a constant prepared on the host: the hardware has no
+    // integer divide, the emulation is ~30 instructions, and on gfx950 a loader's vector instructions are paid in MFMA time)
+    int cpt;           // depth tiles per tap = cin / BD
+    FastDiv by_ow, by_oh, by_cpt, by_kw;
+    AConvFwd(const float* x_, const ConvDims& d_, float pad_, int m_)
+        : x(x_), d(d_), pad(pad_), m(m_), cpt(d_.cin / BD), by_ow(d_.ow), by_oh(d_.oh), by_cpt(d_.cin / BD), by_kw(d_.kw) {}
     struct Row {
         long base;     // offset of x[b, iy0, ix0, 0] (may be negative)
         int iy0, ix0;
@@ -260,9 +266,8 @@ struct AConvFwd {
         Row r;
         r.ok = i < m;
         const int p = r.ok ? i : 0;
-        const int ox = p % d.ow;
-        const int t = p / d.ow;
-        const int oy = t % d.oh, b = t / d.oh;
+        const int t = by_ow.div(p), ox = p - t * d.ow;
+        const int b = by_oh.div(t), oy = t - b * d.oh;
         r.iy0 = oy * d.sh - d.ph;
         r.ix0 = ox * d.sw - d.pw;
         r.base = (((long)b * d.h + r.iy0) * d.w + r.ix0) * d.cin;
@@ -271,13 +276,13 @@ struct AConvFwd {
     static constexpr bool HAS_SLOW = false;
     __device__ __forceinline__ float fill() const { return pad; }
     __device__ __forceinline__ F4 load(const Row& r, int tile, int kq, int& code) const {
-        const int cpt = d.cin / BD;
-        const int kk = tile / cpt, c0 = (tile - kk * cpt) * BD + kq * 4;
-        const int ky = kk / d.kw, kx = kk - ky * d.kw;
+        // the tap of a depth tile is the same for the whole block: scalar work
+        const int kk = by_cpt.div(tile), ky = by_kw.div(kk), kx = kk - ky * d.kw;
+        const int tap_off = (ky * d.w + kx) * d.cin + (tile - kk * cpt) * BD;
         const int iy = r.iy0 + ky, ix = r.ix0 + kx;
-        const bool inside = iy >= 0 && iy < d.h && ix >= 0 && ix < d.w;
+        const bool inside = (unsigned)iy < (unsigned)d.h && (unsigned)ix < (unsigned)d.w;
         code = !r.ok ? LD_ZERO : (inside ? LD_KEEP : LD_PAD);
-        return *reinterpret_cast<const F4*>(code == LD_KEEP ? x + r.base + ((long)ky * d.w + kx) * d.cin + c0 : x);
+        return *reinterpret_cast<const F4*>(code == LD_KEEP ? x + r.base + (tap_off + kq * 4) : x);
     }
 };
 
@@ -287,31 +292,37 @@ struct AConvDgrad {
     const float* dy;
     ConvDims d;
     int m;             // n*h*w
+    int cpt;           // depth tiles per tap = cout / BD
+    FastDiv by_w, by_h, by_cpt, by_kw, by_sh, by_sw;
+    AConvDgrad(const float* dy_, const ConvDims& d_, int m_)
+        : dy(dy_), d(d_), m(m_), cpt(d_.cout / BD), by_w(d_.w), by_h(d_.h), by_cpt(d_.cout / BD), by_kw(d_.kw), by_sh(d_.sh),
+          by_sw(d_.sw) {}
     struct Row {
-        int b, y, x;
+        long base;     // offset of dy[b, 0, 0, 0]
+        int y, x;
         bool ok;
     };
     __device__ __forceinline__ Row prep(int i) const {
         Row r;
         r.ok = i < m;
         const int p = r.ok ? i : 0;
-        r.x = p % d.w;
-        const int t = p / d.w;
-        r.y = t % d.h;
-        r.b = t / d.h;
+        const int t = by_w.div(p);
+        r.x = p - t * d.w;
+        const int b = by_h.div(t);
+        r.y = t - b * d.h;
+        r.base = (long)b * d.oh * d.ow * d.cout;
         return r;
     }
     static constexpr bool HAS_SLOW = false;
     __device__ __forceinline__ float fill() const { return 0.f; }
     __device__ __forceinline__ F4 load(const Row& r, int tile, int kq, int& code) const {
-        const int cpt = d.cout / BD;
-        const int kk = tile / cpt, c0 = (tile - kk * cpt) * BD + kq * 4;
-        const int ky = kk / d.kw, kx = kk - ky * d.kw;
+        const int kk = by_cpt.div(tile), ky = by_kw.div(kk), kx = kk - ky * d.kw;      // (scalar: the block's tap)
+        const int c0 = (tile - kk * cpt) * BD + kq * 4;
         const int ty = r.y + d.ph - ky, tx = r.x + d.pw - kx;
-        const int gy = ty / d.sh, gx = tx / d.sw;     // (truncation for negative ty / tx is caught by ty >= 0)
+        const int gy = by_sh.div(ty), gx = by_sw.div(tx);      // (meaningless for negative ty / tx: caught by ty >= 0)
         const bool hit = r.ok && ty >= 0 && tx >= 0 && gy * d.sh == ty && gx * d.sw == tx && gy < d.oh && gx < d.ow;
         code = hit ? LD_KEEP : LD_ZERO;
-        return *reinterpret_cast<const F4*>(hit ? dy + (((long)r.b * d.oh + gy) * d.ow + gx) * d.cout + c0 : dy);
+        return *reinterpret_cast<const F4*>(hit ? dy + r.base + ((gy * d.ow + gx) * d.cout + c0) : dy);
     }
     // A strided transposed conv multiplies structural zeros: input row y only receives tap rows ky with
     // (y + ph - ky) divisible by the stride and inside the output.  When the BM rows of a block lie in ONE
@@ -320,13 +331,13 @@ struct AConvDgrad {
     __device__ __forceinline__ bool tile_is_zero(int m0, int bm, int tile) const {
         if (d.sh == 1) return false;        // only the top / bottom image rows would gain: not worth the test
         const int last = min(m0 + bm, m) - 1;
-        const int r0 = m0 / d.w, r1 = last / d.w;
+        const int r0 = by_w.div(m0), r1 = by_w.div(last);
         if (r0 != r1) return false;
-        const int y = r0 % d.h;
-        const int kk = tile / (d.cout / BD), ky = kk / d.kw;
+        const int y = r0 - by_h.div(r0) * d.h;
+        const int ky = by_kw.div(by_cpt.div(tile));
         const int ty = y + d.ph - ky;
         if (ty < 0) return true;
-        const int gy = ty / d.sh;
+        const int gy = by_sh.div(ty);
         return gy * d.sh != ty || gy >= d.oh;
     }
 };
@@ -996,7 +1007,7 @@ bool uocr_conv_mfma_eligible(uocr_ctx* ctx, int dtype, const ConvDims& d, int wh
 int uocr_conv_fwd_mfma(uocr_ctx* ctx, const void* x, const void* w, const void* b, void* y, const ConvDims& d,
                        double pad_value, int use_bias, int act, double act_alpha) {
     const int M = d.n * d.oh * d.ow, K = d.kh * d.kw * d.cin;
-    AConvFwd A{(const float*)x, d, (float)pad_value, M};
+    AConvFwd A((const float*)x, d, (float)pad_value, M);
     BRowMajor B{(const float*)w, d.cout, K, d.cout, aligned16(w) ? 1 : 0};
     Epilogue ep{(float*)y, d.cout, use_bias ? (const float*)b : nullptr, act, (float)act_alpha, 0, -1, nullptr,
                 nullptr,    UOCR_ACT_NONE, 0.f};
@@ -1007,7 +1018,7 @@ int uocr_conv_dgrad_mfma(uocr_ctx* ctx, const void* dy, const void* w, void* dx,
                          const ActMask& mask) {
     const int M = d.n * d.h * d.w, D = d.kh * d.kw * d.cout;
     // B((kk, oc), ic) = w[(kk * cin + ic) * cout + oc]: the weights as they lie in memory, read along oc
-    AConvDgrad A{(const float*)dy, d, M};
+    AConvDgrad A((const float*)dy, d, M);
     BDepthContig B{(const float*)w, d.cout, d.cin, D, d.cin, FastDiv(d.cout), aligned16(w) ? 1 : 0};
     Epilogue ep = plain_epilogue((float*)dx, d.cin, 0);
     ep.mask_y = (const float*)mask.y;
