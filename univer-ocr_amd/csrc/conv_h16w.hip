@@ -79,8 +79,9 @@ __global__ __launch_bounds__(256) void wgrad_h16_e42_kernel(const _Float16* __re
     const int xu = tid & 15, xr0 = tid >> 4;
     const int du = tid % 18, dr0 = tid / 18;
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int strip = t % tiles_x, trow = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+    TileWalk walk(blockIdx.x, gridDim.x, tiles_x, tiles_y);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x, walk.next(tiles_x, tiles_y)) {
+        const int strip = walk.strip, trow = walk.trow, img = walk.img;
         const int C0 = strip * BC - 4, R0 = trow * BR;
         const _Float16* xb = x + (size_t)img * h * wd * 4;
         const _Float16* gb = dy + (size_t)img * h * wd * 2;
@@ -214,8 +215,9 @@ __global__ __launch_bounds__(256) void wgrad_h16_e11_kernel(const _Float16* __re
     const int xu = tid & 7, xr0 = tid >> 3;              // x unit = 8 pixels (16 bytes), 8 units per row
     const int du = tid % 18, dr0 = tid / 18;             // dy unit = 4 pixels + the next one, 18 units per row
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int strip = t % tiles_x, trow = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+    TileWalk walk(blockIdx.x, gridDim.x, tiles_x, tiles_y);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x, walk.next(tiles_x, tiles_y)) {
+        const int strip = walk.strip, trow = walk.trow, img = walk.img;
         const int C0 = strip * BC - 4, R0 = trow * BR;
         const _Float16* xb = x + (size_t)img * h * wd;
         const _Float16* gb = dy + (size_t)img * h * wd;
@@ -358,8 +360,9 @@ __global__ __launch_bounds__(256) void wgrad_h16_up_kernel(const _Float16* __res
     const int xu = tid % 17, xr0 = tid / 17;
     const int gu = tid & 15, gr0 = tid >> 4;
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int strip = t % tiles_x, trow = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+    TileWalk walk(blockIdx.x, gridDim.x, tiles_x, tiles_y);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x, walk.next(tiles_x, tiles_y)) {
+        const int strip = walk.strip, trow = walk.trow, img = walk.img;
         const int C0 = strip * BC, R0 = trow * BR;
         const _Float16* xb = xl + (size_t)img * hl * wl * 4;
         const _Float16* gb = dy + (size_t)img * H * W * 4;
@@ -505,8 +508,9 @@ __global__ __launch_bounds__(256) void wgrad_h16_up1_kernel(const _Float16* __re
     const int xu = tid % 17, xr0 = tid / 17;             // xl unit = 4 pixels + the next one, 17 units per row
     const int gu = tid & 15, gr0 = tid >> 4;             // dy unit = 8 high-res pixels (16 bytes) of one row
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int strip = t % tiles_x, trow = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+    TileWalk walk(blockIdx.x, gridDim.x, tiles_x, tiles_y);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x, walk.next(tiles_x, tiles_y)) {
+        const int strip = walk.strip, trow = walk.trow, img = walk.img;
         const int C0 = strip * BC, R0 = trow * BR;
         const _Float16* xb = xl + (size_t)img * hl * wl;
         const _Float16* gb = dy + (size_t)img * H * W;
@@ -643,8 +647,9 @@ __global__ __launch_bounds__(256) void wgrad_h16_s2_kernel(const _Float16* __res
     const int xu = tid % G::XU, xr0 = tid / G::XU;       // x unit = 8 pixels, 17 units per row, 15 rows per pass
     const int du = tid % 18, dr0 = tid / 18;             // dy unit = 4 pixels + the next one, 18 units per row
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int strip = t % tiles_x, trow = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+    TileWalk walk(blockIdx.x, gridDim.x, tiles_x, tiles_y);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x, walk.next(tiles_x, tiles_y)) {
+        const int strip = walk.strip, trow = walk.trow, img = walk.img;
         const int C0 = strip * BC - 1, R0 = trow * BR;   // plane index Q of tile column 0; first position row
         const _Float16* xb = x + (size_t)img * h * wd * CI;
         const _Float16* gb = dy + (size_t)img * oh * ow * CO;

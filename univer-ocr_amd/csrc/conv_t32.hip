@@ -131,8 +131,9 @@ __global__ __launch_bounds__(256) void conv_t32_kernel(const float* __restrict__
     const int sr = tid / G::UW, su = tid - sr * G::UW;
     const bool stager = sr < G::RPP;
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int strip = t % tiles_x, trow = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+    TileWalk walk(blockIdx.x, gridDim.x, tiles_x, tiles_y);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x, walk.next(tiles_x, tiles_y)) {
+        const int strip = walk.strip, trow = walk.trow, img = walk.img;
         const int c_begin = strip * G::BC, r0 = trow * G::BR;
         const float* inb = in + (size_t)img * h_in * w_in * C;
         const size_t out_img = (size_t)img * h_out * w_out * COUT;

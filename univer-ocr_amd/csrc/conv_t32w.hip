@@ -121,8 +121,9 @@ __global__ __launch_bounds__(256) void wgrad_t32_s2_kernel(const float* __restri
     const int xu = tid % G::XU, xr0 = tid / G::XU;       // x unit = 8 pixels, 17 units per row, 15 rows per pass
     const int du = tid % 18, dr0 = tid / 18;             // dy unit = 4 pixels, 18 units per row
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int strip = t % tiles_x, trow = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+    TileWalk walk(blockIdx.x, gridDim.x, tiles_x, tiles_y);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x, walk.next(tiles_x, tiles_y)) {
+        const int strip = walk.strip, trow = walk.trow, img = walk.img;
         const int C0 = strip * BC - 1, R0 = trow * BR;   // plane index Q of tile column 0; first position row
         const float* xb = x + (size_t)img * h * wd * CI;
         const float* gb = dy + (size_t)img * oh * ow * CO;
@@ -237,8 +238,9 @@ __global__ __launch_bounds__(256) void wgrad_t32_e_kernel(const float* __restric
     const int xu = tid & 15, xr0 = tid >> 4;             // x unit = 4 pixels, 16 units per row, 16 rows per pass
     const int du = tid % 18, dr0 = tid / 18;             // dy unit = 4 pixels, 18 units per row, 14 rows per pass
 
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int strip = t % tiles_x, trow = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+    TileWalk walk(blockIdx.x, gridDim.x, tiles_x, tiles_y);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x, walk.next(tiles_x, tiles_y)) {
+        const int strip = walk.strip, trow = walk.trow, img = walk.img;
         const int C0 = strip * BC - 4, R0 = trow * BR;   // position col = (dy column) - sx starts at -4
         const float* xb = x + (size_t)img * h * wd * CI;
         const float* gb = dy + (size_t)img * h * wd * CO;

@@ -264,5 +264,32 @@ __device__ __forceinline__ T act_grad_from_output(T y, int act, T alpha) {
     return T(1);
 }
 
+// Tile coordinates of a persistent block that walks t = blockIdx.x, += gridDim.x over tiles_x * tiles_y * images tiles:
+// the three integer divisions (no hardware divide: ~20 dependent instructions each, in front of the tile's first load)
+// are made once, for the first tile and for the stride; every further tile is three scalar adds with carries.
+struct TileWalk {
+    int strip, trow, img;
+    int qx, qy, qz;
+    __device__ __forceinline__ TileWalk(int first, int step, int tiles_x, int tiles_y) {
+        strip = first % tiles_x;
+        int r = first / tiles_x;
+        trow = r % tiles_y;
+        img = r / tiles_y;
+        qx = step % tiles_x;
+        r = step / tiles_x;
+        qy = r % tiles_y;
+        qz = r / tiles_y;
+    }
+    __device__ __forceinline__ void next(int tiles_x, int tiles_y) {
+        strip += qx;
+        int carry = strip >= tiles_x;
+        strip -= carry ? tiles_x : 0;
+        trow += qy + carry;
+        carry = trow >= tiles_y;
+        trow -= carry ? tiles_y : 0;
+        img += qz + carry;
+    }
+};
+
 // out = (accumulate ? out : 0) + scale * sum(partial[0..count)), one block, deterministic order
 int uocr_finish_sum(uocr_ctx* ctx, const double* partial, int count, double scale, double* out, int accumulate);
