@@ -1,7 +1,7 @@
 #!/bin/bash
 # conv loaders of the MFMA GEMM without integer divisions: tests, the microbenchmark rows they serve, Char alone, the step
 set -o pipefail
-# (tests: run separately)
+timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_configs.py -x -q -m gpu -k "mfma or dense or golden or config or wide or deferred or windows" 2>&1 | tail -2 || exit 1
 timeout -k 10 300 python tools/bench_conv.py --filter "char." --reps 30 2>&1 | grep "char"
 timeout -k 10 300 python tools/bench_conv.py --filter "wide" --reps 5 2>&1 | grep "wide"
 timeout -k 10 200 python tools/bench_nets.py --graphs --steps 60 --only Char 2>/dev/null | grep -v "^$"

@@ -550,10 +550,16 @@ __device__ __forceinline__ void gemm_tile(const ALoader& A, const BLoader& B, co
     };
     auto store_tile = [&](int buf) {
         float* as = As + buf * ASZ;
+        // (interior tiles: every group of the wave was loaded as it is -- one vote instead of 8 selects per group)
+        int codes = bcode[0] | bcode[1];
 #pragma unroll
-        for (int s = 0; s < A_REGS; ++s) areg[s] = ld_resolve(areg[s], acode[s], A.fill());
+        for (int s = 0; s < A_REGS; ++s) codes |= acode[s];
+        if (__builtin_amdgcn_ballot_w64(codes != LD_KEEP) != 0) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) breg[s] = ld_resolve(breg[s], bcode[s], 0.f);
+            for (int s = 0; s < A_REGS; ++s) areg[s] = ld_resolve(areg[s], acode[s], A.fill());
+#pragma unroll
+            for (int s = 0; s < 2; ++s) breg[s] = ld_resolve(breg[s], bcode[s], 0.f);
+        }
         if constexpr (ALoader::DEPTH_CONTIG) {
 #pragma unroll
             for (int s = 0; s < A_PASSES; ++s)
