@@ -57,15 +57,22 @@ def main():
         assert rt.lib.uocr_event_create(ctypes.byref(e)) == 0
 
     def timed(fn):
+        # event pairs around chunks of 5 back-to-back launches, the fastest chunk counts: a host hiccup between two launches
+        # (allocator, garbage collector: ~0.9 ms every dozen calls once earlier rows have filled the allocator's cache)
+        # is not kernel time -- rocprofv3 shows the same kernel durations with and without it (tools/dev/t32_modes.sh)
         fn()
         rt.synchronize()
-        rt.call('uocr_event_record', ev[0])
-        for _ in range(args.reps):
-            fn()
-        rt.call('uocr_event_record', ev[1])
-        ms = ctypes.c_float()
-        assert rt.lib.uocr_event_elapsed_ms_sync(ev[0], ev[1], ctypes.byref(ms)) == 0
-        return ms.value * 1e3 / args.reps
+        per = min(5, args.reps)
+        best = None
+        for _ in range(max(1, args.reps // per)):
+            rt.call('uocr_event_record', ev[0])
+            for _ in range(per):
+                fn()
+            rt.call('uocr_event_record', ev[1])
+            ms = ctypes.c_float()
+            assert rt.lib.uocr_event_elapsed_ms_sync(ev[0], ev[1], ctypes.byref(ms)) == 0
+            best = ms.value if best is None else min(best, ms.value)
+        return best * 1e3 / per
 
     rng = np.random.default_rng(0)
 
