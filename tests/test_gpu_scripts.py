@@ -57,23 +57,35 @@ def test_page_feeder_uint8_pipeline_matches_direct_copy():
             assert got.dtype == np.float32 and np.allclose(got, expect, rtol=1e-6, atol=0), label
 
 
+def run_two_ranks(script_args, env, root, timeout):
+    """`python -m torch.distributed.run --nproc-per-node 2 <script_args>` on a free rendezvous port of 127.0.0.1.  The port
+    is found by binding and closing a socket, so something else can take it before torchrun does: that one failure
+    (and only that: EADDRINUSE in stderr) gets a second port."""
+    import socket
+    import subprocess
+    import sys
+    out = None
+    for _ in range(2):
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+               '127.0.0.1', '--master-port', str(port), *script_args]
+        out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=timeout)
+        if out.returncode == 0 or not any(k in out.stderr for k in ('EADDRINUSE', 'ddress already in use')):
+            break
+    return out
+
+
 def test_bench_two_rank_rehearsal_prints_one_valid_line():
     """`bench.py --gpus 2` launched the way the driver does (torch.distributed.run, one process per rank), with
     UOCR_BENCH_REHEARSAL=1 so that both ranks share the one card through gloo: rendezvous, data-parallel
     trainer, barrier / max-over-ranks timing and the rank-0 JSON line of the multi-rank path."""
     import os
-    import socket
-    import subprocess
-    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, UOCR_BENCH_REHEARSAL='1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-           '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3',
-           '--warmup', '2', '--batch', '4', '--height', '64', '--width', '128']
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    out = run_two_ranks([os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2', '--batch', '4',
+                         '--height', '64', '--width', '128'], env, root, 600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [line for line in out.stdout.splitlines() if line.startswith('{')]
     assert len(lines) == 1
@@ -132,19 +144,11 @@ def test_train_py_data_parallel_two_ranks(tmp_path):
     model_weights.json.  Two ranks share the one card here, so the gradient exchange goes through gloo
     (UOCR_DP_BACKEND=gloo); on a node with one GPU per rank the same code path runs the RCCL entry points."""
     import os
-    import socket
-    import subprocess
-    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
     weights_path = tmp_path / 'model_weights.json'
     env = dict(os.environ, UOCR_DP_BACKEND='gloo', UOCR_WEIGHTS=str(weights_path), UOCR_EPOCHS_SCALE='0.011',
                UOCR_TRAIN_PAGE='32x64', UOCR_DUMP_FINAL_WEIGHTS=str(tmp_path / 'final'))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-           '127.0.0.1', '--master-port', str(port), os.path.join(root, 'train.py'), 'True']
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    out = run_two_ranks([os.path.join(root, 'train.py'), 'True'], env, root, 900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
     weights = json.loads(weights_path.read_text())
     assert 'Monochrome/conv_1' in weights and 'Char/dense_block/dense_3' in weights
