@@ -88,7 +88,8 @@ void* uocr_ctx_get_stream(uocr_ctx* ctx);
  * UOCR_BUILD_EXPERIMENTS=1 ./build.sh and are refused with UOCR_ERR_UNSUPPORTED otherwise; likewise "h3" = 1, the
  * float32 Line output conv forward on error-compensated binary16 MFMAs); the Monochrome pair kernels:
  * "pair_band" (rows per band, 0 auto), "pair_g" (4 / 2 groups of 16 columns per wave), "pair_pf" (row prefetch form
- * of the forward kernels, -1 auto).  Results do not depend on any of them beyond float32
+ * of the forward kernels, -1 auto); "wgrad_bands" (row bands per tap / channel group of the direct weight-gradient
+ * kernels, 0 = 64 or 512 by the kernel's accumulator count).  Results do not depend on any of them beyond float32
  * summation order ("h16": beyond the binary16 rounding of the weight operands; "h3": 22 significant bits). */
 int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value);
 int uocr_ctx_reserve_workspace(uocr_ctx* ctx, size_t bytes);   /* synchronises; not capturable */

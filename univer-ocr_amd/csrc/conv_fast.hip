@@ -1242,9 +1242,14 @@ struct FastConv {
     static int wgrad(uocr_ctx* ctx, int dtype, const void* x, const void* dy, void* dw, void* db, const ConvDims& d,
                      double pad, int use_bias, int accumulate) {
         using C = WgradCfg<KH, KW, CIN, COUT, SH, SW, KYR, WCOB>;
-        // bands of output rows: ~512 blocks per (tap group, channel group), at least 4 rows each
+        // bands of output rows: ~512 (or 64) blocks per (tap group, channel group), at least 4 rows each
         constexpr int RQ = 4;             // rows consumed per block iteration (one per wave)
-        int rows = (d.n * d.oh + 511) / 512;
+        // (a wave ends in a reduce-scatter of its NP accumulators over the 64 lanes, ~3 instructions per accumulator: with 128
+        // of them a band of 4 rows -- one row per wave -- spent four fifths of its time there.  Measured per band target,
+        // 32 x 64 x 128 x 4 -> 4 stride 2: 27.8 us at 512, 17.4 at 128, 17.3 at 64; the 64-accumulator one-channel kernels
+        // are fastest at 512: 13.1 us against 18.5 at 256 and 15.5 at 1024)
+        const int bands = ctx->opt_wgrad_bands > 0 ? ctx->opt_wgrad_bands : (C::NP >= 128 ? 64 : 512);
+        int rows = (d.n * d.oh + bands - 1) / bands;
         rows = ((rows + RQ - 1) / RQ) * RQ;
         if (rows > d.oh) rows = ((d.oh + RQ - 1) / RQ) * RQ;
         const int nbands = (d.oh + rows - 1) / rows;

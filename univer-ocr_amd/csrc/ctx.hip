@@ -44,12 +44,14 @@ int uocr_ctx_create(int device, size_t workspace_bytes, uocr_ctx** out) {
     ctx->opt_pair_band = 0;
     ctx->opt_pair_g = 4;
     ctx->opt_group_blocks = 0;
+    ctx->opt_wgrad_bands = 0;
     ctx->opt_h3 = 0;
 #ifdef UOCR_EXPERIMENTS
     if (const char* e = getenv("UOCR_H3")) ctx->opt_h3 = atoi(e);            // development override (tools/dev/h3_ab.sh)
 #endif
     ctx->opt_pair_pf = -1;   // auto: float32 one step ahead (49.5 us; 50.8 pinned in the loop, 51.8 three ahead), binary16 three (72.1; 73.8 / 75.5)
     if (const char* e = getenv("UOCR_PAIR_PF")) ctx->opt_pair_pf = atoi(e);   // development override (tools/dev/pf_ab.sh)
+    if (const char* e = getenv("UOCR_WGRAD_BANDS")) ctx->opt_wgrad_bands = atoi(e);   // development override (tools/dev/bands_ab.sh)
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return UOCR_ERR_HIP;
@@ -142,6 +144,7 @@ int uocr_ctx_set_option(uocr_ctx* ctx, const char* key, int value) {
     else if (!strcmp(key, "pair_band")) ctx->opt_pair_band = value;
     else if (!strcmp(key, "pair_g")) ctx->opt_pair_g = value;
     else if (!strcmp(key, "group_blocks")) ctx->opt_group_blocks = value;
+    else if (!strcmp(key, "wgrad_bands") && value >= 0) ctx->opt_wgrad_bands = value;
     else if (!strcmp(key, "h3")) {
 #ifndef UOCR_EXPERIMENTS
         if (value) UOCR_FAIL(ctx, UOCR_ERR_UNSUPPORTED, "option h3: this library was built without conv_h3 "

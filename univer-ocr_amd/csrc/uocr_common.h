@@ -35,6 +35,7 @@ struct uocr_ctx {
     int opt_pair_pf;     // row prefetch of the pair forward kernels (-1 auto / 0 / 1 / 2, see conv_pair_strip.hip)
     int opt_h3;          // 1 = the float32 Line output conv forward on error-compensated binary16 MFMAs (conv_h3.hip; experiment)
     int opt_group_blocks; // blocks of a deferred weight-gradient group (0 = four per CU)
+    int opt_wgrad_bands;  // row bands per tap / channel group of the direct weight-gradient kernels (0 = by accumulator count)
     int opt_pair_g;      // groups of 16 columns per wave of the strip kernels: 4 (8 waves per block) or 2 (16 waves)
     char err[512];
 };
