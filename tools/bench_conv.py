@@ -102,15 +102,18 @@ def main():
     def up_rows():
         # Upsample2D(2) + conv5x5 4->4 on the low-res tensor (csrc/conv_up.hip); FLOPs of the 5x5 on the
         # upsampled tensor (what the two-layer path computes), bytes = low-res tensor + high-res tensor
-        for name, hl, wl in (('line.up_2 (fused)', 64, 128), ('line.up_1 (fused)', 128, 256)):
+        for name, hl, wl, ch in (('line.up_2 (fused)', 64, 128, 4), ('line.up_1 (fused)', 128, 256, 4),
+                                 ('para.up_2 (fused)', 64, 128, 1), ('para.up_1 (fused)', 128, 256, 1)):
+            if args.filter not in name:
+                continue
             n = args.batch
-            xl = CP.copy(rng.standard_normal((n, hl, wl, 4)).astype(np.float32))
-            wt = CP.copy((rng.standard_normal((5, 5, 4, 4)) * 0.1).astype(np.float32))
-            b = CP.zeros((4,))
-            g = CP.copy(rng.standard_normal((n, 2 * hl, 2 * wl, 4)).astype(np.float32))
-            dw, db = CP.zeros(wt.shape), CP.zeros((4,))
-            nbytes = 4 * n * hl * wl * 4 * 5
-            flop = 2.0 * n * 4 * hl * wl * 400
+            xl = CP.copy(rng.standard_normal((n, hl, wl, ch)).astype(np.float32))
+            wt = CP.copy((rng.standard_normal((5, 5, ch, ch)) * 0.1).astype(np.float32))
+            b = CP.zeros((ch,))
+            g = CP.copy(rng.standard_normal((n, 2 * hl, 2 * wl, ch)).astype(np.float32))
+            dw, db = CP.zeros(wt.shape), CP.zeros((ch,))
+            nbytes = 4 * n * hl * wl * ch * 5
+            flop = 2.0 * n * 4 * hl * wl * 25 * ch * ch
             for op, fn in [('fwd', lambda: ops.upconv2x_fwd(xl, wt, b, (2, 2), True, 'leaky', 0.01)),
                            ('dgrad', lambda: ops.upconv2x_bwd_data(g, wt, xl.shape, (2, 2))),
                            ('wgrad', lambda: ops.upconv2x_bwd_weight(xl, g, dw, db, (2, 2)))]:
@@ -121,7 +124,7 @@ def main():
     print(f'{"layer":18s} {"op":6s} {"us":>9s} {"MB":>8s} {"GB/s":>8s} {"GFLOP":>8s} {"TF/s":>7s}')
     if args.filter in 'mono.pair (fused)':
         pair_rows()
-    if args.filter in 'line.up_1 (fused)' or args.filter in 'line.up_2 (fused)':
+    if any(args.filter in name for name in ('line.up_1 (fused)', 'line.up_2 (fused)', 'para.up_1 (fused)', 'para.up_2 (fused)')):
         up_rows()
     for name, h, w, cin, cout, ks, st, pd in LAYERS:
         if args.filter not in name:
