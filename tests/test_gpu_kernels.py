@@ -58,6 +58,10 @@ CONV_SHAPES = [
     ((2, 7, 9, 64), (3, 2), 32, (1, 1), (1, 0), 0.0, False),         # no bias
     ((2, 20, 24, 32), (1, 1), 64, (1, 1), (0, 0), 0.0, True),        # 1x1
     ((3, 96, 128, 32), (3, 3), 64, (1, 1), (1, 1), 0.0, True),       # 36864 rows -> BM=128 tiles
+    # the loaders' quotients are multiply-highs by host constants (FastDiv): divisors that are not powers of two --
+    # 3 depth tiles per tap (96 channels), strides 3 and 2, a 4-wide kernel, 13 / 7 / 5-wide images
+    ((2, 13, 7, 96), (3, 4), 32, (3, 2), (1, 2), 0.0, True),
+    ((3, 10, 5, 32), (4, 3), 96, (2, 3), (2, 1), -0.5, True),
 ]
 
 
