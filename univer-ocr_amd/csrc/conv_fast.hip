@@ -1373,8 +1373,8 @@ int uocr_conv_dgrad_fast(uocr_ctx* ctx, int dtype, const void* dy, const void* w
         UOCR_LAUNCH_CHECK(ctx);
         return UOCR_OK;
     }
-    if (f32 && d.kh == 5 && d.kw == 3 && d.sh == 2 && d.sw == 1 && d.ph == 0 && d.pw == 1 && d.cin == 1 && d.cout == 64) {
-        UOCR_REQUIRE(ctx, d.h <= 65535 && d.n <= 65535);
+    if (f32 && d.kh == 5 && d.kw == 3 && d.sh == 2 && d.sw == 1 && d.ph == 0 && d.pw == 1 && d.cin == 1 && d.cout == 64 &&
+        d.h <= 65535 && d.n <= 65535) {                   // (rows and images are grid dimensions y and z)
         hipLaunchKernelGGL(conv_dgrad_c64s2, dim3((unsigned)((d.w + 15) / 16), d.h, d.n), dim3(256), 0, ctx->stream,
                            (const float*)dy, (const float*)w, (float*)dx, d.n, d.h, d.w, d.oh, d.ow,
                            (const float*)mask.y, mask.act, (float)mask.alpha);
