@@ -979,7 +979,8 @@ __global__ __launch_bounds__(320) void conv_wgrad_t542(const TA* __restrict__ x,
         const int y0 = t * TH;
         __syncthreads();                                   // the previous tile's reads are over
         // (rolled staging loops on purpose: with the loads batched in registers, or prefetched across tiles,
-        // the kernel needs 160+ VGPRs and loses more in occupancy than the overlap gains: 57 -> 60-64 us)
+        // the kernel needs 160+ VGPRs and loses more in occupancy than the overlap gains: 57 -> 60-64 us; pairs of
+        // loads through stage_batched: 56 -> 81 us)
         for (int e = tid; e < WH * WW; e += 320) {
             const int r = e / WW, c = e - r * WW;
             const int gy = y0 - 2 + r, gx = x0 - 2 + c;
@@ -1070,7 +1071,7 @@ __global__ __launch_bounds__(320) void conv_wgrad_s2_tiled(const TA* __restrict_
                                                            float* __restrict__ partial, int h, int wd, int oh, int ow,
                                                            float pad, int tiles_per_block) {
     using C = S2Cfg<CIN, COUT>;
-    __shared__ float xs[C::WH * C::WW * CIN];
+    __shared__ __attribute__((aligned(16))) float xs[C::WH * C::WW * CIN];
     __shared__ float gs[C::TH * C::TW * COUT];
     const int tid = threadIdx.x, lane = tid & 63, ky = tid >> 6;
     const int ox0 = blockIdx.x * C::TW, b = blockIdx.z;
@@ -1084,6 +1085,21 @@ __global__ __launch_bounds__(320) void conv_wgrad_s2_tiled(const TA* __restrict_
     for (int t = tile0; t < t_end; ++t) {
         const int oy0 = t * C::TH;
         __syncthreads();                                   // the previous tile's reads are over
+        if constexpr (sizeof(TA) == 4 && (CIN == 1 || CIN == 4)) {
+            using VX = std::conditional_t<CIN == 1, float, float4>;        // (the window's loads in flight together)
+            stage_batched<C::WH * C::WW, 320, 4, VX>(
+                tid,
+                [&](int e, bool& inside) {
+                    const int r = e / C::WW, c = e - r * C::WW;
+                    const int gy = 2 * oy0 - 2 + r, gx = 2 * ox0 - 2 + c;
+                    inside = gy >= 0 && gy < h && gx >= 0 && gx < wd;
+                    return reinterpret_cast<const VX*>(xb + ((size_t)min(max(gy, 0), h - 1) * wd + min(max(gx, 0), wd - 1)) * CIN);
+                },
+                [&](int e, VX v, bool inside) {
+                    if constexpr (CIN == 1) xs[e] = inside ? v : pad;
+                    else *reinterpret_cast<float4*>(xs + e * 4) = inside ? v : make_float4(pad, pad, pad, pad);
+                });
+        } else {
         for (int e = tid; e < C::WH * C::WW; e += 320) {
             const int r = e / C::WW, c = e - r * C::WW;
             const int gy = 2 * oy0 - 2 + r, gx = 2 * ox0 - 2 + c;
@@ -1092,6 +1108,7 @@ __global__ __launch_bounds__(320) void conv_wgrad_s2_tiled(const TA* __restrict_
             const bool in = gy >= 0 && gy < h && gx >= 0 && gx < wd;
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) xs[e * CIN + ci] = in ? v[ci] : pad;
+        }
         }
         for (int e = tid; e < C::TH * C::TW; e += 320) {
             const int r = e / C::TW, c = e - r * C::TW;

@@ -78,6 +78,24 @@ __global__ __launch_bounds__(256) void upconv_weff_kernel(const float* __restric
 template <typename TA>
 __device__ __forceinline__ void stage_planar(float* __restrict__ xs, const TA* __restrict__ xb, int ry, int rx,
                                              int hl, int wl, int tid) {
+    if constexpr (sizeof(TA) == 4) {
+        stage_batched<XH * XW, 256, 3, float4>(
+            tid,
+            [&](int i, bool& inside) {
+                const int r = i / XW, c = i - r * XW;
+                const int gy = ry - 1 + r, gx = rx - 1 + c;
+                inside = gy >= 0 && gy < hl && gx >= 0 && gx < wl;
+                return reinterpret_cast<const float4*>(xb + ((size_t)min(max(gy, 0), hl - 1) * wl + min(max(gx, 0), wl - 1)) * CH);
+            },
+            [&](int i, float4 v, bool inside) {
+                if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                xs[i] = v.x;
+                xs[XPLANE + i] = v.y;
+                xs[2 * XPLANE + i] = v.z;
+                xs[3 * XPLANE + i] = v.w;
+            });
+        return;
+    }
     for (int i = tid; i < XH * XW; i += 256) {
         const int r = i / XW, c = i - r * XW;
         const int gy = ry - 1 + r, gx = rx - 1 + c;
@@ -284,12 +302,24 @@ __global__ __launch_bounds__(256) void upconv_dgrad_kernel(const TA* __restrict_
     const int rx = blockIdx.x * RW, ry = blockIdx.y * RH;
     const int H = 2 * hl, W = 2 * wl;
     const TA* gb = dy + (size_t)blockIdx.z * H * W * CH;
-    for (int i = tid; i < GH * GW; i += 256) {
-        const int r = i / GW, c = i - r * GW;
-        const int gy = 2 * (ry - 1) + r, gx = 2 * (rx - 1) + c;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = ld4(gb + ((size_t)gy * W + gx) * CH);
-        gs[i] = v;
+    if constexpr (sizeof(TA) == 4) {
+        stage_batched<GH * GW, 256, 5, float4>(
+            tid,
+            [&](int i, bool& inside) {
+                const int r = i / GW, c = i - r * GW;
+                const int gy = 2 * (ry - 1) + r, gx = 2 * (rx - 1) + c;
+                inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                return reinterpret_cast<const float4*>(gb + ((size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * CH);
+            },
+            [&](int i, float4 v, bool inside) { gs[i] = inside ? v : make_float4(0.f, 0.f, 0.f, 0.f); });
+    } else {
+        for (int i = tid; i < GH * GW; i += 256) {
+            const int r = i / GW, c = i - r * GW;
+            const int gy = 2 * (ry - 1) + r, gx = 2 * (rx - 1) + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = ld4(gb + ((size_t)gy * W + gx) * CH);
+            gs[i] = v;
+        }
     }
     __syncthreads();
     const int c = tid & 31, r0 = tid >> 5;               // positions (r0, c) and (r0 + 8, c)
@@ -363,10 +393,22 @@ __global__ __launch_bounds__(256) void up1_fwd_kernel(const TA* __restrict__ xl,
     const int tid = threadIdx.x;
     const int rx = blockIdx.x * RW, ry = blockIdx.y * RH;
     const TA* xb = xl + (size_t)blockIdx.z * hl * wl;
-    for (int i = tid; i < XH * XW; i += 256) {
-        const int r = i / XW, c = i - r * XW;
-        const int gy = ry - 1 + r, gx = rx - 1 + c;
-        xs[i] = (gy >= 0 && gy < hl && gx >= 0 && gx < wl) ? ld1(xb + (size_t)gy * wl + gx) : 0.f;
+    if constexpr (sizeof(TA) == 4) {
+        stage_batched<XH * XW, 256, 3, float>(
+            tid,
+            [&](int i, bool& inside) {
+                const int r = i / XW, c = i - r * XW;
+                const int gy = ry - 1 + r, gx = rx - 1 + c;
+                inside = gy >= 0 && gy < hl && gx >= 0 && gx < wl;
+                return reinterpret_cast<const float*>(xb + (size_t)min(max(gy, 0), hl - 1) * wl + min(max(gx, 0), wl - 1));
+            },
+            [&](int i, float v, bool inside) { xs[i] = inside ? v : 0.f; });
+    } else {
+        for (int i = tid; i < XH * XW; i += 256) {
+            const int r = i / XW, c = i - r * XW;
+            const int gy = ry - 1 + r, gx = rx - 1 + c;
+            xs[i] = (gy >= 0 && gy < hl && gx >= 0 && gx < wl) ? ld1(xb + (size_t)gy * wl + gx) : 0.f;
+        }
     }
     float we[36];
     weff1_build(we, w);
@@ -403,10 +445,22 @@ __global__ __launch_bounds__(256) void up1_dgrad_kernel(const TA* __restrict__ d
     const int rx = blockIdx.x * RW, ry = blockIdx.y * RH;
     const int H = 2 * hl, W = 2 * wl;
     const TA* gb = dy + (size_t)blockIdx.z * H * W;
-    for (int i = tid; i < GH * GW; i += 256) {
-        const int r = i / GW, c = i - r * GW;
-        const int gy = 2 * (ry - 1) + r, gx = 2 * (rx - 1) + c;
-        gs[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? ld1(gb + (size_t)gy * W + gx) : 0.f;
+    if constexpr (sizeof(TA) == 4) {
+        stage_batched<GH * GW, 256, 10, float>(
+            tid,
+            [&](int i, bool& inside) {
+                const int r = i / GW, c = i - r * GW;
+                const int gy = 2 * (ry - 1) + r, gx = 2 * (rx - 1) + c;
+                inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+                return reinterpret_cast<const float*>(gb + (size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1));
+            },
+            [&](int i, float v, bool inside) { gs[i] = inside ? v : 0.f; });
+    } else {
+        for (int i = tid; i < GH * GW; i += 256) {
+            const int r = i / GW, c = i - r * GW;
+            const int gy = 2 * (ry - 1) + r, gx = 2 * (rx - 1) + c;
+            gs[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? ld1(gb + (size_t)gy * W + gx) : 0.f;
+        }
     }
     float we[36];
     weff1_build(we, w);
@@ -449,10 +503,22 @@ __global__ __launch_bounds__(256) void up1_wgrad_kernel(const TA* __restrict__ x
     for (int i = 0; i < 36; ++i) acc[i] = 0.f;
     for (int ry = row_begin; ry < row_end; ry += RH) {
         __syncthreads();
-        for (int i = tid; i < XH * XW; i += 256) {
-            const int r = i / XW, cc = i - r * XW;
-            const int gy = ry - 1 + r, gx = rx - 1 + cc;
-            xs[i] = (gy >= 0 && gy < hl && gx >= 0 && gx < wl) ? ld1(xb + (size_t)gy * wl + gx) : 0.f;
+        if constexpr (sizeof(TA) == 4) {
+            stage_batched<XH * XW, 256, 3, float>(
+                tid,
+                [&](int i, bool& inside) {
+                    const int r = i / XW, cc = i - r * XW;
+                    const int gy = ry - 1 + r, gx = rx - 1 + cc;
+                    inside = gy >= 0 && gy < hl && gx >= 0 && gx < wl;
+                    return reinterpret_cast<const float*>(xb + (size_t)min(max(gy, 0), hl - 1) * wl + min(max(gx, 0), wl - 1));
+                },
+                [&](int i, float v, bool inside) { xs[i] = inside ? v : 0.f; });
+        } else {
+            for (int i = tid; i < XH * XW; i += 256) {
+                const int r = i / XW, cc = i - r * XW;
+                const int gy = ry - 1 + r, gx = rx - 1 + cc;
+                xs[i] = (gy >= 0 && gy < hl && gx >= 0 && gx < wl) ? ld1(xb + (size_t)gy * wl + gx) : 0.f;
+            }
         }
         __syncthreads();
 #pragma unroll

@@ -265,6 +265,30 @@ __device__ __forceinline__ T act_grad_from_output(T y, int act, T alpha) {
     return T(1);
 }
 
+// A tile staging loop `for (i = tid; i < COUNT; i += NT) lds[i] = in_image(i) ? load(i) : fill` compiles to ONE load, a wait
+// and a store per trip: COUNT / NT global round trips in a row in front of every tile (ten for the dy tile of the upsample +
+// conv backward-data kernels).  Here a thread issues up to BATCH loads (clamped addresses, no branch) before it waits for the
+// first one; `addr(i, inside)` gives element i's clamped source pointer and whether it lies inside the image, `put(i, v,
+// inside)` stores it (or the fill value).
+template <int COUNT, int NT, int BATCH, typename V, typename Addr, typename Put>
+__device__ __forceinline__ void stage_batched(int tid, Addr addr, Put put) {
+    constexpr int K = (COUNT + NT - 1) / NT;
+#pragma unroll
+    for (int k0 = 0; k0 < K; k0 += BATCH) {
+        V v[BATCH];
+        bool in[BATCH];
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k)
+            if (k0 + k < K) v[k] = *addr(min(tid + NT * (k0 + k), COUNT - 1), in[k]);
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k)
+            if (k0 + k < K) {
+                const int i = tid + NT * (k0 + k);
+                if (i < COUNT) put(i, v[k], in[k]);
+            }
+    }
+}
+
 // Tile coordinates of a persistent block that walks t = blockIdx.x, += gridDim.x over tiles_x * tiles_y * images tiles:
 // the three integer divisions (no hardware divide: ~20 dependent instructions each, in front of the tile's first load)
 // are made once, for the first tile and for the stride; every further tile is three scalar adds with carries.
