@@ -393,23 +393,15 @@ __global__ __launch_bounds__(256) void up1_fwd_kernel(const TA* __restrict__ xl,
     const int tid = threadIdx.x;
     const int rx = blockIdx.x * RW, ry = blockIdx.y * RH;
     const TA* xb = xl + (size_t)blockIdx.z * hl * wl;
-    if constexpr (sizeof(TA) == 4) {
-        stage_batched<XH * XW, 256, 3, float>(
-            tid,
-            [&](int i, bool& inside) {
-                const int r = i / XW, c = i - r * XW;
-                const int gy = ry - 1 + r, gx = rx - 1 + c;
-                inside = gy >= 0 && gy < hl && gx >= 0 && gx < wl;
-                return reinterpret_cast<const float*>(xb + (size_t)min(max(gy, 0), hl - 1) * wl + min(max(gx, 0), wl - 1));
-            },
-            [&](int i, float v, bool inside) { xs[i] = inside ? v : 0.f; });
-    } else {
-        for (int i = tid; i < XH * XW; i += 256) {
+    stage_batched<XH * XW, 256, 3, TA>(
+        tid,
+        [&](int i, bool& inside) {
             const int r = i / XW, c = i - r * XW;
             const int gy = ry - 1 + r, gx = rx - 1 + c;
-            xs[i] = (gy >= 0 && gy < hl && gx >= 0 && gx < wl) ? ld1(xb + (size_t)gy * wl + gx) : 0.f;
-        }
-    }
+            inside = gy >= 0 && gy < hl && gx >= 0 && gx < wl;
+            return xb + (size_t)min(max(gy, 0), hl - 1) * wl + min(max(gx, 0), wl - 1);
+        },
+        [&](int i, TA v, bool inside) { xs[i] = inside ? (float)v : 0.f; });
     float we[36];
     weff1_build(we, w);
     const float b0 = use_bias ? bias[0] : 0.f;
@@ -445,23 +437,15 @@ __global__ __launch_bounds__(256) void up1_dgrad_kernel(const TA* __restrict__ d
     const int rx = blockIdx.x * RW, ry = blockIdx.y * RH;
     const int H = 2 * hl, W = 2 * wl;
     const TA* gb = dy + (size_t)blockIdx.z * H * W;
-    if constexpr (sizeof(TA) == 4) {
-        stage_batched<GH * GW, 256, 10, float>(
-            tid,
-            [&](int i, bool& inside) {
-                const int r = i / GW, c = i - r * GW;
-                const int gy = 2 * (ry - 1) + r, gx = 2 * (rx - 1) + c;
-                inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
-                return reinterpret_cast<const float*>(gb + (size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1));
-            },
-            [&](int i, float v, bool inside) { gs[i] = inside ? v : 0.f; });
-    } else {
-        for (int i = tid; i < GH * GW; i += 256) {
+    stage_batched<GH * GW, 256, 10, TA>(
+        tid,
+        [&](int i, bool& inside) {
             const int r = i / GW, c = i - r * GW;
             const int gy = 2 * (ry - 1) + r, gx = 2 * (rx - 1) + c;
-            gs[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? ld1(gb + (size_t)gy * W + gx) : 0.f;
-        }
-    }
+            inside = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            return gb + (size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1);
+        },
+        [&](int i, TA v, bool inside) { gs[i] = inside ? (float)v : 0.f; });
     float we[36];
     weff1_build(we, w);
     __syncthreads();
@@ -503,23 +487,15 @@ __global__ __launch_bounds__(256) void up1_wgrad_kernel(const TA* __restrict__ x
     for (int i = 0; i < 36; ++i) acc[i] = 0.f;
     for (int ry = row_begin; ry < row_end; ry += RH) {
         __syncthreads();
-        if constexpr (sizeof(TA) == 4) {
-            stage_batched<XH * XW, 256, 3, float>(
-                tid,
-                [&](int i, bool& inside) {
-                    const int r = i / XW, cc = i - r * XW;
-                    const int gy = ry - 1 + r, gx = rx - 1 + cc;
-                    inside = gy >= 0 && gy < hl && gx >= 0 && gx < wl;
-                    return reinterpret_cast<const float*>(xb + (size_t)min(max(gy, 0), hl - 1) * wl + min(max(gx, 0), wl - 1));
-                },
-                [&](int i, float v, bool inside) { xs[i] = inside ? v : 0.f; });
-        } else {
-            for (int i = tid; i < XH * XW; i += 256) {
+        stage_batched<XH * XW, 256, 3, TA>(
+            tid,
+            [&](int i, bool& inside) {
                 const int r = i / XW, cc = i - r * XW;
                 const int gy = ry - 1 + r, gx = rx - 1 + cc;
-                xs[i] = (gy >= 0 && gy < hl && gx >= 0 && gx < wl) ? ld1(xb + (size_t)gy * wl + gx) : 0.f;
-            }
-        }
+                inside = gy >= 0 && gy < hl && gx >= 0 && gx < wl;
+                return xb + (size_t)min(max(gy, 0), hl - 1) * wl + min(max(gx, 0), wl - 1);
+            },
+            [&](int i, TA v, bool inside) { xs[i] = inside ? (float)v : 0.f; });
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
