@@ -434,14 +434,29 @@ __global__ __launch_bounds__(256) void opt_fused_kernel(T* __restrict__ w, T* __
     if (threadIdx.x == 0) last = sync_arrive(counter) == gridDim.x - 1;       // (threads 0-3 are one wave: drained together)
     __syncthreads();
     if (!last) return;
+    // every partial this thread adds is requested before the first one is waited for (agent-scope loads take a trip to the
+    // memory side each; one range after the other, one block at a time was 3 x 3 of them in a row), block order kept
     __shared__ double red[16];
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    {
+        double t[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = threadIdx.x + 256 * k;
+                t[k][r] = (i < (int)gridDim.x && r < rr.n) ? pub_load(partial + (size_t)i * 4 + r) : 0.0;
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] += t[k][r];
+    }
     double total = 0.0;
     for (int r = 0; r < rr.n; ++r) {
-        double a = 0.0;
-        for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x) a += pub_load(partial + (size_t)i * 4 + r);
-        a = block_reduce_sum(a, red);
+        const double sum = block_reduce_sum(a[r], red);
         __syncthreads();
-        total += rr.strength[r] * a;
+        total += rr.strength[r] * sum;
     }
     if (threadIdx.x == 0) {
         *loss_out = total;
@@ -715,7 +730,10 @@ static int launch_opt_fused(uocr_ctx* ctx, int dtype, int opt, void* w, void* g,
     const size_t vec_bytes = 4 * (dtype == UOCR_F64 ? 8 : 4);
     const bool vec = aligned(w, vec_bytes) && aligned(g, vec_bytes) && aligned(s1, vec_bytes) &&
                      (opt == 0 || aligned(s2, vec_bytes));
-    const unsigned grid = uocr_blocks_for(vec ? (count + 3) / 4 : count, 256, 1024);
+    // with regulariser sums every block ends in a ticket on ONE counter (same-address atomics are served one after the other)
+    // and the last one adds all partials: a block per CU (802 k parameters, 3 ranges: 35.9 us at 784 blocks, 32.5 at 512,
+    // 30.2 at 256, 29.9 at 128 -- of which ~18 us are the benchmark's own loss-slot launches)
+    const unsigned grid = uocr_blocks_for(vec ? (count + 3) / 4 : count, 256, nranges > 0 ? 256u : 1024u);
     int rc = uocr_need_workspace(ctx, (size_t)grid * 4 * sizeof(double));
     if (rc) return rc;
     double* partial = (double*)ctx->workspace;

@@ -198,7 +198,18 @@ __device__ __forceinline__ void last_block_sum(unsigned* counter, double* partia
     __syncthreads();
     if (smem[16] == 0.0) return;                       // block-uniform
     double acc = 0.0;
-    for (int i = threadIdx.x; i < count; i += blockDim.x) acc += pub_load(partial + i);
+    if (count <= 4 * (int)blockDim.x) {                // (the usual case: all of a thread's partials requested at once)
+        double t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + k * blockDim.x;
+            t[k] = i < count ? pub_load(partial + i) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc += t[k];
+    } else {
+        for (int i = threadIdx.x; i < count; i += blockDim.x) acc += pub_load(partial + i);
+    }
     acc = block_reduce_sum(acc, smem);
     if (threadIdx.x == 0) {
         *out = scale * acc;
